@@ -1,0 +1,333 @@
+"""ORACLE (test infrastructure) — DSL dict -> phase table.
+
+Checker-side restatement of how the fixed policy reads the reference's YAML game
+DSL (`yaml.safe_load` output of /root/reference/games/*.yaml, loaded by
+agent/tools/utils.py:557-581).  Only tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg may import this module; the product has its own
+compiler in game_engine_amd/csrc/ge_table.cpp and the two are compared in
+tests/test_table.py.
+
+What the reference leaves to an LLM and this table pins down
+(POLICY.md is the normative text; numbers here must match it):
+
+* completion kind of a phase     <- phases.<id>.completion_criteria.type
+                                    (PhaseNode_system_prompt.txt:14-27)
+* who must act                   <- completion_criteria.target_players.condition
+                                    (bot_behavior_system_prompt.txt:21-50)
+* what an action means           <- action kind, classified from the condition,
+                                    phase name and tools (ww:218-311, tt phases 2/3/5)
+* what the Referee does when the
+  phase is entered               <- entry effect (referee_system_prompt_2.txt:1-8,19-22,75-82;
+                                    ww:2-9,316-317; tt description)
+* which next_phase branch wins   <- resolver per natural-language key, first
+                                    match in DSL order (PhaseNode_system_prompt.txt:44-56;
+                                    ww:435-447; tt "Check Round Progress")
+"""
+from __future__ import annotations
+
+import re
+from dataclasses import dataclass, field
+from typing import Any, Dict, List, Optional, Tuple
+
+# ---- enums shared (by value) with oracle/ge_oracle.c and, independently, with
+# ---- include/ge_step.h; tests/test_table.py checks the three agree.
+PACK_WEREWOLF = 1
+PACK_TWO_TRUTHS = 2
+
+COMP_UI = 0          # UI_displayed: complete by definition
+COMP_TIMER = 1       # timer: complete by definition
+COMP_ACTION = 2      # player_action: every target player has acted in this visit
+
+ACT_NONE = 0
+ACT_WOLF_TARGET = 1
+ACT_DOCTOR_PROTECT = 2
+ACT_DETECTIVE = 3
+ACT_DAY_VOTE = 4
+ACT_TT_STATEMENTS = 5
+ACT_TT_LIE = 6
+ACT_TT_VOTE = 7
+
+EFF_NONE = 0
+EFF_ASSIGN_ROLES = 1
+EFF_NIGHT_BEGIN = 2
+EFF_NIGHT_RESOLVE = 3
+EFF_DAY_RESOLVE = 4
+EFF_TT_ROUND_START = 5
+EFF_TT_REVEAL = 6
+EFF_TT_SCORE = 7
+
+RES_ALWAYS = 0
+RES_WOLVES_ZERO = 1
+RES_WOLVES_GE_VILLAGERS = 2
+RES_FOLLOWS_DAY = 3
+RES_FOLLOWS_NIGHT = 4
+RES_ALL_ROUNDS_DONE = 5
+RES_OTHERWISE = 6
+
+# base masks a condition term may test (bit index inside ge "predicate word")
+WW_BASE = {
+    ("is_alive", True): 0, ("can_vote", True): 1, ("role_revealed", True): 2,
+    ("has_secret_role", True): 3, ("night_action_eligible", True): 4,
+    ("night_action_submitted", True): 5,
+    ("team", "villagers"): 6, ("team", "werewolves"): 7,
+    ("role", 1): 8, ("role", 2): 9, ("role", 3): 10, ("role", 4): 11,
+}
+TT_BASE = {
+    ("is_speaker", True): 0, ("statements_submitted", True): 1, ("lie_revealed", True): 2,
+    ("can_vote", True): 3, ("has_voted", True): 4,
+}
+
+# role classes of the werewolf pack (index into declaration.roles is game data;
+# the *class* of each declared role is what the policy needs)
+ROLE_NONE, ROLE_VILLAGER, ROLE_WEREWOLF, ROLE_DOCTOR, ROLE_DETECTIVE = 0, 1, 2, 3, 4
+TEAM_NONE, TEAM_VILLAGERS, TEAM_WEREWOLVES = 0, 1, 2
+TEAM_NAMES = {TEAM_NONE: "", TEAM_VILLAGERS: "villagers", TEAM_WEREWOLVES: "werewolves"}
+
+MAX_TERMS = 4
+MAX_BRANCHES = 4
+MAX_PHASES = 32
+
+
+class DslError(ValueError):
+    pass
+
+
+@dataclass
+class Term:
+    field: str
+    value: Any            # True / "str" / number
+    negate: bool
+    base: int = -1        # base-mask index in the pack (filled by compile)
+
+
+@dataclass
+class Branch:
+    resolver: int
+    target_id: int        # DSL phase id
+    target_idx: int = -1  # dense index
+    key: str = ""
+
+
+@dataclass
+class Phase:
+    id: int
+    idx: int
+    name: str
+    completion: int
+    terms: List[Term] = field(default_factory=list)
+    act: int = ACT_NONE
+    effect: int = EFF_NONE
+    branches: List[Branch] = field(default_factory=list)
+    tools: List[str] = field(default_factory=list)
+
+
+@dataclass
+class Table:
+    pack: int
+    phases: List[Phase]
+    role_names: List[str]            # index = role class (ww); [""] for tt
+    template: Dict[str, Any]
+    rounds: int = 1                  # two-truths: agreed speaking turns per player
+    fields: List[str] = field(default_factory=list)
+
+    def idx_of(self, phase_id: int) -> int:
+        for p in self.phases:
+            if p.id == phase_id:
+                return p.idx
+        raise KeyError(phase_id)
+
+    def by_id(self, phase_id: int) -> Phase:
+        return self.phases[self.idx_of(phase_id)]
+
+
+_TERM_RE = re.compile(
+    r"^\s*player\.(\w+)\s*(==|!=)\s*(?:'([^']*)'|\"([^\"]*)\"|(true|false)|(-?\d+))\s*$", re.I)
+
+
+def parse_condition(cond: Optional[str]) -> List[Term]:
+    """`player.f == v and player.g == w` -> terms (ww:247,279,310,390; tt phases 2,3,5).
+
+    Only the conjunctive form the shipped phases use is accepted for phase targets;
+    anything else is a DslError rather than a guess."""
+    if not cond:
+        return []
+    terms: List[Term] = []
+    for part in re.split(r"\s+and\s+", cond.strip()):
+        m = _TERM_RE.match(part)
+        if not m:
+            raise DslError(f"unsupported condition term: {part!r}")
+        fld, op, s1, s2, b, n = m.groups()
+        if b is not None:
+            val, neg = True, (b.lower() == "false")
+        elif n is not None:
+            val, neg = int(n), False
+        else:
+            val, neg = (s1 if s1 is not None else s2), False
+        if op == "!=":
+            neg = not neg
+        terms.append(Term(fld, val, neg))
+    if len(terms) > MAX_TERMS:
+        raise DslError("too many condition terms")
+    return terms
+
+
+def _role_class(name: str) -> int:
+    n = name.lower()
+    if "wolf" in n or "mafia" in n:
+        return ROLE_WEREWOLF
+    if "doctor" in n or "medic" in n:
+        return ROLE_DOCTOR
+    if "detective" in n or "seer" in n:
+        return ROLE_DETECTIVE
+    return ROLE_VILLAGER
+
+
+def detect_pack(declaration: dict) -> int:
+    f = set((declaration.get("player_states") or {}).keys())
+    if {"role", "team", "is_alive", "selected_target_id"} <= f:
+        return PACK_WEREWOLF
+    if {"is_speaker", "lie_index", "vote_choice", "total_score"} <= f:
+        return PACK_TWO_TRUTHS
+    raise DslError("no rule pack matches declaration.player_states " + str(sorted(f)))
+
+
+def _resolver_for(key: str) -> int:
+    k = key.lower()
+    if "no living werewol" in k or "all werewolves eliminated" in k:
+        return RES_WOLVES_ZERO
+    if "outnumber" in k:
+        return RES_WOLVES_GE_VILLAGERS
+    if "follows a day" in k:
+        return RES_FOLLOWS_DAY
+    if "follows a night" in k:
+        return RES_FOLLOWS_NIGHT
+    if "all players have completed" in k:
+        return RES_ALL_ROUNDS_DONE
+    if k.startswith("otherwise"):
+        return RES_OTHERWISE
+    raise DslError(f"no branch resolver for next_phase key {key!r}")
+
+
+def _phase_items(phases: dict):
+    out = []
+    for k, v in phases.items():
+        out.append((int(k), v))      # yaml gives int keys, the JSON fixtures str keys
+    return out                        # DSL order is kept: phases table order = file order
+
+
+def compile_dsl(dsl: dict, rounds: int = 1) -> Table:
+    decl = dsl.get("declaration") or {}
+    pack = detect_pack(decl)
+    tmpl_all = ((decl.get("player_states_template") or {}).get("player_states") or {})
+    # utils.py:603-609: .get('1') misses yaml's int key, "first available id" is what runs
+    template = dict(tmpl_all.get("1") or (tmpl_all[next(iter(tmpl_all))] if tmpl_all else {}))
+    if pack == PACK_WEREWOLF:
+        role_names = [""] * 5
+        for r in decl.get("roles") or []:
+            c = _role_class(r["name"])
+            if not role_names[c]:
+                role_names[c] = r["name"]
+        if not all(role_names[1:]):
+            raise DslError("werewolf pack needs Villager/Werewolf/Doctor/Detective roles")
+        base = WW_BASE
+    else:
+        role_names = [""]
+        base = TT_BASE
+
+    items = _phase_items(dsl.get("phases") or {})
+    if not items or len(items) > MAX_PHASES:
+        raise DslError("phase count out of range")
+    idx_of = {pid: i for i, (pid, _) in enumerate(items)}
+    phases: List[Phase] = []
+    for i, (pid, ph) in enumerate(items):
+        cc = ph.get("completion_criteria") or {}
+        ctype = (cc.get("type") or "UI_displayed")
+        comp = {"ui_displayed": COMP_UI, "timer": COMP_TIMER, "player_action": COMP_ACTION}.get(ctype.lower())
+        if comp is None:
+            raise DslError(f"phase {pid}: unknown completion type {ctype!r}")
+        tools = [t for a in (ph.get("actions") or []) for t in (a.get("tools") or [])]
+        p = Phase(id=pid, idx=i, name=ph.get("name", f"Phase {pid}"), completion=comp, tools=tools)
+        text = (p.name + " " + (ph.get("description") or "")).lower()
+        if comp == COMP_ACTION:
+            p.terms = parse_condition(((cc.get("target_players") or {}).get("condition")))
+            for t in p.terms:
+                key = None
+                if t.field == "role" and pack == PACK_WEREWOLF:
+                    key = ("role", _role_class(str(t.value)))
+                elif isinstance(t.value, str):
+                    key = (t.field, t.value)
+                else:
+                    key = (t.field, True)
+                if key not in base:
+                    raise DslError(f"phase {pid}: condition field {t.field!r} not in rule pack")
+                t.base = base[key]
+            p.act = _classify_action(pack, p, text)
+        p.effect = _classify_effect(pack, p, text)
+        nxt = ph.get("next_phase")
+        if nxt is None:
+            pass
+        elif "id" in nxt and not isinstance(nxt.get("id"), dict):
+            p.branches = [Branch(RES_ALWAYS, int(nxt["id"]))]
+        else:
+            for key, tgt in nxt.items():
+                p.branches.append(Branch(_resolver_for(str(key)), int(tgt["id"]), key=str(key)))
+        if len(p.branches) > MAX_BRANCHES:
+            raise DslError(f"phase {pid}: too many branches")
+        phases.append(p)
+    for p in phases:
+        for b in p.branches:
+            if b.target_id not in idx_of:
+                raise DslError(f"phase {p.id}: next_phase id {b.target_id} not in phases")
+            b.target_idx = idx_of[b.target_id]
+    # a night begins at the first wolf-target phase reached from a non-night phase
+    for p in phases:
+        if p.act == ACT_WOLF_TARGET and p.effect == EFF_NONE:
+            p.effect = EFF_NIGHT_BEGIN
+    return Table(pack=pack, phases=phases, role_names=role_names, template=template,
+                 rounds=rounds, fields=list((decl.get("player_states") or {}).keys()))
+
+
+def _classify_action(pack: int, p: Phase, text: str) -> int:
+    bases = {(t.base, t.negate) for t in p.terms}
+    if pack == PACK_WEREWOLF:
+        if (WW_BASE[("role", ROLE_WEREWOLF)], False) in bases:
+            return ACT_WOLF_TARGET
+        if (WW_BASE[("role", ROLE_DOCTOR)], False) in bases:
+            return ACT_DOCTOR_PROTECT
+        if (WW_BASE[("role", ROLE_DETECTIVE)], False) in bases:
+            return ACT_DETECTIVE
+        if (WW_BASE[("can_vote", True)], False) in bases:
+            return ACT_DAY_VOTE
+    else:
+        if (TT_BASE[("is_speaker", True)], True) in bases:
+            return ACT_TT_VOTE
+        if (TT_BASE[("is_speaker", True)], False) in bases:
+            if "createTextInputPanel" in p.tools or "statement" in p.name.lower():
+                return ACT_TT_STATEMENTS
+            return ACT_TT_LIE
+    raise DslError(f"phase {p.id}: cannot classify player action {[(t.field, t.value) for t in p.terms]}")
+
+
+def _classify_effect(pack: int, p: Phase, text: str) -> int:
+    name = p.name.lower()
+    if pack == PACK_WEREWOLF:
+        if "role assignment" in name or "assign roles" in text:
+            return EFF_ASSIGN_ROLES
+        if "markPlayerDead" in p.tools:
+            if "night" in text:
+                return EFF_NIGHT_RESOLVE
+            if "vot" in text:
+                return EFF_DAY_RESOLVE
+        return EFF_NONE
+    if "round start" in name:
+        return EFF_TT_ROUND_START
+    if "reveal" in name:
+        return EFF_TT_REVEAL
+    if "scoring" in name:
+        return EFF_TT_SCORE
+    return EFF_NONE
+
+
+def wolves_for(n_players: int) -> int:
+    """role_assignment_system_prompt.txt:13,19-20: ~20-30 % wolves, 1-2 for 5-7, 2-3 for 8+."""
+    return max(1, n_players // 4)

@@ -1,0 +1,132 @@
+"""ORACLE (test infrastructure) — ctypes front of oracle/ge_oracle.c.
+
+`Oracle(dsl_dict, n_players)` compiles the DSL with oracle/dsl_table.py, feeds the
+table to the C restatement and returns canonical projections
+([phase_id, prev_phase_id, phase0_done, end_turn] + 11 ints per player
+ (+ detective memory per player for the werewolf pack)) — the same list the
+reference harness (oracle/refharness/walker.py:project_state) produces.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import List
+
+import numpy as np
+
+from . import dsl_table as T
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "libge_oracle.so")
+
+
+class _Phase(C.Structure):
+    _fields_ = [("completion", C.c_uint8), ("act", C.c_uint8), ("effect", C.c_uint8),
+                ("n_terms", C.c_uint8), ("n_branches", C.c_uint8), ("pad", C.c_uint8 * 3),
+                ("term_base", C.c_uint8 * 4), ("term_neg", C.c_uint8 * 4),
+                ("br_res", C.c_uint8 * 4), ("br_target", C.c_uint8 * 4),
+                ("phase_id", C.c_int32)]
+
+
+class _Table(C.Structure):
+    _fields_ = [("pack", C.c_int32), ("n_phases", C.c_int32), ("rounds", C.c_int32), ("pad", C.c_int32),
+                ("init_fields", C.c_uint8 * 12), ("pad2", C.c_uint8 * 4), ("ph", _Phase * 32)]
+
+
+ROOM_DTYPE = np.dtype([("phase", "u1"), ("prev", "u1"), ("phase0_done", "u1"), ("n", "u1"),
+                       ("end_turn", "<i4"), ("p", "u1", (16, 12)), ("det", "u1", (16,))])
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "ge_oracle.c")
+    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "libge_oracle.so"])
+    return _LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+        _lib.orc_room_init.argtypes = [C.POINTER(_Table), C.c_int, C.c_void_p]
+        _lib.orc_run.argtypes = [C.POINTER(_Table), C.c_uint64, C.c_uint64, C.c_uint64,
+                                 C.c_uint32, C.c_uint32, C.c_void_p, C.c_int]
+        assert _lib.orc_sizeof_room() == ROOM_DTYPE.itemsize
+        assert _lib.orc_sizeof_table() == C.sizeof(_Table)
+    return _lib
+
+
+def _init_fields(table: T.Table) -> List[int]:
+    t = table.template
+    if table.pack == T.PACK_WEREWOLF:
+        team = {"": 0, "villagers": 1, "werewolves": 2}[t.get("team", "")]
+        role = table.role_names.index(t.get("role", "")) if t.get("role", "") in table.role_names else 0
+        f = [role, team, int(bool(t.get("is_alive", True))), int(bool(t.get("role_revealed"))),
+             int(bool(t.get("can_vote"))), int(bool(t.get("has_secret_role"))),
+             int(bool(t.get("night_action_eligible"))), int(bool(t.get("night_action_submitted"))),
+             int(t.get("selected_target_id") or 0), 0, 0]
+    else:
+        f = [int(bool(t.get("is_speaker"))), int(bool(t.get("statements_submitted"))),
+             int(t.get("lie_index") or 0), int(bool(t.get("lie_revealed"))), int(bool(t.get("can_vote"))),
+             int(t.get("vote_choice") or 0), int(bool(t.get("has_voted"))), int(t.get("total_score") or 0),
+             int(t.get("rounds_as_speaker") or 0), 0, 0]
+    return f + [0]
+
+
+class Oracle:
+    def __init__(self, dsl: dict, n_players: int, rounds: int = 1):
+        self.table = T.compile_dsl(dsl, rounds=rounds)
+        self.n = n_players
+        lo = 4 if self.table.pack == T.PACK_WEREWOLF else 3        # declaration.min_players
+        if not lo <= n_players <= 12:
+            raise ValueError("n_players out of range")
+        ct = _Table()
+        ct.pack, ct.n_phases, ct.rounds = self.table.pack, len(self.table.phases), rounds
+        for i, v in enumerate(_init_fields(self.table)):
+            ct.init_fields[i] = v
+        for p in self.table.phases:
+            cp = ct.ph[p.idx]
+            cp.completion, cp.act, cp.effect = p.completion, p.act, p.effect
+            cp.n_terms, cp.n_branches, cp.phase_id = len(p.terms), len(p.branches), p.id
+            for k, t in enumerate(p.terms):
+                cp.term_base[k], cp.term_neg[k] = t.base, int(t.negate)
+            for k, b in enumerate(p.branches):
+                cp.br_res[k], cp.br_target[k] = b.resolver, b.target_idx
+        self.ct = ct
+        self.ids = [p.id for p in self.table.phases]
+
+    def init_rooms(self, n_rooms: int) -> np.ndarray:
+        rooms = np.zeros(n_rooms, dtype=ROOM_DTYPE)
+        one = np.zeros(1, dtype=ROOM_DTYPE)
+        lib().orc_room_init(C.byref(self.ct), self.n, one.ctypes.data)
+        rooms[:] = one[0]
+        return rooms
+
+    def run(self, rooms: np.ndarray, seed: int, first_room: int, first_turn: int, n_turns: int,
+            threads: int = 1) -> None:
+        assert rooms.dtype == ROOM_DTYPE and rooms.flags.c_contiguous
+        lib().orc_run(C.byref(self.ct), seed, first_room, len(rooms), first_turn, n_turns,
+                      rooms.ctypes.data, threads)
+
+    def project(self, room) -> List[int]:
+        out = [self.ids[int(room["phase"])], self.ids[int(room["prev"])], int(room["phase0_done"]),
+               int(room["end_turn"])]
+        for i in range(self.n):
+            out += [int(x) for x in room["p"][i][:11]]
+        if self.table.pack == T.PACK_WEREWOLF:
+            out += [int(x) for x in room["det"][: self.n]]
+        return out
+
+    def trajectory(self, seed: int, room_index: int, n_turns: int) -> List[List[int]]:
+        rooms = self.init_rooms(1)
+        out = []
+        for t in range(n_turns):
+            self.run(rooms, seed, room_index, t, 1)
+            out.append(self.project(rooms[0]))
+        return out

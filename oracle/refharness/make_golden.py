@@ -1,0 +1,67 @@
+"""Generates tests/golden/*.json by running the REFERENCE's node coroutines
+(/root/reference/agent/game_agent_v2.py, and v3 as a cross-check) under FixedPolicy.
+
+Build container only (needs /root/reference).  Run:  python -m oracle.refharness.make_golden
+Outputs (committed; data only — inputs and expected integer projections):
+  tests/golden/dsl/<game>.json          yaml.safe_load of /root/reference/games/<game>.yaml
+  tests/golden/traj_<game>_n<N>.json    per (seed, room): projection after every turn
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+
+import yaml
+
+from .walker import REFERENCE_ROOT, RoomSession
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+GOLD = os.path.join(ROOT, "tests", "golden")
+SEEDS = [0, 1, 0xC0FFEE]
+CASES = [                                # (game, n_players, rooms, turns, rounds)
+    ("werewolf-(mafia)", 8, [0, 1, 2, 65535], 72, 1),
+    ("werewolf-(mafia)", 12, [0, 1, 16777215], 96, 1),
+    ("werewolf-(mafia)", 4, [0, 5], 48, 1),
+    ("werewolf-(mafia)", 5, [0, 3], 48, 1),
+    ("werewolf-(mafia)", 7, [2], 64, 1),
+    ("two-truths-and-a-lie", 4, [0, 1, 2, 1048575], 64, 1),
+    ("two-truths-and-a-lie", 3, [0, 9], 48, 1),
+    ("two-truths-and-a-lie", 6, [4], 160, 2),
+    ("two-truths-and-a-lie", 12, [1], 200, 1),
+]
+
+
+def main():
+    os.makedirs(os.path.join(GOLD, "dsl"), exist_ok=True)
+    for game in sorted({c[0] for c in CASES}):
+        with open(os.path.join(REFERENCE_ROOT, "games", f"{game}.yaml"), encoding="utf-8") as f:
+            dsl = yaml.safe_load(f)
+        with open(os.path.join(GOLD, "dsl", f"{game}.json"), "w", encoding="utf-8") as f:
+            json.dump(dsl, f, ensure_ascii=False, indent=1)
+    for game, n, rooms, turns, rounds in CASES:
+        cases = []
+        for seed in SEEDS:
+            for room in rooms:
+                a = RoomSession(game, n, seed, room, "v2", rounds)
+                b = RoomSession(game, n, seed, room, "v3", rounds)
+                traj = []
+                for t in range(turns):
+                    a.step()
+                    b.step()
+                    pa = a.project()
+                    assert pa == b.project(), (game, n, seed, room, t, "v2 != v3")
+                    traj.append(pa)
+                assert traj[-1][3] >= 0, (game, n, seed, room, "did not finish; raise turns")
+                cases.append({"seed": seed, "room": room, "turns": traj})
+                print(game, n, hex(seed), room, "end_turn", traj[-1][3], file=sys.stderr)
+        name = f"traj_{game.split('-(')[0].replace('-', '_')}_n{n}.json"
+        with open(os.path.join(GOLD, name), "w") as f:
+            json.dump({"game": game, "n_players": n, "rounds": rounds,
+                       "source": "reference game_agent_v2 + v3 nodes under oracle/refharness FixedPolicy",
+                       "layout": "[phase, prev_phase, phase0_done, end_turn] + 11/player (+ det/player for werewolf)",
+                       "cases": cases}, f, separators=(",", ":"))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,30 @@
+"""Pins the oracle (oracle/ge_oracle.c via oracle/oracle.py) against golden vectors that were
+produced by running the REFERENCE's own node coroutines (game_agent_v2.py / v3) under the
+fixed policy — turn by turn, bit-exact.  CPU only."""
+import pytest
+
+from conftest import golden_files, load_dsl, load_golden
+from oracle.oracle import Oracle
+
+
+@pytest.mark.parametrize("name", golden_files())
+def test_oracle_matches_reference_trajectories(name):
+    g = load_golden(name)
+    orc = Oracle(load_dsl(g["game"]), g["n_players"], rounds=g["rounds"])
+    for case in g["cases"]:
+        got = orc.trajectory(case["seed"], case["room"], len(case["turns"]))
+        for t, (a, b) in enumerate(zip(got, case["turns"])):
+            assert a == b, f"{name} seed={case['seed']:#x} room={case['room']} turn={t}"
+
+
+def test_oracle_batched_equals_stepwise(dsl_ww):
+    """orc_run over many rooms/turns == per-turn stepping; threads do not change results."""
+    import numpy as np
+    orc = Oracle(dsl_ww, 8)
+    a = orc.init_rooms(257)
+    b = orc.init_rooms(257)
+    orc.run(a, 0xC0FFEE, 1000, 0, 64, threads=1)
+    for t in range(64):
+        orc.run(b, 0xC0FFEE, 1000, t, 1, threads=4)
+    assert a.tobytes() == b.tobytes()
+    assert (a["end_turn"] >= 0).mean() > 0.5
