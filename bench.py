@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""bench.py — room-phase steps/sec of the batch stepper on N MI355X of one node.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]          (N>1: launched by torch.distributed.run)
+
+Workload (BASELINE.json configs[1], per GPU): 65 536 Werewolf rooms x 8 players,
+games/werewolf-(mafia).yaml, all players bots, LLM replaced by the fixed policy, in STEADY STATE
+(a finished room is recycled into a new game on its next turn) so that every one of the K timed
+steps advances every room through real game logic.  A "step" = one turn (= one LangGraph run in
+the reference) of every room of the batch.  Inputs are resident in HBM before the timed region.
+
+Prints ONE JSON line on rank 0 (contract in the task brief) with `roofline` (dominant kernel, HIP
+events on the launch stream) and `cpu_baseline` (the oracle's C restatement on the host cores;
+the ONLY place bench.py touches oracle/).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+ROOMS_PER_GPU = 65536
+N_PLAYERS = 8
+GAME = "werewolf-(mafia)"
+SEED = 0xC0FFEE
+
+
+def load_dsl():
+    with open(os.path.join(ROOT, "tests", "golden", "dsl", f"{GAME}.json"), encoding="utf-8") as f:
+        return json.load(f)
+
+
+def cpu_baseline(dsl, budget_s=12.0):
+    """The oracle (a scalar C port of the reference loop + policy) on this host's cores, on a
+    bounded sample of the same steady-state workload."""
+    from oracle.oracle import Oracle
+    cores = len(os.sched_getaffinity(0))
+    orc = Oracle(dsl, N_PLAYERS)
+    rooms = orc.init_rooms(ROOMS_PER_GPU)
+    t0 = time.perf_counter()
+    orc.run(rooms, SEED, 0, 0, 16, threads=cores, restart=True)        # calibrate
+    dt = max(time.perf_counter() - t0, 1e-4)
+    turns = int(min(max(16 * budget_s / dt, 64), 4096))
+    rooms = orc.init_rooms(ROOMS_PER_GPU)
+    t0 = time.perf_counter()
+    orc.run(rooms, SEED, 0, 0, turns, threads=cores, restart=True)
+    dt_all = time.perf_counter() - t0
+    one = orc.init_rooms(4096)
+    t1 = max(turns // 8, 16)
+    t0 = time.perf_counter()
+    orc.run(one, SEED, 0, 0, t1, threads=1, restart=True)
+    dt_one = time.perf_counter() - t0
+    return {"value": ROOMS_PER_GPU * turns / dt_all, "unit": "room-phase steps/s", "cores": cores,
+            "kind": "port",
+            "sample": f"{ROOMS_PER_GPU} werewolf x{N_PLAYERS} rooms x {turns} turns, steady state, OpenMP over rooms",
+            "single_thread_value": 4096 * t1 / dt_one}
+
+
+def pmc_traffic(bytes_per_room):
+    """HBM bytes per launch from a committed rocprofv3 --pmc pass of this same command
+    (profiles/*pmc_traffic.json, written by tools/pmc_summary.py), or None."""
+    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(p):
+        return None
+    try:
+        with open(p) as f:
+            return json.load(f).get("bytes_per_launch")
+    except Exception:
+        return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4096)
+    ap.add_argument("--warmup", type=int, default=256)
+    ap.add_argument("--fuse", type=int, default=64, help="turns fused per launch (1 = one launch per turn)")
+    ap.add_argument("--rooms", type=int, default=ROOMS_PER_GPU, help="rooms per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from game_engine_amd import GameTable, RoomBatch
+    from game_engine_amd.dist import allgather_summary, shard_first_room
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the stepper has no CPU path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    dsl = load_dsl()
+    table = GameTable(dsl)
+    rooms = args.rooms
+    batch = RoomBatch([(table, N_PLAYERS, rooms)], seed=SEED, first_room=shard_first_room(rooms, rank),
+                      device=local_rank, max_fuse=args.fuse, restart=True)
+    bytes_per_room = batch.bytes_per_room(0)          # record size; B = 2x (read + written once per turn)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    batch.step(args.warmup, stream)                   # untimed; also brings the batch to steady state
+    batch.sync()
+    batch.set_timing(True)
+    batch.kernel_time(reset=True)
+    barrier()
+    t0 = time.perf_counter()
+    batch.step(args.steps, stream)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms, launches = batch.kernel_time(reset=True)
+    batch.set_timing(False)
+
+    t_el = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
+    elapsed = float(t_el.item())
+
+    # the one collective of the path: all-gather of the per-GPU summary (RCCL over xGMI)
+    ts = time.perf_counter()
+    summary = allgather_summary(batch, world)
+    barrier()
+    summary_ms = (time.perf_counter() - ts) * 1e3
+
+    # un-fused reference point: one launch per turn, same workload, short
+    unfused = None
+    if rank == 0:
+        b1 = RoomBatch([(table, N_PLAYERS, rooms)], seed=SEED, device=local_rank, max_fuse=1, restart=True)
+        b1.step(64, stream); b1.sync()
+        b1.set_timing(True); b1.kernel_time(reset=True)
+        t1 = time.perf_counter()
+        b1.step(256, stream); b1.sync()
+        w1 = time.perf_counter() - t1
+        k1, l1 = b1.kernel_time(reset=True)
+        unfused = {"value": rooms * 256 / w1, "ms_per_step": w1 * 1e3 / 256, "kernel_us_per_launch": k1 * 1e3 / max(l1, 1),
+                   "achieved_GBs": 2 * bytes_per_room * rooms / (k1 * 1e-3 / max(l1, 1)) / 1e9}
+        b1.close()
+
+    if rank == 0:
+        total_steps = rooms * world * args.steps
+        per_launch_units = rooms * (args.steps / max(launches, 1))
+        alg_bytes = 2 * bytes_per_room * per_launch_units
+        avg_launch_s = kernel_ms * 1e-3 / max(launches, 1)
+        achieved = alg_bytes / avg_launch_s / 1e9
+        out = {
+            "metric": "room-phase steps/sec", "value": total_steps / elapsed, "unit": "room-phase steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "config": {"workload": f"{rooms} Werewolf rooms x {N_PLAYERS} players per GPU, games/werewolf-(mafia).yaml, "
+                                   "steady state (finished rooms recycled), fixed policy, seed 0xC0FFEE",
+                       "rooms_per_gpu": rooms, "n_players": N_PLAYERS, "turns_fused_per_launch": args.fuse,
+                       "bytes_per_room_record": bytes_per_room, "sharding": f"rooms x{world}, no data-path collective"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(bytes_per_room),
+                         "kernel": "ge_step_kernel", "avg_launch_us": avg_launch_s * 1e6, "launches": launches,
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "note": "algorithmic bytes = 2 x record x rooms x turns in the launch; with fused turns the "
+                                 "state stays in registers, so real HBM traffic is ~1/fuse of this (see traffic)"},
+            "unfused": unfused,
+            "summary": {k: summary[k] for k in ("rooms", "finished", "village_wins", "wolf_wins", "games_recycled", "checksum")},
+            "summary_allgather_ms": summary_ms,
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(dsl)
+        print(json.dumps(out))
+    batch.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

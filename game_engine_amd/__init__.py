@@ -1,0 +1,11 @@
+"""game_engine_amd — MI355X-native batch room-phase stepper.
+
+Host-side Python mirror of the one reference path this repository accelerates: the per-turn
+loop of liruihan000/game_engine (agent/game_agent_v2.py:1571-1587).  All compute is in
+libge_step.so (HIP, gfx950) behind the C ABI of include/ge_step.h; there is no CPU fallback.
+"""
+from .stepper import (GameTable, RoomBatch, GeError, load_dsl_by_gamename, library_path,
+                      ROOM_VIEW_DTYPE, WW_FIELDS, TT_FIELDS)
+
+__all__ = ["GameTable", "RoomBatch", "GeError", "load_dsl_by_gamename", "library_path",
+           "ROOM_VIEW_DTYPE", "WW_FIELDS", "TT_FIELDS"]

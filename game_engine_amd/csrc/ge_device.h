@@ -1,0 +1,322 @@
+// ge_device.h — one turn of one room, in registers, for gfx950.
+//
+// What a turn is: one graph run of the reference,
+//   BotBehaviorNode (agent/game_agent_v2.py:468) -> PhaseNode (:987) -> RefereeNode (:619),
+// with the LLM decisions fixed by POLICY.md.  Lane = room: a 64-wide wavefront advances 64
+// independent rooms; all per-player work inside a room is bit-parallel over N-bit masks
+// (ge_layout.h), so there is no cross-lane traffic on the step path at all.
+// Integer / branchy code: no MFMA (there is no contraction here), VALU + a little LDS
+// (the phase table, 16 B per row).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "ge_layout.h"
+
+namespace ge {
+
+enum { COMP_UI = 0, COMP_TIMER = 1, COMP_ACTION = 2 };
+enum { ACT_NONE = 0, ACT_WOLF_TARGET, ACT_DOCTOR_PROTECT, ACT_DETECTIVE, ACT_DAY_VOTE,
+       ACT_TT_STATEMENTS, ACT_TT_LIE, ACT_TT_VOTE };
+enum { EFF_NONE = 0, EFF_ASSIGN_ROLES, EFF_NIGHT_BEGIN, EFF_NIGHT_RESOLVE, EFF_DAY_RESOLVE,
+       EFF_TT_ROUND_START, EFF_TT_REVEAL, EFF_TT_SCORE };
+enum { RES_ALWAYS = 0, RES_WOLVES_ZERO, RES_WOLVES_GE_VILLAGERS, RES_FOLLOWS_DAY, RES_FOLLOWS_NIGHT,
+       RES_ALL_ROUNDS_DONE, RES_OTHERWISE };
+
+constexpr uint32_t GOLDEN = 0x9E3779B9u;
+
+// ---- POLICY.md §RNG: stateless 32-bit counter hash
+GE_HD uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    return x;
+}
+GE_HD uint32_t room_key(uint32_t seed_lo, uint32_t seed_hi, uint64_t room) {
+    uint32_t k = mix32(seed_lo ^ 0x243F6A88u);
+    k = mix32(k ^ seed_hi);
+    k = mix32(k ^ (uint32_t)room);
+    k = mix32(k ^ (uint32_t)(room >> 32));
+    return k;
+}
+GE_HD uint32_t turn_key(uint32_t rk, uint32_t turn) { return mix32(rk ^ (turn * GOLDEN)); }
+GE_HD uint32_t draw(uint32_t tk, uint32_t idx) { return mix32(tk + (idx + 1u) * GOLDEN); }
+
+#if defined(__HIPCC__)
+__device__ __forceinline__ uint32_t pick(uint32_t d, uint32_t k) { return __umulhi(d, k); }
+__device__ __forceinline__ uint32_t popc(uint32_t x) { return (uint32_t)__popc(x); }
+__device__ __forceinline__ uint32_t ctz(uint32_t x) { return (uint32_t)__ffs((int)x) - 1u; }
+
+// position of the n-th (0-based) set bit of a <=16-bit mask; the bit must exist
+template <int NB> __device__ __forceinline__ uint32_t nth_set_bit(uint32_t m, uint32_t n) {
+    uint32_t pos = 0, c;
+    if (NB > 8) { c = popc(m & 0xFFu); if (n >= c) { n -= c; pos = 8; m >>= 8; } }
+    c = popc(m & 0xFu); if (n >= c) { n -= c; pos += 4; m >>= 4; }
+    c = popc(m & 0x3u); if (n >= c) { n -= c; pos += 2; m >>= 2; }
+    c = m & 1u;         if (n >= c) { pos += 1; }
+    return pos;
+}
+
+// 1-based id with the most votes among `voters`, ties -> lowest id, 0 if nobody voted.
+// votes: one nibble per player (1-based target id, 0 = none).  Counters are nibbles too
+// (<= 12 voters), so the whole tally is one or two registers.
+template <int NB, typename nib_t>
+__device__ __forceinline__ uint32_t plurality(nib_t votes, uint32_t voters) {
+    nib_t tally = 0;
+#pragma unroll
+    for (int i = 0; i < NB; i++) {
+        uint32_t c = (uint32_t)(votes >> (4 * i)) & 15u;
+        bool ok = ((voters >> i) & 1u) && c != 0u;
+        tally += ok ? (nib_t(1) << (4u * (c - 1u))) : nib_t(0);
+    }
+    uint32_t best = 0, arg = 0;
+#pragma unroll
+    for (int k = 0; k < NB; k++) {
+        uint32_t cnt = (uint32_t)(tally >> (4 * k)) & 15u;
+        bool gt = cnt > best;
+        best = gt ? cnt : best;
+        arg = gt ? (uint32_t)(k + 1) : arg;
+    }
+    return arg;
+}
+
+// ------------------------------------------------------------------ werewolf
+template <int NB>
+__device__ __forceinline__ void ww_turn(WW<NB> &s, const DevRow *rows, uint32_t n, uint32_t nw,
+                                        uint32_t phase0_idx, uint32_t rkey, uint32_t turn) {
+    using nib_t = typename WW<NB>::nib_t;
+    const uint32_t ALL = (1u << n) - 1u;
+    const DevRow row = rows[s.phase];
+    const uint32_t comp = row.r0 & 3u, act = (row.r0 >> 2) & 7u, p_eff = (row.r0 >> 5) & 7u;
+    const uint32_t nterms = (row.r0 >> 8) & 7u, nbr = (row.r0 >> 11) & 7u;
+    const uint32_t tk = turn_key(rkey, turn);
+
+    const uint32_t nrb2 = ~s.rb2;
+    const uint32_t r_vil = s.rb0 & ~s.rb1 & nrb2, r_wolf = ~s.rb0 & s.rb1 & nrb2;
+    const uint32_t r_doc = s.rb0 & s.rb1 & nrb2, r_det = s.rb2 & ~s.rb1 & ~s.rb0;
+
+    // ---- who must act: target_players.condition AND alive, all players at once
+    uint32_t T = 0;
+    if (comp == COMP_ACTION) {
+        T = s.alive;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t b = (row.r1 >> (4 * j)) & 15u;
+            uint32_t m = s.alive;
+            m = b == 1 ? s.can_vote : m;  m = b == 2 ? s.revealed : m;  m = b == 3 ? s.secret : m;
+            m = b == 4 ? s.elig : m;      m = b == 5 ? s.sub : m;       m = b == 6 ? s.team_v : m;
+            m = b == 7 ? s.team_w : m;    m = b == 8 ? r_vil : m;       m = b == 9 ? r_wolf : m;
+            m = b == 10 ? r_doc : m;      m = b == 11 ? r_det : m;
+            m = ((row.r0 >> (16 + j)) & 1u) ? ~m : m;
+            T &= (uint32_t)j < nterms ? m : 0xFFFFFFFFu;
+        }
+        T &= ALL;
+    }
+
+    // ---- BotBehaviorNode: every due bot acts with probability 3/4, one action per visit
+    uint32_t newly = 0, new_det_v = 0, new_det_w = 0;
+    {
+        uint32_t todo = T & ~s.acted;
+        const uint32_t known = s.det_v | s.det_w;
+        const uint32_t kw_alive = s.det_w & s.alive;
+        const uint32_t non_wolf = s.alive & ~s.team_w;
+        while (todo) {
+            const uint32_t i = ctz(todo);
+            const uint32_t me = 1u << i;
+            todo &= todo - 1u;
+            const uint32_t d = draw(tk, i);
+            if ((d & 3u) == 0u) continue;
+            uint32_t cand = s.alive;                                   // ACT_DOCTOR_PROTECT
+            if (act == ACT_WOLF_TARGET) cand = non_wolf;
+            if (act == ACT_DETECTIVE) {
+                const uint32_t others = s.alive & ~me;
+                cand = others & ~known;
+                cand = cand ? cand : others;
+            }
+            if (act == ACT_DAY_VOTE) {
+                cand = s.alive & ~me;
+                if (s.team_w & me) cand = non_wolf;
+                else if ((r_det & me) && kw_alive) cand = kw_alive & (0u - kw_alive);
+            }
+            cand = cand ? cand : s.alive;
+            const uint32_t c = nth_set_bit<NB>(cand, pick(d, popc(cand))) + 1u;
+            const uint32_t sh = 4u * i;
+            s.choice = (s.choice & ~(nib_t(15) << sh)) | (nib_t(c) << sh);
+            newly |= me;
+            // RefereeNode (A): record the action (bt:204-225 update_player_state)
+            if (act <= ACT_DETECTIVE) {
+                s.sel = (s.sel & ~(nib_t(15) << sh)) | (nib_t(c) << sh);
+                if (act == ACT_DETECTIVE) {
+                    const uint32_t tb = 1u << (c - 1u);
+                    if (s.team_w & tb) new_det_w |= tb; else new_det_v |= tb;
+                }
+            }
+        }
+    }
+    s.acted |= newly;
+    if (act >= ACT_WOLF_TARGET && act <= ACT_DETECTIVE) s.sub |= newly;
+
+    // ---- PhaseNode: phase-0 guard (v2:1025-1052): first turn only records phase 0, Referee skipped
+    if (s.phase == phase0_idx && !(s.flags & FLAG_PHASE0_DONE)) {
+        s.flags |= FLAG_PHASE0_DONE;
+        return;
+    }
+    uint32_t q = s.phase;
+    if (nbr != 0u && (comp != COMP_ACTION || (T & ~s.acted) == 0u)) {
+        const uint32_t w = popc(s.alive & s.team_w), g = popc(s.alive & s.team_v);
+        const uint32_t prev_eff = (s.flags >> 1) & 7u;
+        const uint32_t C = 1u | ((w == 0u) << RES_WOLVES_ZERO) | ((w >= g) << RES_WOLVES_GE_VILLAGERS) |
+                           ((prev_eff == EFF_DAY_RESOLVE) << RES_FOLLOWS_DAY) |
+                           ((prev_eff == EFF_NIGHT_RESOLVE) << RES_FOLLOWS_NIGHT) | (1u << RES_OTHERWISE);
+#pragma unroll
+        for (int b = 3; b >= 0; b--) {
+            const uint32_t res = (row.r2 >> (4 * b)) & 15u;
+            const bool ok = (uint32_t)b < nbr && ((C >> res) & 1u);
+            q = ok ? ((row.r3 >> (8 * b)) & 255u) : q;
+        }
+    }
+    s.det_v |= new_det_v;
+    s.det_w |= new_det_w;
+    if (q == s.phase) return;
+
+    // ---- RefereeNode (B): effect of entering q
+    const uint32_t q0 = rows[q].r0;
+    const uint32_t eff = (q0 >> 5) & 7u;
+    if (eff == EFF_ASSIGN_ROLES) {
+        uint32_t rem = ALL, wolves = 0, doc = 0, det = 0;
+        for (uint32_t j = 0; j < nw + 2u; j++) {
+            const uint32_t k = popc(rem);
+            if (k == 0u) break;
+            const uint32_t bit = 1u << nth_set_bit<NB>(rem, pick(draw(tk, 16u + j), k));
+            rem &= ~bit;
+            if (j < nw) wolves |= bit; else if (j == nw) doc = bit; else det = bit;
+        }
+        s.rb0 = rem | doc; s.rb1 = wolves | doc; s.rb2 = det;
+        s.team_w = wolves; s.team_v = ALL & ~wolves;
+        s.secret = ALL & ~rem; s.elig = ALL & ~rem;
+    } else if (eff == EFF_NIGHT_BEGIN) {
+        s.sub = 0; s.sel = 0;
+    } else if (eff == EFF_NIGHT_RESOLVE || eff == EFF_DAY_RESOLVE) {
+        const bool day = eff == EFF_DAY_RESOLVE;
+        const uint32_t voters = day ? (s.alive & s.acted) : (s.alive & r_wolf);
+        const uint32_t victim = plurality<NB, nib_t>(day ? s.choice : s.sel, voters);
+        uint32_t protect = 0;
+        if (!day) {
+            const uint32_t docs = s.alive & r_doc;
+            if (docs) protect = (uint32_t)(s.sel >> (4u * (31u - (uint32_t)__clz((int)docs)))) & 15u;
+        }
+        if (victim != 0u && victim != protect) {
+            const uint32_t bit = 1u << (victim - 1u);
+            s.alive &= ~bit; s.can_vote &= ~bit; s.elig &= ~bit; s.revealed |= bit;
+        }
+    }
+    s.acted = 0; s.choice = 0;
+    s.flags = (s.flags & FLAG_PHASE0_DONE) | (p_eff << 1);
+    s.prev = s.phase;
+    s.phase = q;
+    if (((q0 >> 11) & 7u) == 0u && s.end_turn == END_NONE) s.end_turn = turn < 0xFFFEu ? turn : 0xFFFEu;
+}
+
+// ------------------------------------------------------------------ two truths and a lie
+template <int NB>
+__device__ __forceinline__ void tt_turn(TT<NB> &s, const DevRow *rows, uint32_t n, uint32_t rounds,
+                                        uint32_t phase0_idx, uint32_t rkey, uint32_t turn) {
+    const uint32_t ALL = (1u << n) - 1u;
+    const DevRow row = rows[s.phase];
+    const uint32_t comp = row.r0 & 3u, act = (row.r0 >> 2) & 7u, p_eff = (row.r0 >> 5) & 7u;
+    const uint32_t nterms = (row.r0 >> 8) & 7u, nbr = (row.r0 >> 11) & 7u;
+    const uint32_t tk = turn_key(rkey, turn);
+
+    uint32_t T = 0;
+    if (comp == COMP_ACTION) {
+        T = ALL;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t b = (row.r1 >> (4 * j)) & 15u;
+            uint32_t m = s.speaker;
+            m = b == 1 ? s.submitted : m; m = b == 2 ? s.revealed : m;
+            m = b == 3 ? s.can_vote : m;  m = b == 4 ? s.has_voted : m;
+            m = ((row.r0 >> (16 + j)) & 1u) ? ~m : m;
+            T &= (uint32_t)j < nterms ? m : 0xFFFFFFFFu;
+        }
+        T &= ALL;
+    }
+
+    uint32_t newly = 0;
+    {
+        uint32_t todo = T & ~s.acted;
+        while (todo) {
+            const uint32_t i = ctz(todo);
+            todo &= todo - 1u;
+            const uint32_t d = draw(tk, i);
+            if ((d & 3u) == 0u) continue;
+            const uint32_t c = act == ACT_TT_STATEMENTS ? 1u : 1u + pick(d, 3u);
+            const uint32_t sh = 2u * i;
+            s.choice = (s.choice & ~(3u << sh)) | (c << sh);
+            newly |= 1u << i;
+            if (act == ACT_TT_LIE) s.lie = (s.lie & ~(3u << sh)) | (c << sh);
+            if (act == ACT_TT_VOTE) s.vote = (s.vote & ~(3u << sh)) | (c << sh);
+        }
+    }
+    s.acted |= newly;
+    if (act == ACT_TT_STATEMENTS) s.submitted |= newly;
+    if (act == ACT_TT_VOTE) s.has_voted |= newly;
+
+    if (s.phase == phase0_idx && !(s.flags & FLAG_PHASE0_DONE)) {
+        s.flags |= FLAG_PHASE0_DONE;
+        return;
+    }
+    uint32_t q = s.phase;
+    if (nbr != 0u && (comp != COMP_ACTION || (T & ~s.acted) == 0u)) {
+        uint32_t all_done = 1u;
+        if ((row.r0 >> 20) & 1u) {                       // some branch asks "all rounds done?"
+#pragma unroll
+            for (int i = 0; i < NB; i++)
+                if ((uint32_t)i < n && ((uint32_t)(s.rounds >> (4 * i)) & 15u) < rounds) all_done = 0u;
+        }
+        const uint32_t C = 1u | (all_done << RES_ALL_ROUNDS_DONE) | (1u << RES_OTHERWISE);
+#pragma unroll
+        for (int b = 3; b >= 0; b--) {
+            const uint32_t res = (row.r2 >> (4 * b)) & 15u;
+            const bool ok = (uint32_t)b < nbr && ((C >> res) & 1u);
+            q = ok ? ((row.r3 >> (8 * b)) & 255u) : q;
+        }
+    }
+    if (q == s.phase) return;
+
+    const uint32_t q0 = rows[q].r0;
+    const uint32_t eff = (q0 >> 5) & 7u;
+    if (eff == EFF_TT_ROUND_START) {
+        uint32_t speaker = 0;
+#pragma unroll
+        for (int i = NB - 1; i >= 0; i--)
+            if ((uint32_t)i < n && ((uint32_t)(s.rounds >> (4 * i)) & 15u) < rounds) speaker = 1u << i;
+        s.speaker = speaker; s.can_vote = ALL & ~speaker;
+        s.submitted = 0; s.lie = 0; s.revealed = 0; s.vote = 0; s.has_voted = 0;
+    } else if (eff == EFF_TT_REVEAL) {
+        s.revealed |= s.speaker;
+    } else if (eff == EFF_TT_SCORE) {
+        if (s.speaker) {
+            const uint32_t sp = ctz(s.speaker);
+            const uint32_t lie = (s.lie >> (2u * sp)) & 3u;
+            uint32_t fooled = 0;
+#pragma unroll
+            for (int i = 0; i < NB; i++) {
+                const bool voter = (uint32_t)i != sp && ((s.has_voted >> i) & 1u);
+                const bool right = ((s.vote >> (2 * i)) & 3u) == lie;
+                uint32_t add = (voter && right) ? 1u : 0u;
+                fooled += (voter && !right) ? 1u : 0u;
+                // the speaker's own slot takes `fooled` below; everyone else +1 if right
+                s.score[i / 4] += add << (8 * (i % 4));
+            }
+#pragma unroll
+            for (int i = 0; i < NB; i++)
+                s.score[i / 4] += ((uint32_t)i == sp ? fooled : 0u) << (8 * (i % 4));
+            s.rounds += uint64_t(1) << (4u * sp);
+        }
+    }
+    s.acted = 0; s.choice = 0;
+    s.flags = (s.flags & FLAG_PHASE0_DONE) | (p_eff << 1);
+    s.prev = s.phase;
+    s.phase = q;
+    if (((q0 >> 11) & 7u) == 0u && s.end_turn == END_NONE) s.end_turn = turn < 0xFFFEu ? turn : 0xFFFEu;
+}
+#endif  // __HIPCC__
+
+}  // namespace ge

@@ -1,0 +1,200 @@
+// ge_layout.h — packed room records in HBM and their in-register form.
+//
+// The reference keeps a room as Python dicts (AgentState, agent/game_agent_v2.py:97-117;
+// per-player field dicts from games/*.yaml player_states_template).  Here a room is a
+// fixed-size little-endian record of 32-bit words, FIELD-MAJOR ("bitboards"): every boolean
+// player field is one N-bit mask over the players, small integers are nibble / 2-bit / byte
+// arrays.  A condition such as `player.role == 'Werewolf' and player.is_alive == true`
+// (ww:247) is then one AND of two masks for all players at once.
+//
+// HBM layout ("plane SoA"): a segment of R rooms with W words per record is stored as
+// ceil(W/4) planes; plane j holds words 4j..4j+3 of every room as one dense array of
+// 16-byte elements (the last plane 8-byte elements when W % 4 == 2).  A wavefront whose
+// lanes are 64 consecutive rooms therefore loads/stores 1 KiB (or 512 B) contiguous per
+// instruction: dwordx4 / dwordx2 per lane, fully coalesced.
+//
+// Record sizes = the algorithmic bytes B/2 of DESIGN.md (read once + written once per turn):
+//   werewolf  N<=8 : 8 words  = 32 B      werewolf  N<=12: 10 words = 40 B
+//   two-truths N<=4: 6 words  = 24 B      two-truths N<=8:  8 words = 32 B     N<=12: 12 words = 48 B
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define GE_HD __host__ __device__ __forceinline__
+#else
+#define GE_HD inline
+#endif
+
+namespace ge {
+
+template <int NB> struct Nib;                       // nibble-array carrier: 4 bits per player
+template <> struct Nib<8> { using type = uint32_t; };
+template <> struct Nib<12> { using type = uint64_t; };
+
+constexpr int FLAG_PHASE0_DONE = 1;                 // flags bit 0; bits 1..3 = effect of prev phase
+constexpr uint32_t END_NONE = 0xFFFFu;              // end_turn: not finished
+
+// ---------------------------------------------------------------- werewolf pack
+// masks 0..7 are, in this order, the base predicates 0..7 a DSL condition may test.
+template <int NB> struct WW {
+    using nib_t = typename Nib<NB>::type;
+    uint32_t alive, can_vote, revealed, secret, elig, sub, team_v, team_w;   // bases 0..7
+    uint32_t acted, rb0, rb1, rb2, det_v, det_w;    // rb*: bit-planes of the role index 0..4
+    nib_t sel, choice;                              // selected_target_id / latest action choice
+    uint32_t phase, prev, flags, end_turn;
+    uint32_t games;                                 // games this slot has completed (restart mode), 16 bits
+};
+
+template <int NB> struct WWLayout;
+
+template <> struct WWLayout<8> {
+    static constexpr int WORDS = 8;
+    static GE_HD void unpack(const uint32_t *w, WW<8> &s) {
+        s.alive = w[0] & 0xFF; s.can_vote = (w[0] >> 8) & 0xFF; s.revealed = (w[0] >> 16) & 0xFF; s.secret = w[0] >> 24;
+        s.elig = w[1] & 0xFF; s.sub = (w[1] >> 8) & 0xFF; s.team_v = (w[1] >> 16) & 0xFF; s.team_w = w[1] >> 24;
+        s.acted = w[2] & 0xFF; s.rb0 = (w[2] >> 8) & 0xFF; s.rb1 = (w[2] >> 16) & 0xFF; s.rb2 = w[2] >> 24;
+        s.det_v = w[3] & 0xFF; s.det_w = (w[3] >> 8) & 0xFF; s.phase = (w[3] >> 16) & 0xFF; s.prev = w[3] >> 24;
+        s.sel = w[4]; s.choice = w[5];
+        s.end_turn = w[6] & 0xFFFF; s.flags = (w[6] >> 16) & 0xFF;
+        s.games = w[7] & 0xFFFF;
+    }
+    static GE_HD void pack(const WW<8> &s, uint32_t *w) {
+        w[0] = s.alive | (s.can_vote << 8) | (s.revealed << 16) | (s.secret << 24);
+        w[1] = s.elig | (s.sub << 8) | (s.team_v << 16) | (s.team_w << 24);
+        w[2] = s.acted | (s.rb0 << 8) | (s.rb1 << 16) | (s.rb2 << 24);
+        w[3] = s.det_v | (s.det_w << 8) | (s.phase << 16) | (s.prev << 24);
+        w[4] = s.sel; w[5] = s.choice;
+        w[6] = s.end_turn | (s.flags << 16);
+        w[7] = s.games;
+    }
+};
+
+template <> struct WWLayout<12> {
+    static constexpr int WORDS = 10;
+    // words 0..6: mask(12) | mask(12)<<12 | byte<<24 ; bytes: phase prev flags end_lo end_hi games_lo games_hi
+    static GE_HD void unpack(const uint32_t *w, WW<12> &s) {
+        s.alive = w[0] & 0xFFF; s.can_vote = (w[0] >> 12) & 0xFFF; s.phase = w[0] >> 24;
+        s.revealed = w[1] & 0xFFF; s.secret = (w[1] >> 12) & 0xFFF; s.prev = w[1] >> 24;
+        s.elig = w[2] & 0xFFF; s.sub = (w[2] >> 12) & 0xFFF; s.flags = w[2] >> 24;
+        s.team_v = w[3] & 0xFFF; s.team_w = (w[3] >> 12) & 0xFFF;
+        s.acted = w[4] & 0xFFF; s.rb0 = (w[4] >> 12) & 0xFFF;
+        s.end_turn = (w[3] >> 24) | ((w[4] >> 24) << 8);
+        s.rb1 = w[5] & 0xFFF; s.rb2 = (w[5] >> 12) & 0xFFF;
+        s.det_v = w[6] & 0xFFF; s.det_w = (w[6] >> 12) & 0xFFF;
+        s.games = (w[5] >> 24) | ((w[6] >> 24) << 8);
+        s.sel = (uint64_t)w[7] | ((uint64_t)(w[9] & 0xFFFF) << 32);
+        s.choice = (uint64_t)w[8] | ((uint64_t)(w[9] >> 16) << 32);
+    }
+    static GE_HD void pack(const WW<12> &s, uint32_t *w) {
+        w[0] = s.alive | (s.can_vote << 12) | (s.phase << 24);
+        w[1] = s.revealed | (s.secret << 12) | (s.prev << 24);
+        w[2] = s.elig | (s.sub << 12) | (s.flags << 24);
+        w[3] = s.team_v | (s.team_w << 12) | ((s.end_turn & 0xFF) << 24);
+        w[4] = s.acted | (s.rb0 << 12) | ((s.end_turn >> 8) << 24);
+        w[5] = s.rb1 | (s.rb2 << 12) | ((s.games & 0xFF) << 24);
+        w[6] = s.det_v | (s.det_w << 12) | (((s.games >> 8) & 0xFF) << 24);
+        w[7] = (uint32_t)s.sel; w[8] = (uint32_t)s.choice;
+        w[9] = (uint32_t)((s.sel >> 32) & 0xFFFF) | ((uint32_t)((s.choice >> 32) & 0xFFFF) << 16);
+    }
+};
+
+// ---------------------------------------------------------------- two-truths pack
+// masks 0..4 are the base predicates 0..4 (is_speaker, statements_submitted, lie_revealed,
+// can_vote, has_voted).  lie / vote / choice: 2 bits per player.  score: a byte per player,
+// rounds_as_speaker: a nibble per player.
+template <int NB> struct TT {
+    uint32_t speaker, submitted, revealed, can_vote, has_voted, acted;
+    uint32_t lie, vote, choice;                     // 2 bits x N
+    uint32_t score[(NB + 3) / 4];                   // 4 players per word
+    uint64_t rounds;                                // 4 bits x N
+    uint32_t phase, prev, flags, end_turn;
+    uint32_t games;
+};
+
+template <int NB> struct TTLayout;
+
+template <> struct TTLayout<4> {
+    static constexpr int WORDS = 6;
+    static GE_HD void unpack(const uint32_t *w, TT<4> &s) {
+        s.speaker = w[0] & 0xF; s.submitted = (w[0] >> 4) & 0xF; s.revealed = (w[0] >> 8) & 0xF;
+        s.can_vote = (w[0] >> 12) & 0xF; s.has_voted = (w[0] >> 16) & 0xF; s.acted = (w[0] >> 20) & 0xF;
+        s.phase = w[0] >> 24;
+        s.lie = w[1] & 0xFF; s.vote = (w[1] >> 8) & 0xFF; s.choice = (w[1] >> 16) & 0xFF; s.prev = w[1] >> 24;
+        s.score[0] = w[2];
+        s.rounds = w[3] & 0xFFFF; s.end_turn = w[3] >> 16;
+        s.flags = w[4] & 0xFF; s.games = w[4] >> 16;
+    }
+    static GE_HD void pack(const TT<4> &s, uint32_t *w) {
+        w[0] = s.speaker | (s.submitted << 4) | (s.revealed << 8) | (s.can_vote << 12) | (s.has_voted << 16) |
+               (s.acted << 20) | (s.phase << 24);
+        w[1] = s.lie | (s.vote << 8) | (s.choice << 16) | (s.prev << 24);
+        w[2] = s.score[0];
+        w[3] = (uint32_t)s.rounds | (s.end_turn << 16);
+        w[4] = s.flags | ((s.games & 0xFFFF) << 16); w[5] = 0;
+    }
+};
+
+template <> struct TTLayout<8> {
+    static constexpr int WORDS = 8;
+    static GE_HD void unpack(const uint32_t *w, TT<8> &s) {
+        s.speaker = w[0] & 0xFF; s.submitted = (w[0] >> 8) & 0xFF; s.revealed = (w[0] >> 16) & 0xFF; s.can_vote = w[0] >> 24;
+        s.has_voted = w[1] & 0xFF; s.acted = (w[1] >> 8) & 0xFF; s.phase = (w[1] >> 16) & 0xFF; s.prev = w[1] >> 24;
+        s.lie = w[2] & 0xFFFF; s.vote = w[2] >> 16;
+        s.choice = w[3] & 0xFFFF; s.end_turn = w[3] >> 16;
+        s.score[0] = w[4]; s.score[1] = w[5];
+        s.rounds = w[6];
+        s.flags = w[7] & 0xFF; s.games = w[7] >> 16;
+    }
+    static GE_HD void pack(const TT<8> &s, uint32_t *w) {
+        w[0] = s.speaker | (s.submitted << 8) | (s.revealed << 16) | (s.can_vote << 24);
+        w[1] = s.has_voted | (s.acted << 8) | (s.phase << 16) | (s.prev << 24);
+        w[2] = s.lie | (s.vote << 16);
+        w[3] = s.choice | (s.end_turn << 16);
+        w[4] = s.score[0]; w[5] = s.score[1];
+        w[6] = (uint32_t)s.rounds;
+        w[7] = s.flags | ((s.games & 0xFFFF) << 16);
+    }
+};
+
+template <> struct TTLayout<12> {
+    static constexpr int WORDS = 12;
+    static GE_HD void unpack(const uint32_t *w, TT<12> &s) {
+        s.speaker = w[0] & 0xFFF; s.submitted = (w[0] >> 12) & 0xFFF; s.phase = w[0] >> 24;
+        s.revealed = w[1] & 0xFFF; s.can_vote = (w[1] >> 12) & 0xFFF; s.prev = w[1] >> 24;
+        s.has_voted = w[2] & 0xFFF; s.acted = (w[2] >> 12) & 0xFFF; s.flags = w[2] >> 24;
+        s.lie = w[3] & 0xFFFFFF; s.vote = w[4] & 0xFFFFFF; s.choice = w[5] & 0xFFFFFF;
+        s.end_turn = (w[3] >> 24) | ((w[4] >> 24) << 8);
+        s.score[0] = w[6]; s.score[1] = w[7]; s.score[2] = w[8];
+        s.rounds = (uint64_t)w[9] | ((uint64_t)(w[10] & 0xFFFF) << 32);
+        s.games = w[10] >> 16;
+    }
+    static GE_HD void pack(const TT<12> &s, uint32_t *w) {
+        w[0] = s.speaker | (s.submitted << 12) | (s.phase << 24);
+        w[1] = s.revealed | (s.can_vote << 12) | (s.prev << 24);
+        w[2] = s.has_voted | (s.acted << 12) | (s.flags << 24);
+        w[3] = s.lie | ((s.end_turn & 0xFF) << 24);
+        w[4] = s.vote | ((s.end_turn >> 8) << 24);
+        w[5] = s.choice;
+        w[6] = s.score[0]; w[7] = s.score[1]; w[8] = s.score[2];
+        w[9] = (uint32_t)s.rounds; w[10] = ((uint32_t)(s.rounds >> 32) & 0xFFFF) | ((s.games & 0xFFFF) << 16); w[11] = 0;
+    }
+};
+
+// ---------------------------------------------------------------- phase table on the device
+// One row = 4 words (ds_read_b128):
+//   r0: completion[1:0] act[4:2] effect[7:5] n_terms[10:8] n_br[13:11] term_neg[19:16]
+//   r1: term_base  4 x 4 bits        r2: br_res 4 x 4 bits        r3: br_target 4 x 8 bits
+struct DevRow { uint32_t r0, r1, r2, r3; };
+
+struct DevTable {
+    DevRow rows[32];
+    int32_t n_phases, rounds, n_players, pad;
+};
+
+// plane geometry of a segment
+GE_HD int planes_of(int words) { return (words + 3) / 4; }
+GE_HD int plane_words(int words, int j) { return (words - 4 * j) >= 4 ? 4 : (words - 4 * j); }
+// byte offset of plane j inside a segment of `rooms` rooms (rooms padded by the caller to 64)
+GE_HD uint64_t plane_offset(uint64_t rooms_padded, int j) { return (uint64_t)j * 16u * rooms_padded; }
+
+}  // namespace ge

@@ -1,0 +1,691 @@
+// ge_step.hip — kernels and C ABI of libge_step.so (gfx950 only).
+//
+// Replaces, for a batch of rooms, the reference's per-room turn loop
+// (agent/game_agent_v2.py:1571-1587 graph; nodes :198/:468/:987/:619) and its dict plumbing
+// (agent/tools/backend_tools.py:204-225, 285-344).  See include/ge_step.h for the boundary,
+// ge_layout.h for the HBM layout, ge_device.h for the turn itself.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <new>
+#include <vector>
+
+#include "../../include/ge_step.h"
+#include "ge_device.h"
+#include "ge_layout.h"
+
+using namespace ge;
+
+namespace {
+
+enum Kind { K_WW8 = 0, K_WW12, K_TT4, K_TT8, K_TT12, K_COUNT };
+
+struct SegDev {
+    uint32_t *base;            // planes of this segment
+    uint64_t rooms;            // real rooms
+    uint64_t rooms_padded;     // multiple of 256: plane stride
+    uint64_t first_global;     // global index of the segment's room 0
+    uint32_t kind, n_players, nw, rounds;
+    uint32_t phase0_idx, block_begin, table_idx, words;
+    uint32_t init_words[12];   // the initial record (player_states_template, phase 0)
+};
+
+struct StepArgs {
+    SegDev seg[GE_MAX_SEGMENTS];
+    uint32_t n_seg, turn0, n_turns, seed_lo, seed_hi, block_threads, restart;
+};
+
+constexpr int N_SUM = 5 + 16 + 16 + 1;     // ge_summary counters before `turn`
+
+template <int WORDS>
+__device__ __forceinline__ void load_words(const uint32_t *base, uint64_t rooms_padded, uint64_t room, uint32_t *w) {
+    constexpr int NP = (WORDS + 3) / 4;
+#pragma unroll
+    for (int j = 0; j < NP; j++) {
+        const char *plane = reinterpret_cast<const char *>(base) + plane_offset(rooms_padded, j);
+        if (WORDS - 4 * j >= 4) {
+            const uint4 v = reinterpret_cast<const uint4 *>(plane)[room];
+            w[4 * j] = v.x; w[4 * j + 1] = v.y; w[4 * j + 2] = v.z; w[4 * j + 3] = v.w;
+        } else {
+            const uint2 v = reinterpret_cast<const uint2 *>(plane)[room];
+            w[4 * j] = v.x; w[4 * j + 1] = v.y;
+        }
+    }
+}
+
+template <int WORDS>
+__device__ __forceinline__ void store_words(uint32_t *base, uint64_t rooms_padded, uint64_t room, const uint32_t *w) {
+    constexpr int NP = (WORDS + 3) / 4;
+#pragma unroll
+    for (int j = 0; j < NP; j++) {
+        char *plane = reinterpret_cast<char *>(base) + plane_offset(rooms_padded, j);
+        if (WORDS - 4 * j >= 4)
+            reinterpret_cast<uint4 *>(plane)[room] = make_uint4(w[4 * j], w[4 * j + 1], w[4 * j + 2], w[4 * j + 3]);
+        else
+            reinterpret_cast<uint2 *>(plane)[room] = make_uint2(w[4 * j], w[4 * j + 1]);
+    }
+}
+
+template <int NB>
+__device__ __forceinline__ void run_ww(const SegDev &sg, const StepArgs &a, const DevRow *rows, uint64_t room) {
+    using L = WWLayout<NB>;
+    uint32_t w[L::WORDS];
+    load_words<L::WORDS>(sg.base, sg.rooms_padded, room, w);
+    WW<NB> s;
+    L::unpack(w, s);
+    const uint32_t rk = room_key(a.seed_lo, a.seed_hi, sg.first_global + room);
+    for (uint32_t t = 0; t < a.n_turns; t++) {
+        if (a.restart && ((rows[s.phase].r0 >> 11) & 7u) == 0u) {      // recycle a finished room
+            const uint32_t g = s.games;
+            L::unpack(sg.init_words, s);
+            s.games = g < 0xFFFFu ? g + 1u : g;
+        }
+        ww_turn<NB>(s, rows, sg.n_players, sg.nw, sg.phase0_idx, rk, a.turn0 + t);
+    }
+    L::pack(s, w);
+    store_words<L::WORDS>(sg.base, sg.rooms_padded, room, w);
+}
+
+template <int NB>
+__device__ __forceinline__ void run_tt(const SegDev &sg, const StepArgs &a, const DevRow *rows, uint64_t room) {
+    using L = TTLayout<NB>;
+    uint32_t w[L::WORDS];
+    load_words<L::WORDS>(sg.base, sg.rooms_padded, room, w);
+    TT<NB> s;
+    L::unpack(w, s);
+    const uint32_t rk = room_key(a.seed_lo, a.seed_hi, sg.first_global + room);
+    for (uint32_t t = 0; t < a.n_turns; t++) {
+        if (a.restart && ((rows[s.phase].r0 >> 11) & 7u) == 0u) {
+            const uint32_t g = s.games;
+            L::unpack(sg.init_words, s);
+            s.games = g < 0xFFFFu ? g + 1u : g;
+        }
+        tt_turn<NB>(s, rows, sg.n_players, sg.rounds, sg.phase0_idx, rk, a.turn0 + t);
+    }
+    L::pack(s, w);
+    store_words<L::WORDS>(sg.base, sg.rooms_padded, room, w);
+}
+
+// One launch advances every room of every segment by a.n_turns turns.  Blocks are
+// segment-homogeneous (segments are padded to whole blocks), so a mixed Werewolf /
+// Two-Truths batch diverges per block, never inside a wavefront.
+__global__ void __launch_bounds__(256) ge_step_kernel(const StepArgs a, const DevTable *__restrict__ tables) {
+    __shared__ DevRow rows[GE_MAX_PHASES];
+    uint32_t si = 0;
+    for (uint32_t k = 1; k < a.n_seg; k++)
+        if (blockIdx.x >= a.seg[k].block_begin) si = k;
+    const SegDev &sg = a.seg[si];
+    if (threadIdx.x < GE_MAX_PHASES) rows[threadIdx.x] = tables[sg.table_idx].rows[threadIdx.x];
+    __syncthreads();
+    const uint64_t room = (uint64_t)(blockIdx.x - sg.block_begin) * blockDim.x + threadIdx.x;
+    if (room >= sg.rooms) return;
+    switch (sg.kind) {
+    case K_WW8: run_ww<8>(sg, a, rows, room); break;
+    case K_WW12: run_ww<12>(sg, a, rows, room); break;
+    case K_TT4: run_tt<4>(sg, a, rows, room); break;
+    case K_TT8: run_tt<8>(sg, a, rows, room); break;
+    default: run_tt<12>(sg, a, rows, room); break;
+    }
+}
+
+// ---- summary: per-room contributions -> wavefront shuffle reduce -> LDS -> one atomic per block
+__device__ __forceinline__ uint64_t wave_sum(uint64_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+struct RoomStats { uint32_t finished, village, wolves, alive, end_turn, games; };
+
+template <int NB> __device__ __forceinline__ RoomStats stats_ww(const uint32_t *w, const DevRow *rows, uint32_t *hist_score) {
+    WW<NB> s; WWLayout<NB>::unpack(w, s);
+    RoomStats r;
+    r.finished = ((rows[s.phase].r0 >> 11) & 7u) == 0u;
+    const uint32_t wv = __popc(s.alive & s.team_w);
+    r.village = r.finished && wv == 0; r.wolves = r.finished && wv != 0;
+    r.alive = __popc(s.alive); r.end_turn = s.end_turn; r.games = s.games;
+    (void)hist_score;
+    return r;
+}
+template <int NB> __device__ __forceinline__ RoomStats stats_tt(const uint32_t *w, const DevRow *rows, uint32_t n, uint32_t *hist_score) {
+    TT<NB> s; TTLayout<NB>::unpack(w, s);
+    RoomStats r;
+    r.finished = ((rows[s.phase].r0 >> 11) & 7u) == 0u;
+    r.village = 0; r.wolves = 0; r.alive = n; r.end_turn = s.end_turn; r.games = s.games;
+    for (uint32_t i = 0; i < n; i++) {
+        uint32_t sc = (s.score[i / 4] >> (8 * (i % 4))) & 255u;
+        atomicAdd(&hist_score[sc < 15 ? sc : 15], 1u);
+    }
+    return r;
+}
+
+__global__ void __launch_bounds__(256) ge_summary_kernel(const StepArgs a, const DevTable *__restrict__ tables,
+                                                         unsigned long long *__restrict__ out) {
+    __shared__ DevRow rows[GE_MAX_PHASES];
+    __shared__ uint32_t h_end[16], h_score[16];
+    __shared__ unsigned long long acc[7];
+    uint32_t si = 0;
+    for (uint32_t k = 1; k < a.n_seg; k++)
+        if (blockIdx.x >= a.seg[k].block_begin) si = k;
+    const SegDev &sg = a.seg[si];
+    if (threadIdx.x < GE_MAX_PHASES) rows[threadIdx.x] = tables[sg.table_idx].rows[threadIdx.x];
+    if (threadIdx.x < 16) { h_end[threadIdx.x] = 0; h_score[threadIdx.x] = 0; }
+    if (threadIdx.x < 7) acc[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t room = (uint64_t)(blockIdx.x - sg.block_begin) * blockDim.x + threadIdx.x;
+    RoomStats r = {0, 0, 0, 0, END_NONE, 0};
+    uint64_t ck = 0;
+    if (room < sg.rooms) {
+        uint32_t w[12];
+        switch (sg.kind) {
+        case K_WW8: load_words<8>(sg.base, sg.rooms_padded, room, w); r = stats_ww<8>(w, rows, h_score); break;
+        case K_WW12: load_words<10>(sg.base, sg.rooms_padded, room, w); r = stats_ww<12>(w, rows, h_score); break;
+        case K_TT4: load_words<6>(sg.base, sg.rooms_padded, room, w); r = stats_tt<4>(w, rows, sg.n_players, h_score); break;
+        case K_TT8: load_words<8>(sg.base, sg.rooms_padded, room, w); r = stats_tt<8>(w, rows, sg.n_players, h_score); break;
+        default: load_words<12>(sg.base, sg.rooms_padded, room, w); r = stats_tt<12>(w, rows, sg.n_players, h_score); break;
+        }
+        const uint64_t g = sg.first_global + room;
+        uint32_t h = mix32((uint32_t)g ^ mix32((uint32_t)(g >> 32) ^ 0xA5A5A5A5u));
+        for (uint32_t j = 0; j < sg.words; j++) h = mix32(h ^ w[j]);
+        ck = (uint64_t)h | ((uint64_t)mix32(h ^ 0x5BD1E995u) << 32);
+        if (r.finished) atomicAdd(&h_end[(r.end_turn >> 3) < 15 ? (r.end_turn >> 3) : 15], 1u);
+    }
+    const uint64_t v0 = wave_sum(r.finished), v1 = wave_sum(r.village), v2 = wave_sum(r.wolves);
+    const uint64_t v3 = wave_sum(r.alive), v4 = wave_sum(r.finished ? r.end_turn : 0), v5 = wave_sum(ck);
+    const uint64_t v6 = wave_sum(r.games);
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&acc[0], v0); atomicAdd(&acc[1], v1); atomicAdd(&acc[2], v2);
+        atomicAdd(&acc[3], v3); atomicAdd(&acc[4], v4); atomicAdd(&acc[5], v5); atomicAdd(&acc[6], v6);
+    }
+    __syncthreads();
+    // out: [0] finished [1] village [2] wolves [3] alive [4] sum_end [5..20] end hist [21..36] score hist [37] checksum
+    if (threadIdx.x < 5) atomicAdd(&out[threadIdx.x], acc[threadIdx.x]);
+    if (threadIdx.x == 5) atomicAdd(&out[37], acc[5]);
+    if (threadIdx.x == 6) atomicAdd(&out[38], acc[6]);
+    if (threadIdx.x >= 64 && threadIdx.x < 80 && h_end[threadIdx.x - 64]) atomicAdd(&out[5 + threadIdx.x - 64], (unsigned long long)h_end[threadIdx.x - 64]);
+    if (threadIdx.x >= 128 && threadIdx.x < 144 && h_score[threadIdx.x - 128]) atomicAdd(&out[21 + threadIdx.x - 128], (unsigned long long)h_score[threadIdx.x - 128]);
+}
+
+thread_local int g_last_hip = 0;
+
+#define HIP_TRY(expr)                                   \
+    do {                                                \
+        hipError_t e__ = (expr);                        \
+        if (e__ != hipSuccess) { g_last_hip = (int)e__; return GE_ERR_HIP; } \
+    } while (0)
+
+struct Segment {
+    ge_game_table table;
+    SegDev dev;
+    uint64_t local_first;      // index of the segment's room 0 inside the batch
+};
+
+DevRow to_dev_row(const ge_phase_row &r) {
+    DevRow d = {0, 0, 0, 0};
+    d.r0 = (r.completion & 3u) | ((r.act & 7u) << 2) | ((r.effect & 7u) << 5) | ((r.n_terms & 7u) << 8) |
+           ((r.n_branches & 7u) << 11);
+    for (int j = 0; j < GE_MAX_TERMS; j++) {
+        d.r0 |= (uint32_t)(r.term_neg[j] & 1u) << (16 + j);
+        d.r1 |= (uint32_t)(r.term_base[j] & 15u) << (4 * j);
+    }
+    for (int b = 0; b < GE_MAX_BRANCHES; b++) {
+        d.r2 |= (uint32_t)(r.br_res[b] & 15u) << (4 * b);
+        d.r3 |= (uint32_t)r.br_target[b] << (8 * b);
+        if (b < r.n_branches && r.br_res[b] == GE_RES_ALL_ROUNDS_DONE) d.r0 |= 1u << 20;
+    }
+    return d;
+}
+
+int words_of(uint32_t kind) {
+    switch (kind) {
+    case K_WW8: return 8; case K_WW12: return 10; case K_TT4: return 6; case K_TT8: return 8; default: return 12;
+    }
+}
+
+// canonical view <-> packed words (host side of ge_batch_read_rooms / write_rooms)
+template <int NB> void view_to_ww(const ge_room_view &v, const ge_game_table &tb, uint32_t *w) {
+    WW<NB> s;
+    memset(&s, 0, sizeof s);
+    for (int i = 0; i < v.n_players; i++) {
+        const uint8_t *f = v.players[i];
+        const uint32_t b = 1u << i;
+        if (f[0] & 1) s.rb0 |= b; if (f[0] & 2) s.rb1 |= b; if (f[0] & 4) s.rb2 |= b;
+        if (f[1] == 1) s.team_v |= b; if (f[1] == 2) s.team_w |= b;
+        if (f[2]) s.alive |= b; if (f[3]) s.revealed |= b; if (f[4]) s.can_vote |= b; if (f[5]) s.secret |= b;
+        if (f[6]) s.elig |= b; if (f[7]) s.sub |= b;
+        s.sel |= (typename WW<NB>::nib_t)(f[8] & 15) << (4 * i);
+        if (f[9]) s.acted |= b;
+        s.choice |= (typename WW<NB>::nib_t)(f[10] & 15) << (4 * i);
+        if (v.det[i] == 1) s.det_v |= b; if (v.det[i] == 2) s.det_w |= b;
+    }
+    int pi = 0, qi = 0;
+    for (int k = 0; k < tb.n_phases; k++) {
+        if (tb.rows[k].phase_id == v.phase_id) pi = k;
+        if (tb.rows[k].phase_id == v.prev_phase_id) qi = k;
+    }
+    s.phase = pi; s.prev = qi;
+    s.flags = (v.phase0_done ? FLAG_PHASE0_DONE : 0) | ((uint32_t)tb.rows[qi].effect << 1);
+    s.end_turn = v.end_turn < 0 ? END_NONE : (uint32_t)v.end_turn;
+    s.games = (uint32_t)v.games & 0xFFFFu;
+    WWLayout<NB>::pack(s, w);
+}
+
+template <int NB> void ww_to_view(const uint32_t *w, const ge_game_table &tb, int n, ge_room_view &v) {
+    WW<NB> s;
+    WWLayout<NB>::unpack(w, s);
+    memset(&v, 0, sizeof v);
+    v.pack = GE_PACK_WEREWOLF; v.n_players = (uint8_t)n;
+    v.phase_id = tb.rows[s.phase].phase_id; v.prev_phase_id = tb.rows[s.prev].phase_id;
+    v.phase0_done = s.flags & FLAG_PHASE0_DONE;
+    v.end_turn = s.end_turn == END_NONE ? -1 : (int32_t)s.end_turn;
+    v.games = (int32_t)s.games;
+    for (int i = 0; i < n; i++) {
+        uint8_t *f = v.players[i];
+        f[0] = (uint8_t)(((s.rb0 >> i) & 1) | (((s.rb1 >> i) & 1) << 1) | (((s.rb2 >> i) & 1) << 2));
+        f[1] = (uint8_t)(((s.team_v >> i) & 1) ? 1 : (((s.team_w >> i) & 1) ? 2 : 0));
+        f[2] = (s.alive >> i) & 1; f[3] = (s.revealed >> i) & 1; f[4] = (s.can_vote >> i) & 1;
+        f[5] = (s.secret >> i) & 1; f[6] = (s.elig >> i) & 1; f[7] = (s.sub >> i) & 1;
+        f[8] = (uint8_t)((s.sel >> (4 * i)) & 15); f[9] = (s.acted >> i) & 1;
+        f[10] = (uint8_t)((s.choice >> (4 * i)) & 15);
+        v.det[i] = (uint8_t)(((s.det_v >> i) & 1) ? 1 : (((s.det_w >> i) & 1) ? 2 : 0));
+    }
+}
+
+template <int NB> void view_to_tt(const ge_room_view &v, const ge_game_table &tb, uint32_t *w) {
+    TT<NB> s;
+    memset(&s, 0, sizeof s);
+    for (int i = 0; i < v.n_players; i++) {
+        const uint8_t *f = v.players[i];
+        const uint32_t b = 1u << i;
+        if (f[0]) s.speaker |= b; if (f[1]) s.submitted |= b; if (f[3]) s.revealed |= b;
+        if (f[4]) s.can_vote |= b; if (f[6]) s.has_voted |= b; if (f[9]) s.acted |= b;
+        s.lie |= (uint32_t)(f[2] & 3) << (2 * i); s.vote |= (uint32_t)(f[5] & 3) << (2 * i);
+        s.choice |= (uint32_t)(f[10] & 3) << (2 * i);
+        s.score[i / 4] |= (uint32_t)f[7] << (8 * (i % 4));
+        s.rounds |= (uint64_t)(f[8] & 15) << (4 * i);
+    }
+    int pi = 0, qi = 0;
+    for (int k = 0; k < tb.n_phases; k++) {
+        if (tb.rows[k].phase_id == v.phase_id) pi = k;
+        if (tb.rows[k].phase_id == v.prev_phase_id) qi = k;
+    }
+    s.phase = pi; s.prev = qi;
+    s.flags = (v.phase0_done ? FLAG_PHASE0_DONE : 0) | ((uint32_t)tb.rows[qi].effect << 1);
+    s.end_turn = v.end_turn < 0 ? END_NONE : (uint32_t)v.end_turn;
+    s.games = (uint32_t)v.games & 0xFFFFu;
+    TTLayout<NB>::pack(s, w);
+}
+
+template <int NB> void tt_to_view(const uint32_t *w, const ge_game_table &tb, int n, ge_room_view &v) {
+    TT<NB> s;
+    TTLayout<NB>::unpack(w, s);
+    memset(&v, 0, sizeof v);
+    v.pack = GE_PACK_TWO_TRUTHS; v.n_players = (uint8_t)n;
+    v.phase_id = tb.rows[s.phase].phase_id; v.prev_phase_id = tb.rows[s.prev].phase_id;
+    v.phase0_done = s.flags & FLAG_PHASE0_DONE;
+    v.end_turn = s.end_turn == END_NONE ? -1 : (int32_t)s.end_turn;
+    v.games = (int32_t)s.games;
+    for (int i = 0; i < n; i++) {
+        uint8_t *f = v.players[i];
+        f[0] = (s.speaker >> i) & 1; f[1] = (s.submitted >> i) & 1; f[2] = (s.lie >> (2 * i)) & 3;
+        f[3] = (s.revealed >> i) & 1; f[4] = (s.can_vote >> i) & 1; f[5] = (s.vote >> (2 * i)) & 3;
+        f[6] = (s.has_voted >> i) & 1; f[7] = (uint8_t)((s.score[i / 4] >> (8 * (i % 4))) & 255);
+        f[8] = (uint8_t)((s.rounds >> (4 * i)) & 15); f[9] = (s.acted >> i) & 1; f[10] = (s.choice >> (2 * i)) & 3;
+    }
+}
+
+void view_to_words(uint32_t kind, const ge_room_view &v, const ge_game_table &tb, uint32_t *w) {
+    switch (kind) {
+    case K_WW8: view_to_ww<8>(v, tb, w); break;
+    case K_WW12: view_to_ww<12>(v, tb, w); break;
+    case K_TT4: view_to_tt<4>(v, tb, w); break;
+    case K_TT8: view_to_tt<8>(v, tb, w); break;
+    default: view_to_tt<12>(v, tb, w); break;
+    }
+}
+
+void words_to_view(uint32_t kind, const uint32_t *w, const ge_game_table &tb, int n, ge_room_view &v) {
+    switch (kind) {
+    case K_WW8: ww_to_view<8>(w, tb, n, v); break;
+    case K_WW12: ww_to_view<12>(w, tb, n, v); break;
+    case K_TT4: tt_to_view<4>(w, tb, n, v); break;
+    case K_TT8: tt_to_view<8>(w, tb, n, v); break;
+    default: tt_to_view<12>(w, tb, n, v); break;
+    }
+}
+
+}  // namespace
+
+struct ge_batch {
+    int device = 0;
+    uint64_t seed = 0, first_room = 0, turn = 0, n_rooms = 0;
+    uint32_t max_fuse = 64, block_threads = 256, n_blocks = 0, flags = 0;
+    std::vector<Segment> segs;
+    void *state = nullptr;            // one allocation, segments back to back
+    size_t state_bytes = 0;
+    DevTable *tables = nullptr;
+    unsigned long long *sum_dev = nullptr;
+    hipStream_t last_stream = nullptr;
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    size_t events_used = 0;
+    double timed_ms = 0.0;
+    uint64_t launches = 0;
+};
+
+static int fill_args(const ge_batch *b, StepArgs &a, uint32_t turn0, uint32_t n_turns) {
+    memset(&a, 0, sizeof a);
+    a.n_seg = (uint32_t)b->segs.size();
+    for (uint32_t k = 0; k < a.n_seg; k++) a.seg[k] = b->segs[k].dev;
+    a.turn0 = turn0; a.n_turns = n_turns;
+    a.seed_lo = (uint32_t)b->seed; a.seed_hi = (uint32_t)(b->seed >> 32);
+    a.block_threads = b->block_threads;
+    a.restart = (b->flags & GE_FLAG_RESTART) ? 1u : 0u;
+    return GE_OK;
+}
+
+extern "C" {
+
+int ge_abi_version(void) { return GE_ABI_VERSION; }
+int ge_last_hip_error(void) { return g_last_hip; }
+
+int ge_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char *ge_strerror(int status) {
+    switch (status) {
+    case GE_OK: return "ok";
+    case GE_ERR_ARG: return "invalid argument";
+    case GE_ERR_DSL: return "game DSL cannot be compiled";
+    case GE_ERR_NO_DEVICE: return "no HIP device (the stepper has no CPU path)";
+    case GE_ERR_HIP: return "HIP runtime error";
+    case GE_ERR_NOMEM: return "out of memory";
+    case GE_ERR_RANGE: return "out of range";
+    case GE_ERR_UNSUPPORTED: return "unsupported";
+    default: return "unknown status";
+    }
+}
+
+int ge_batch_create(const ge_batch_desc *desc, ge_batch **out) {
+    if (!desc || !out || desc->n_segments == 0 || desc->n_segments > GE_MAX_SEGMENTS) return GE_ERR_ARG;
+    *out = nullptr;
+    if (ge_device_count() <= 0) return GE_ERR_NO_DEVICE;
+    if (desc->device < 0 || desc->device >= ge_device_count()) return GE_ERR_ARG;
+    ge_batch *b = new (std::nothrow) ge_batch();
+    if (!b) return GE_ERR_NOMEM;
+    b->device = desc->device; b->seed = desc->seed; b->first_room = desc->first_room;
+    b->max_fuse = desc->max_fuse ? desc->max_fuse : 64u;
+    b->flags = desc->flags;
+    uint64_t total = 0;
+    for (uint32_t k = 0; k < desc->n_segments; k++) total += desc->seg[k].n_rooms;
+    b->block_threads = total >= (1u << 19) ? 256u : 64u;
+    uint64_t local = 0, global = desc->first_room;
+    size_t bytes = 0;
+    uint32_t blocks = 0;
+    for (uint32_t k = 0; k < desc->n_segments; k++) {
+        const ge_segment_desc &sd = desc->seg[k];
+        if (!sd.table || sd.n_rooms == 0 || sd.table->abi_version != GE_ABI_VERSION ||
+            sd.table->n_phases <= 0 || sd.table->n_phases > GE_MAX_PHASES) { delete b; return GE_ERR_ARG; }
+        Segment s;
+        s.table = *sd.table;
+        const uint32_t n = sd.n_players;
+        if (n > GE_MAX_PLAYERS || (int)n < s.table.min_players) { delete b; return GE_ERR_ARG; }
+        SegDev &d = s.dev;
+        memset(&d, 0, sizeof d);
+        if (s.table.pack == GE_PACK_WEREWOLF) {
+            if (n < 4) { delete b; return GE_ERR_ARG; }
+            d.kind = n <= 8 ? K_WW8 : K_WW12;
+        } else if (s.table.pack == GE_PACK_TWO_TRUTHS) {
+            if (n < 2 || s.table.rounds < 1 || s.table.rounds > 15 ||
+                s.table.rounds * 2 * ((int)n - 1) > 255) { delete b; return GE_ERR_ARG; }
+            d.kind = n <= 4 ? K_TT4 : (n <= 8 ? K_TT8 : K_TT12);
+        } else { delete b; return GE_ERR_ARG; }
+        d.words = (uint32_t)words_of(d.kind);
+        d.rooms = sd.n_rooms;
+        d.rooms_padded = (sd.n_rooms + 255u) & ~uint64_t(255);
+        d.first_global = global;
+        d.n_players = n; d.nw = n / 4 > 1 ? n / 4 : 1; d.rounds = (uint32_t)s.table.rounds;
+        d.phase0_idx = 255;
+        for (int r = 0; r < s.table.n_phases; r++)
+            if (s.table.rows[r].phase_id == 0) d.phase0_idx = (uint32_t)r;
+        if (d.phase0_idx == 255) { delete b; return GE_ERR_ARG; }   // AgentState starts at phase id 0 (v2:103)
+        d.block_begin = blocks; d.table_idx = k;
+        blocks += (uint32_t)((sd.n_rooms + b->block_threads - 1) / b->block_threads);
+        s.local_first = local;
+        d.base = reinterpret_cast<uint32_t *>(bytes);     // offset for now, rebased after hipMalloc
+        bytes += (size_t)planes_of((int)d.words) * 16u * d.rooms_padded;
+        local += sd.n_rooms; global += sd.n_rooms;
+        b->segs.push_back(s);
+    }
+    b->n_rooms = local; b->n_blocks = blocks; b->state_bytes = bytes;
+    int st = GE_OK;
+    do {
+        if (hipSetDevice(b->device) != hipSuccess) { st = GE_ERR_HIP; break; }
+        hipError_t e = hipMalloc(&b->state, bytes);
+        if (e != hipSuccess) { g_last_hip = (int)e; st = e == hipErrorOutOfMemory ? GE_ERR_NOMEM : GE_ERR_HIP; break; }
+        if (hipMalloc(reinterpret_cast<void **>(&b->tables), sizeof(DevTable) * b->segs.size()) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void **>(&b->sum_dev), sizeof(unsigned long long) * 64) != hipSuccess) { st = GE_ERR_HIP; break; }
+        std::vector<DevTable> host_tables(b->segs.size());
+        for (size_t k = 0; k < b->segs.size(); k++) {
+            Segment &s = b->segs[k];
+            s.dev.base = reinterpret_cast<uint32_t *>(static_cast<char *>(b->state) + reinterpret_cast<size_t>(s.dev.base));
+            DevTable &dt = host_tables[k];
+            memset(&dt, 0, sizeof dt);
+            for (int r = 0; r < s.table.n_phases; r++) dt.rows[r] = to_dev_row(s.table.rows[r]);
+            dt.n_phases = s.table.n_phases; dt.rounds = s.table.rounds; dt.n_players = (int32_t)s.dev.n_players;
+        }
+        if (hipMemcpy(b->tables, host_tables.data(), sizeof(DevTable) * host_tables.size(), hipMemcpyHostToDevice) != hipSuccess) { st = GE_ERR_HIP; break; }
+    } while (0);
+    if (st != GE_OK) { ge_batch_destroy(b); return st; }
+    st = ge_batch_reset(b);
+    if (st != GE_OK) { ge_batch_destroy(b); return st; }
+    *out = b;
+    return GE_OK;
+}
+
+int ge_batch_reset(ge_batch *b) {
+    if (!b) return GE_ERR_ARG;
+    int st = ge_batch_sync(b);
+    if (st != GE_OK) return st;
+    b->turn = 0;
+    // initial state: player_states_template for every player, phase id 0 (utils.py:642-647)
+    for (size_t k = 0; k < b->segs.size() && st == GE_OK; k++) {
+        Segment &s = b->segs[k];
+        ge_room_view v;
+        memset(&v, 0, sizeof v);
+        v.phase_id = 0; v.prev_phase_id = 0; v.end_turn = -1; v.n_players = (uint8_t)s.dev.n_players;
+        v.pack = (uint8_t)s.table.pack;
+        for (uint32_t i = 0; i < s.dev.n_players; i++) memcpy(v.players[i], s.table.init_fields, 12);
+        uint32_t w[12] = {0};
+        view_to_words(s.dev.kind, v, s.table, w);
+        memcpy(s.dev.init_words, w, sizeof w);
+        const int np = planes_of((int)s.dev.words);
+        for (int j = 0; j < np && st == GE_OK; j++) {
+            const int pw = plane_words((int)s.dev.words, j);
+            std::vector<uint32_t> plane((size_t)pw * s.dev.rooms_padded);
+            for (uint64_t r = 0; r < s.dev.rooms_padded; r++)
+                for (int x = 0; x < pw; x++) plane[r * pw + x] = w[4 * j + x];
+            char *dst = reinterpret_cast<char *>(s.dev.base) + plane_offset(s.dev.rooms_padded, j);
+            if (hipMemcpy(dst, plane.data(), plane.size() * 4, hipMemcpyHostToDevice) != hipSuccess) st = GE_ERR_HIP;
+        }
+    }
+    return st;
+}
+
+int ge_batch_set_timing(ge_batch *b, int on) {
+    if (!b) return GE_ERR_ARG;
+    b->timing = on != 0;
+    return GE_OK;
+}
+
+int ge_batch_step(ge_batch *b, uint32_t n_turns, void *hip_stream) {
+    if (!b) return GE_ERR_ARG;
+    if (b->turn + n_turns > 0xFFFFFFFFull) return GE_ERR_RANGE;
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    HIP_TRY(hipSetDevice(b->device));
+    b->last_stream = st;
+    uint32_t left = n_turns;
+    while (left) {
+        const uint32_t k = left < b->max_fuse ? left : b->max_fuse;
+        StepArgs a;
+        fill_args(b, a, (uint32_t)b->turn, k);
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (b->timing) {
+            if (b->events_used == b->events.size()) {
+                HIP_TRY(hipEventCreate(&e0));
+                HIP_TRY(hipEventCreate(&e1));
+                b->events.emplace_back(e0, e1);
+            }
+            e0 = b->events[b->events_used].first; e1 = b->events[b->events_used].second;
+            b->events_used++;
+            HIP_TRY(hipEventRecord(e0, st));
+        }
+        hipLaunchKernelGGL(ge_step_kernel, dim3(b->n_blocks), dim3(b->block_threads), 0, st, a, b->tables);
+        HIP_TRY(hipGetLastError());
+        if (b->timing) HIP_TRY(hipEventRecord(e1, st));
+        b->launches++;
+        b->turn += k;
+        left -= k;
+    }
+    return GE_OK;
+}
+
+int ge_batch_sync(ge_batch *b) {
+    if (!b) return GE_ERR_ARG;
+    HIP_TRY(hipSetDevice(b->device));
+    HIP_TRY(hipStreamSynchronize(b->last_stream));
+    return GE_OK;
+}
+
+int ge_batch_kernel_time(ge_batch *b, int reset, double *total_ms, uint64_t *launches) {
+    if (!b) return GE_ERR_ARG;
+    int st = ge_batch_sync(b);
+    if (st != GE_OK) return st;
+    for (size_t i = 0; i < b->events_used; i++) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, b->events[i].first, b->events[i].second));
+        b->timed_ms += ms;
+    }
+    b->events_used = 0;
+    if (total_ms) *total_ms = b->timed_ms;
+    if (launches) *launches = b->launches;
+    if (reset) { b->timed_ms = 0.0; b->launches = 0; }
+    return GE_OK;
+}
+
+int ge_batch_turn(const ge_batch *b, uint64_t *turn) {
+    if (!b || !turn) return GE_ERR_ARG;
+    *turn = b->turn;
+    return GE_OK;
+}
+
+int ge_batch_n_rooms(const ge_batch *b, uint64_t *n) {
+    if (!b || !n) return GE_ERR_ARG;
+    *n = b->n_rooms;
+    return GE_OK;
+}
+
+static int rooms_io(ge_batch *b, uint64_t first, uint64_t count, ge_room_view *dst, const ge_room_view *src) {
+    if (first + count > b->n_rooms || first + count < first) return GE_ERR_RANGE;
+    int st = ge_batch_sync(b);
+    if (st != GE_OK) return st;
+    for (Segment &s : b->segs) {
+        const uint64_t lo = first > s.local_first ? first : s.local_first;
+        const uint64_t hi = (first + count) < (s.local_first + s.dev.rooms) ? (first + count) : (s.local_first + s.dev.rooms);
+        if (lo >= hi) continue;
+        const uint64_t r0 = lo - s.local_first, nr = hi - lo;
+        const int W = (int)s.dev.words, np = planes_of(W);
+        std::vector<uint32_t> buf((size_t)nr * 12);
+        std::vector<uint32_t> plane;
+        if (src) {
+            for (uint64_t r = 0; r < nr; r++) {
+                const ge_room_view &v = src[lo - first + r];
+                if (v.n_players != s.dev.n_players) return GE_ERR_ARG;
+                view_to_words(s.dev.kind, v, s.table, &buf[r * 12]);
+            }
+        }
+        for (int j = 0; j < np; j++) {
+            const int pw = plane_words(W, j);
+            plane.resize((size_t)nr * pw);
+            char *dev = reinterpret_cast<char *>(s.dev.base) + plane_offset(s.dev.rooms_padded, j) + r0 * (uint64_t)pw * 4u;
+            if (src) {
+                for (uint64_t r = 0; r < nr; r++)
+                    for (int x = 0; x < pw; x++) plane[r * pw + x] = buf[r * 12 + 4 * j + x];
+                HIP_TRY(hipMemcpy(dev, plane.data(), plane.size() * 4, hipMemcpyHostToDevice));
+            } else {
+                HIP_TRY(hipMemcpy(plane.data(), dev, plane.size() * 4, hipMemcpyDeviceToHost));
+                for (uint64_t r = 0; r < nr; r++)
+                    for (int x = 0; x < pw; x++) buf[r * 12 + 4 * j + x] = plane[r * pw + x];
+            }
+        }
+        if (dst)
+            for (uint64_t r = 0; r < nr; r++)
+                words_to_view(s.dev.kind, &buf[r * 12], s.table, (int)s.dev.n_players, dst[lo - first + r]);
+    }
+    return GE_OK;
+}
+
+int ge_batch_read_rooms(ge_batch *b, uint64_t first, uint64_t count, ge_room_view *dst, size_t cap_bytes) {
+    if (!b || (!dst && count)) return GE_ERR_ARG;
+    if (cap_bytes / sizeof(ge_room_view) < count) return GE_ERR_ARG;
+    return rooms_io(b, first, count, dst, nullptr);
+}
+
+int ge_batch_write_rooms(ge_batch *b, uint64_t first, uint64_t count, const ge_room_view *src) {
+    if (!b || (!src && count)) return GE_ERR_ARG;
+    return rooms_io(b, first, count, nullptr, src);
+}
+
+int ge_batch_summary(ge_batch *b, ge_summary *out) {
+    if (!b || !out) return GE_ERR_ARG;
+    HIP_TRY(hipSetDevice(b->device));
+    hipStream_t st = b->last_stream;
+    HIP_TRY(hipMemsetAsync(b->sum_dev, 0, sizeof(unsigned long long) * 64, st));
+    StepArgs a;
+    fill_args(b, a, (uint32_t)b->turn, 0);
+    // the summary kernel uses 256-thread blocks of its own
+    uint32_t blocks = 0;
+    for (uint32_t k = 0; k < a.n_seg; k++) {
+        a.seg[k].block_begin = blocks;
+        blocks += (uint32_t)((a.seg[k].rooms + 255u) / 256u);
+    }
+    hipLaunchKernelGGL(ge_summary_kernel, dim3(blocks), dim3(256), 0, st, a, b->tables, b->sum_dev);
+    HIP_TRY(hipGetLastError());
+    unsigned long long h[64];
+    HIP_TRY(hipMemcpyAsync(h, b->sum_dev, sizeof h, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    memset(out, 0, sizeof *out);
+    out->rooms = b->n_rooms;
+    out->finished = h[0]; out->village_wins = h[1]; out->wolf_wins = h[2]; out->alive_players = h[3];
+    out->sum_end_turn = h[4];
+    for (int i = 0; i < 16; i++) { out->end_turn_hist[i] = h[5 + i]; out->score_hist[i] = h[21 + i]; }
+    out->checksum = h[37];
+    out->games_recycled = h[38];
+    out->turn = b->turn;
+    return GE_OK;
+}
+
+int ge_batch_state(ge_batch *b, uint32_t segment, void **dev_ptr, size_t *bytes, uint32_t *bytes_per_room) {
+    if (!b || segment >= b->segs.size()) return GE_ERR_ARG;
+    const SegDev &d = b->segs[segment].dev;
+    if (dev_ptr) *dev_ptr = d.base;
+    if (bytes) *bytes = (size_t)planes_of((int)d.words) * 16u * d.rooms_padded;
+    if (bytes_per_room) *bytes_per_room = d.words * 4u;
+    return GE_OK;
+}
+
+void ge_batch_destroy(ge_batch *b) {
+    if (!b) return;
+    (void)hipSetDevice(b->device);
+    for (auto &ev : b->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    if (b->state) (void)hipFree(b->state);
+    if (b->tables) (void)hipFree(b->tables);
+    if (b->sum_dev) (void)hipFree(b->sum_dev);
+    delete b;
+}
+
+}  // extern "C"

@@ -1,0 +1,259 @@
+"""Host side of the batch stepper, mirroring the reference's interface for this path.
+
+Reference surface kept (same names / argument meaning):
+  load_dsl_by_gamename(gamename)            agent/tools/utils.py:557-581  (YAML -> dict)
+  AgentState fields returned by agent_state current_phase_id, current_phase_name, player_states
+                                            {"1": {<declared fields>}}  agent/game_agent_v2.py:97-117
+  player ids "1".."N"                       agent/tools/utils.py:642-647
+What is new: rooms are stepped in batches on the GPU (RoomBatch), one turn = one graph run.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+from typing import Any, Dict, List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+
+from . import _lib
+
+ROOM_VIEW_DTYPE = np.dtype([("phase_id", "<i4"), ("prev_phase_id", "<i4"), ("end_turn", "<i4"), ("games", "<i4"),
+                            ("phase0_done", "u1"), ("n_players", "u1"), ("pack", "u1"), ("pad", "u1"),
+                            ("players", "u1", (16, 12)), ("det", "u1", (16,))])
+
+PACK_WEREWOLF, PACK_TWO_TRUTHS = 1, 2
+WW_FIELDS = ["role", "team", "is_alive", "role_revealed", "can_vote", "has_secret_role",
+             "night_action_eligible", "night_action_submitted", "selected_target_id"]
+TT_FIELDS = ["is_speaker", "statements_submitted", "lie_index", "lie_revealed", "can_vote",
+             "vote_choice", "has_voted", "total_score", "rounds_as_speaker"]
+_TEAMS = ["", "villagers", "werewolves"]
+
+
+class GeError(RuntimeError):
+    def __init__(self, status: int, what: str = ""):
+        msg = _lib.load().ge_strerror(status).decode()
+        super().__init__(f"{what}: {msg} ({status})" if what else f"{msg} ({status})")
+        self.status = status
+
+
+def library_path() -> str:
+    return _lib.LIB_PATH
+
+
+def _check(status: int, what: str = ""):
+    if status != 0:
+        raise GeError(status, what)
+
+
+def load_dsl_by_gamename(gamename: str, games_dir: Optional[str] = None) -> dict:
+    """Same contract as the reference's loader (utils.py:557-581): '<games_dir>/<gamename>.yaml'
+    -> dict, {} when the name is empty or the file is missing.  Also accepts the JSON form of
+    the same document ('<gamename>.json')."""
+    if not gamename:
+        return {}
+    games_dir = games_dir or os.environ.get("GE_GAMES_DIR", "games")
+    ypath = os.path.join(games_dir, f"{gamename}.yaml")
+    jpath = os.path.join(games_dir, f"{gamename}.json")
+    if os.path.exists(ypath):
+        import yaml
+        with open(ypath, encoding="utf-8") as f:
+            return yaml.safe_load(f) or {}
+    if os.path.exists(jpath):
+        with open(jpath, encoding="utf-8") as f:
+            return json.load(f)
+    return {}
+
+
+class GameTable:
+    """A game DSL compiled by ge_table_compile_json."""
+
+    def __init__(self, dsl: dict, rounds: int = 1):
+        if not isinstance(dsl, dict) or not dsl:
+            raise GeError(-2, "empty DSL")
+        self.dsl = dsl
+        text = json.dumps(dsl, ensure_ascii=False).encode("utf-8")   # int phase keys become strings
+        self.c = _lib.Table()
+        err = C.create_string_buffer(512)
+        st = _lib.load().ge_table_compile_json(text, len(text), rounds, C.byref(self.c), err, len(err))
+        if st != 0:
+            raise GeError(st, err.value.decode("utf-8", "replace"))
+
+    @classmethod
+    def from_gamename(cls, gamename: str, games_dir: Optional[str] = None, rounds: int = 1) -> "GameTable":
+        return cls(load_dsl_by_gamename(gamename, games_dir), rounds)
+
+    @property
+    def pack(self) -> int:
+        return self.c.pack
+
+    @property
+    def n_phases(self) -> int:
+        return self.c.n_phases
+
+    def rows(self) -> List[dict]:
+        out = []
+        for i in range(self.c.n_phases):
+            r = self.c.rows[i]
+            out.append({"phase_id": r.phase_id, "name": r.name.decode("utf-8", "replace"),
+                        "completion": r.completion, "act": r.act, "effect": r.effect,
+                        "terms": [(r.term_base[j], r.term_neg[j]) for j in range(r.n_terms)],
+                        "branches": [(r.br_res[j], r.br_target[j]) for j in range(r.n_branches)]})
+        return out
+
+    def phase_name(self, phase_id: int) -> str:
+        for i in range(self.c.n_phases):
+            if self.c.rows[i].phase_id == phase_id:
+                return self.c.rows[i].name.decode("utf-8", "replace")
+        return f"Phase {phase_id}"        # utils.py:30 fallback
+
+    def role_name(self, cls_idx: int) -> str:
+        return self.c.role_names[cls_idx].value.decode("utf-8", "replace")
+
+
+Segment = Tuple[GameTable, int, int]      # (table, n_players, n_rooms)
+
+
+class RoomBatch:
+    """A batch of independent rooms resident in HBM.  One `step()` = one turn of every room
+    (= one LangGraph run per room in the reference)."""
+
+    def __init__(self, segments: Sequence[Segment], seed: int = 0, first_room: int = 0,
+                 device: int = 0, max_fuse: int = 0, restart: bool = False):
+        lib = _lib.load()
+        if not 1 <= len(segments) <= _lib.GE_MAX_SEGMENTS:
+            raise GeError(-1, "segments")
+        self.segments = list(segments)
+        d = _lib.BatchDesc()
+        d.seed, d.first_room, d.n_segments, d.device, d.max_fuse = seed, first_room, len(segments), device, max_fuse
+        d.flags = 1 if restart else 0
+        for k, (tb, n_players, n_rooms) in enumerate(segments):
+            d.seg[k].table = C.pointer(tb.c)
+            d.seg[k].n_players, d.seg[k].n_rooms = n_players, n_rooms
+        h = C.c_void_p()
+        _check(lib.ge_batch_create(C.byref(d), C.byref(h)), "ge_batch_create")
+        self._h = h
+        self._lib = lib
+        self.n_rooms = sum(s[2] for s in segments)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.ge_batch_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # ---- stepping
+    def step(self, n_turns: int = 1, stream: int = 0):
+        _check(self._lib.ge_batch_step(self._h, n_turns, C.c_void_p(stream or None)), "ge_batch_step")
+
+    def reset(self):
+        _check(self._lib.ge_batch_reset(self._h), "ge_batch_reset")
+
+    def sync(self):
+        _check(self._lib.ge_batch_sync(self._h), "ge_batch_sync")
+
+    @property
+    def turn(self) -> int:
+        t = C.c_uint64()
+        _check(self._lib.ge_batch_turn(self._h, C.byref(t)))
+        return t.value
+
+    def set_timing(self, on: bool):
+        _check(self._lib.ge_batch_set_timing(self._h, int(on)))
+
+    def kernel_time(self, reset: bool = True) -> Tuple[float, int]:
+        ms, n = C.c_double(), C.c_uint64()
+        _check(self._lib.ge_batch_kernel_time(self._h, int(reset), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    # ---- state access
+    def read_rooms(self, first: int = 0, count: Optional[int] = None) -> np.ndarray:
+        count = self.n_rooms - first if count is None else count
+        out = np.zeros(count, dtype=ROOM_VIEW_DTYPE)
+        _check(self._lib.ge_batch_read_rooms(self._h, first, count, out.ctypes.data, out.nbytes), "ge_batch_read_rooms")
+        return out
+
+    def write_rooms(self, first: int, views: np.ndarray):
+        assert views.dtype == ROOM_VIEW_DTYPE and views.flags.c_contiguous
+        _check(self._lib.ge_batch_write_rooms(self._h, first, len(views), views.ctypes.data), "ge_batch_write_rooms")
+
+    def summary(self) -> Dict[str, Any]:
+        s = _lib.Summary()
+        _check(self._lib.ge_batch_summary(self._h, C.byref(s)), "ge_batch_summary")
+        return summary_to_dict(np.frombuffer(bytes(s), dtype="<u8"))
+
+    def summary_words(self) -> np.ndarray:
+        s = _lib.Summary()
+        _check(self._lib.ge_batch_summary(self._h, C.byref(s)), "ge_batch_summary")
+        return np.frombuffer(bytes(s), dtype="<u8").copy()
+
+    def state(self, segment: int = 0) -> Tuple[int, int, int]:
+        p, nbytes, bpr = C.c_void_p(), C.c_size_t(), C.c_uint32()
+        _check(self._lib.ge_batch_state(self._h, segment, C.byref(p), C.byref(nbytes), C.byref(bpr)))
+        return p.value, nbytes.value, bpr.value
+
+    def bytes_per_room(self, segment: int = 0) -> int:
+        return self.state(segment)[2]
+
+    def _segment_of(self, room: int) -> Tuple[GameTable, int]:
+        base = 0
+        for tb, n, rooms in self.segments:
+            if room < base + rooms:
+                return tb, n
+            base += rooms
+        raise IndexError(room)
+
+    def agent_state(self, room: int) -> Dict[str, Any]:
+        """AgentState-shaped dict of one room (agent/game_agent_v2.py:97-117): what the TS
+        frontend's useCoAgent sync receives (src/lib/canvas/types.ts:338-360)."""
+        tb, _ = self._segment_of(room)
+        return view_to_agent_state(tb, self.read_rooms(room, 1)[0])
+
+
+def summary_to_dict(w: np.ndarray) -> Dict[str, Any]:
+    w = [int(x) for x in w]
+    return {"rooms": w[0], "finished": w[1], "village_wins": w[2], "wolf_wins": w[3], "alive_players": w[4],
+            "sum_end_turn": w[5], "end_turn_hist": w[6:22], "score_hist": w[22:38], "checksum": w[38], "turn": w[39], "games_recycled": w[40]}
+
+
+def project_view(view) -> List[int]:
+    """Canonical integer projection of one room: [phase, prev_phase, phase0_done, end_turn]
+    + 11 ints per player (+ detective memory per player, werewolf) — the form the parity
+    tests compare (tests/golden/*.json 'layout')."""
+    n = int(view["n_players"])
+    out = [int(view["phase_id"]), int(view["prev_phase_id"]), int(view["phase0_done"]), int(view["end_turn"])]
+    for i in range(n):
+        out += [int(x) for x in view["players"][i][:11]]
+    if int(view["pack"]) == PACK_WEREWOLF:
+        out += [int(x) for x in view["det"][:n]]
+    return out
+
+
+def view_to_agent_state(tb: GameTable, view) -> Dict[str, Any]:
+    n = int(view["n_players"])
+    ps: Dict[str, Dict[str, Any]] = {}
+    det = [int(x) for x in view["det"][:n]]
+    for i in range(n):
+        f = [int(x) for x in view["players"][i]]
+        if int(view["pack"]) == PACK_WEREWOLF:
+            rec = {"role": tb.role_name(f[0]), "team": _TEAMS[f[1]], "is_alive": bool(f[2]),
+                   "role_revealed": bool(f[3]), "can_vote": bool(f[4]), "has_secret_role": bool(f[5]),
+                   "night_action_eligible": bool(f[6]), "night_action_submitted": bool(f[7]),
+                   "selected_target_id": f[8],
+                   "investigated_alignments": ({str(k + 1): _TEAMS[d] for k, d in enumerate(det) if d}
+                                               if f[0] == 4 else {})}
+        else:
+            rec = {"is_speaker": bool(f[0]), "statements_submitted": bool(f[1]), "lie_index": f[2],
+                   "lie_revealed": bool(f[3]), "can_vote": bool(f[4]), "vote_choice": f[5],
+                   "has_voted": bool(f[6]), "total_score": f[7], "rounds_as_speaker": f[8]}
+        ps[str(i + 1)] = rec
+    pid = int(view["phase_id"])
+    return {"current_phase_id": pid, "current_phase_name": tb.phase_name(pid), "player_states": ps,
+            "previous_phase_id": int(view["prev_phase_id"]), "end_turn": int(view["end_turn"])}

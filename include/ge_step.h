@@ -1,0 +1,211 @@
+/* ge_step.h — C ABI of the MI355X batch room-phase stepper (libge_step.so).
+ *
+ * Drop-in boundary for ONE path of liruihan000/game_engine: the per-turn loop
+ *   InitialRouterNode -> BotBehaviorNode -> PhaseNode -> RefereeNode -> ActionExecutor
+ *   (reference agent/game_agent_v2.py:198/468/987/619/1243, graph :1571-1587;
+ *    newer fused form agent/game_agent_v3.py:205/448/540)
+ * which the reference runs one room per LangGraph thread (src/app/api/copilotkit/route.ts:22-47)
+ * with an LLM call per node.  Here the same turn is applied to a BATCH of independent rooms
+ * on the GPU with the LLM replaced by the fixed policy of POLICY.md.
+ *
+ * Conventions:
+ *   - plain C, no torch / STL types; every function returns 0 or a negative ge_status;
+ *     nothing throws or aborts across this boundary; HIP errors map to GE_ERR_HIP.
+ *   - the caller owns every host buffer it passes; the library owns device memory behind
+ *     the opaque ge_batch handle.
+ *   - a handle is not thread-safe: one handle per host thread / GPU.
+ *   - ge_batch_step is asynchronous on the given stream; read / summary / sync synchronise.
+ *   - there is NO CPU fallback: without a HIP device ge_batch_create fails with GE_ERR_NO_DEVICE.
+ */
+#ifndef GE_STEP_H
+#define GE_STEP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GE_ABI_VERSION 1
+#define GE_MAX_PHASES 32
+#define GE_MAX_PLAYERS 12
+#define GE_MAX_SEGMENTS 4
+#define GE_MAX_TERMS 4
+#define GE_MAX_BRANCHES 4
+#define GE_NAME_LEN 64
+
+typedef enum ge_status {
+    GE_OK = 0,
+    GE_ERR_ARG = -1,        /* null pointer, bad size, out-of-range value */
+    GE_ERR_DSL = -2,        /* the DSL cannot be compiled (message in the err buffer) */
+    GE_ERR_NO_DEVICE = -3,  /* no usable HIP device: the product has no CPU path */
+    GE_ERR_HIP = -4,        /* a HIP runtime call failed (ge_last_hip_error) */
+    GE_ERR_NOMEM = -5,
+    GE_ERR_RANGE = -6,      /* room range outside the batch / turn counter would overflow */
+    GE_ERR_UNSUPPORTED = -7 /* valid DSL feature the kernels do not implement yet */
+} ge_status;
+
+/* rule packs: which declared player_states schema the game uses
+ * (reference games/werewolf-(mafia).yaml:21-72, games/two-truths-and-a-lie.yaml declaration) */
+enum { GE_PACK_WEREWOLF = 1, GE_PACK_TWO_TRUTHS = 2 };
+/* completion_criteria.type (dsl_phases_generation_prompt.txt:106-150) */
+enum { GE_COMP_UI = 0, GE_COMP_TIMER = 1, GE_COMP_ACTION = 2 };
+/* what a bot action in a player_action phase means (bot_behavior_system_prompt.txt:21-56) */
+enum { GE_ACT_NONE = 0, GE_ACT_WOLF_TARGET, GE_ACT_DOCTOR_PROTECT, GE_ACT_DETECTIVE, GE_ACT_DAY_VOTE,
+       GE_ACT_TT_STATEMENTS, GE_ACT_TT_LIE, GE_ACT_TT_VOTE };
+/* what the Referee applies when a phase is entered (referee_system_prompt_2.txt:1-8,19-22,75-82) */
+enum { GE_EFF_NONE = 0, GE_EFF_ASSIGN_ROLES, GE_EFF_NIGHT_BEGIN, GE_EFF_NIGHT_RESOLVE, GE_EFF_DAY_RESOLVE,
+       GE_EFF_TT_ROUND_START, GE_EFF_TT_REVEAL, GE_EFF_TT_SCORE };
+/* resolver bound to a natural-language next_phase key (ww:435-447, tt "Check Round Progress") */
+enum { GE_RES_ALWAYS = 0, GE_RES_WOLVES_ZERO, GE_RES_WOLVES_GE_VILLAGERS, GE_RES_FOLLOWS_DAY,
+       GE_RES_FOLLOWS_NIGHT, GE_RES_ALL_ROUNDS_DONE, GE_RES_OTHERWISE };
+
+/* One DSL phase, compiled.  Replaces what the LLM reads out of dsl['phases'][id] each turn
+ * (v2:1057, 1087-1103). */
+typedef struct ge_phase_row {
+    int32_t phase_id;                     /* DSL id (0..16, 99, ...) */
+    uint8_t completion;                   /* GE_COMP_* */
+    uint8_t act;                          /* GE_ACT_*  (GE_COMP_ACTION phases) */
+    uint8_t effect;                       /* GE_EFF_*  applied when this phase is entered */
+    uint8_t n_terms;                      /* target_players.condition: AND of terms */
+    uint8_t term_base[GE_MAX_TERMS];      /* base predicate index inside the pack (POLICY.md) */
+    uint8_t term_neg[GE_MAX_TERMS];       /* 1: the term is "== false" / "!=" */
+    uint8_t n_branches;                   /* 0: terminal phase (next_phase: null) */
+    uint8_t br_res[GE_MAX_BRANCHES];      /* GE_RES_*, evaluated in DSL order, first match wins */
+    uint8_t br_target[GE_MAX_BRANCHES];   /* dense row index of the successor */
+    uint8_t pad[3];
+    char name[GE_NAME_LEN];               /* phases.<id>.name, UTF-8, truncated */
+} ge_phase_row;
+
+/* A compiled game (one YAML file).  Host-visible so callers may inspect or build one by hand. */
+typedef struct ge_game_table {
+    int32_t abi_version;
+    int32_t pack;                         /* GE_PACK_* */
+    int32_t n_phases;
+    int32_t rounds;                       /* two-truths: agreed speaking turns per player */
+    int32_t min_players;                  /* declaration.min_players */
+    uint8_t init_fields[12];              /* player_states_template, canonical field order */
+    char role_names[5][GE_NAME_LEN];      /* werewolf: "", Villager, Werewolf, Doctor, Detective as declared */
+    ge_phase_row rows[GE_MAX_PHASES];
+} ge_game_table;
+
+/* Compiles a game DSL given as JSON text (the host parses YAML with its own loader, as the
+ * reference does: yaml.safe_load in agent/tools/utils.py:572, js-yaml in
+ * src/app/api/games/initialize-players/route.ts).  Replaces the LLM's reading of the DSL.
+ * `err` (may be NULL) receives a NUL-terminated message on GE_ERR_DSL. */
+int ge_table_compile_json(const char *dsl_json, size_t len, int rounds, ge_game_table *out,
+                          char *err, size_t err_cap);
+
+/* Canonical, layout-independent view of one room: the integer projection of the reference's
+ * AgentState (v2:97-117): current_phase_id, phase history tail, player_states fields.
+ * players[i] = player id i+1; field order per pack:
+ *   werewolf : role team is_alive role_revealed can_vote has_secret_role night_action_eligible
+ *              night_action_submitted selected_target_id acted choice
+ *   two-truths: is_speaker statements_submitted lie_index lie_revealed can_vote vote_choice
+ *              has_voted total_score rounds_as_speaker acted choice
+ * (acted/choice = this visit's latest logged action per player, i.e. the playerActions log
+ *  of bt:285-344 reduced to what later turns read.)
+ * det[i]: the Detective's investigated_alignments for player i+1: 0 unknown, 1 villagers, 2 werewolves. */
+typedef struct ge_room_view {
+    int32_t phase_id;
+    int32_t prev_phase_id;
+    int32_t end_turn;                     /* turn in which a terminal phase was entered (saturates at 65534), else -1 */
+    int32_t games;                        /* GE_FLAG_RESTART: games this slot completed before the current one */
+    uint8_t phase0_done;                  /* phase-0 guard of v2:1025-1052 already taken */
+    uint8_t n_players;
+    uint8_t pack;
+    uint8_t pad;
+    uint8_t players[16][12];
+    uint8_t det[16];
+} ge_room_view;
+
+typedef struct ge_segment_desc {
+    const ge_game_table *table;           /* copied at create; need not outlive the call */
+    uint32_t n_players;                   /* werewolf 4..12, two-truths 3..12 */
+    uint32_t reserved;
+    uint64_t n_rooms;
+} ge_segment_desc;
+
+/* ge_batch_desc.flags */
+#define GE_FLAG_NONE 0u
+/* steady state: a room that starts a turn in a terminal phase is first re-initialised to the
+ * DSL template (a new game on the same slot; the turn counter and hence the RNG stream keep
+ * running).  Off: terminal phases are absorbing, as in the reference. */
+#define GE_FLAG_RESTART 1u
+
+typedef struct ge_batch_desc {
+    uint64_t seed;
+    uint64_t first_room;                  /* global index of this batch's room 0 (sharding: the RNG is
+                                             keyed by GLOBAL room index, so results do not depend on
+                                             how rooms are split over GPUs) */
+    uint32_t n_segments;                  /* rooms are grouped by game: one segment per (table, N) */
+    uint32_t flags;
+    int32_t device;                       /* HIP device ordinal */
+    uint32_t max_fuse;                    /* turns fused into one launch (state stays in registers);
+                                             0 = library default, 1 = one launch per turn */
+    ge_segment_desc seg[GE_MAX_SEGMENTS];
+} ge_batch_desc;
+
+typedef struct ge_batch ge_batch;
+
+/* Aggregate over the rooms of a batch (what the cross-shard all-gather exchanges).
+ * Every field is a sum over rooms, so shard summaries add up to the whole-job summary. */
+typedef struct ge_summary {
+    uint64_t rooms;
+    uint64_t finished;                    /* rooms in a terminal phase */
+    uint64_t village_wins, wolf_wins;     /* werewolf rooms finished with no / some wolves alive */
+    uint64_t alive_players;
+    uint64_t sum_end_turn;                /* over finished rooms */
+    uint64_t end_turn_hist[16];           /* finished rooms by end_turn / 8 (last bucket open) */
+    uint64_t score_hist[16];              /* two-truths: players by total_score (last bucket open) */
+    uint64_t checksum;                    /* sum over rooms of hash(global room index, packed state) */
+    uint64_t turn;                        /* turns stepped so far */
+    uint64_t games_recycled;              /* GE_FLAG_RESTART: finished games whose slot was re-initialised */
+} ge_summary;
+
+/* Creates the batch with every room in the DSL's initial state (player_states_template,
+ * phase 0): the batched InitialRouterNode init of v2:255-289 + utils.py:584-653. */
+int ge_batch_create(const ge_batch_desc *desc, ge_batch **out);
+
+/* Advances EVERY room by n_turns turns (one turn = one graph run of the reference, §3.1).
+ * `hip_stream` is a hipStream_t (NULL = the default stream).  Asynchronous. */
+int ge_batch_step(ge_batch *b, uint32_t n_turns, void *hip_stream);
+
+/* Back to the initial state and turn 0 (same seed, same rooms).  Synchronises. */
+int ge_batch_reset(ge_batch *b);
+
+int ge_batch_sync(ge_batch *b);
+int ge_batch_turn(const ge_batch *b, uint64_t *turn);
+int ge_batch_n_rooms(const ge_batch *b, uint64_t *n_rooms);
+
+/* Copies `count` rooms starting at local index `first` into dst (cap_bytes >= count*sizeof(ge_room_view)).
+ * Synchronises.  Room order: segment 0's rooms, then segment 1's, ... */
+int ge_batch_read_rooms(ge_batch *b, uint64_t first, uint64_t count, ge_room_view *dst, size_t cap_bytes);
+
+/* Overwrites rooms from canonical views (checkpoint restore, tests of hand-built states). */
+int ge_batch_write_rooms(ge_batch *b, uint64_t first, uint64_t count, const ge_room_view *src);
+
+/* Device-side reduction of the whole batch.  Synchronises. */
+int ge_batch_summary(ge_batch *b, ge_summary *out);
+
+/* Raw packed state of one segment in HBM (for checkpoint = plain D2H copy, or zero-copy wrapping
+ * by the host framework).  bytes_per_room is the algorithmic record size. */
+int ge_batch_state(ge_batch *b, uint32_t segment, void **dev_ptr, size_t *bytes, uint32_t *bytes_per_room);
+
+/* Timing of the kernels launched by the most recent ge_batch_step calls since the last reset,
+ * measured with hipEvents on the stream they were launched on. */
+int ge_batch_set_timing(ge_batch *b, int on);     /* off by default: no events are recorded */
+int ge_batch_kernel_time(ge_batch *b, int reset, double *total_ms, uint64_t *launches);
+
+void ge_batch_destroy(ge_batch *b);
+
+const char *ge_strerror(int status);
+int ge_last_hip_error(void);              /* hipError_t of the last GE_ERR_HIP on this thread */
+int ge_abi_version(void);
+int ge_device_count(void);                /* number of HIP devices, 0 if none; never fails */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GE_STEP_H */

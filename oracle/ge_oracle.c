@@ -62,6 +62,7 @@ typedef struct {
 typedef struct {
     uint8_t phase, prev, phase0_done, n;
     int32_t end_turn;
+    int32_t games;            /* restart mode: games completed on this slot before the current one */
     uint8_t p[16][12];
     uint8_t det[16];          /* 0 unknown, 1 villagers, 2 werewolves (the detective's memory) */
 } orc_room;
@@ -326,19 +327,28 @@ void orc_room_step(const orc_table *tb, orc_room *r, uint64_t seed, uint64_t roo
     for (int i = 0; i < n; i++) { r->p[i][F_ACTED] = 0; r->p[i][F_CHOICE] = 0; }
     r->prev = (uint8_t)p;
     r->phase = (uint8_t)q;
-    if (!qh->n_branches && r->end_turn < 0) r->end_turn = (int32_t)turn;
+    if (!qh->n_branches && r->end_turn < 0) r->end_turn = turn < 0xFFFEu ? (int32_t)turn : 0xFFFE;
 }
 
 /* rooms[i] is room (first_room + i); turns first_turn .. first_turn+n_turns-1 */
 void orc_run(const orc_table *tb, uint64_t seed, uint64_t first_room, uint64_t n_rooms,
-             uint32_t first_turn, uint32_t n_turns, orc_room *rooms, int threads) {
+             uint32_t first_turn, uint32_t n_turns, orc_room *rooms, int threads, int restart) {
 #ifdef _OPENMP
     if (threads > 0) omp_set_num_threads(threads);
 #pragma omp parallel for schedule(static)
 #endif
     for (int64_t i = 0; i < (int64_t)n_rooms; i++)
-        for (uint32_t t = 0; t < n_turns; t++)
-            orc_room_step(tb, &rooms[i], seed, first_room + (uint64_t)i, first_turn + t);
+        for (uint32_t t = 0; t < n_turns; t++) {
+            orc_room *r = &rooms[i];
+            if (restart && !tb->ph[r->phase].n_branches) {
+                /* steady state: a finished room becomes a NEW room on the same slot; the clock
+                 * (turn index) keeps running, so the new game draws fresh random numbers */
+                int32_t g = r->games < 0xFFFF ? r->games + 1 : r->games;
+                orc_room_init(tb, r->n, r);
+                r->games = g;
+            }
+            orc_room_step(tb, r, seed, first_room + (uint64_t)i, first_turn + t);
+        }
     (void)threads;
 }
 

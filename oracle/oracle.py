@@ -37,7 +37,7 @@ class _Table(C.Structure):
 
 
 ROOM_DTYPE = np.dtype([("phase", "u1"), ("prev", "u1"), ("phase0_done", "u1"), ("n", "u1"),
-                       ("end_turn", "<i4"), ("p", "u1", (16, 12)), ("det", "u1", (16,))])
+                       ("end_turn", "<i4"), ("games", "<i4"), ("p", "u1", (16, 12)), ("det", "u1", (16,))])
 
 
 def build(force: bool = False) -> str:
@@ -56,7 +56,7 @@ def lib():
         _lib = C.CDLL(build())
         _lib.orc_room_init.argtypes = [C.POINTER(_Table), C.c_int, C.c_void_p]
         _lib.orc_run.argtypes = [C.POINTER(_Table), C.c_uint64, C.c_uint64, C.c_uint64,
-                                 C.c_uint32, C.c_uint32, C.c_void_p, C.c_int]
+                                 C.c_uint32, C.c_uint32, C.c_void_p, C.c_int, C.c_int]
         assert _lib.orc_sizeof_room() == ROOM_DTYPE.itemsize
         assert _lib.orc_sizeof_table() == C.sizeof(_Table)
     return _lib
@@ -109,10 +109,10 @@ class Oracle:
         return rooms
 
     def run(self, rooms: np.ndarray, seed: int, first_room: int, first_turn: int, n_turns: int,
-            threads: int = 1) -> None:
+            threads: int = 1, restart: bool = False) -> None:
         assert rooms.dtype == ROOM_DTYPE and rooms.flags.c_contiguous
         lib().orc_run(C.byref(self.ct), seed, first_room, len(rooms), first_turn, n_turns,
-                      rooms.ctypes.data, threads)
+                      rooms.ctypes.data, threads, int(restart))
 
     def project(self, room) -> List[int]:
         out = [self.ids[int(room["phase"])], self.ids[int(room["prev"])], int(room["phase0_done"]),
@@ -123,10 +123,11 @@ class Oracle:
             out += [int(x) for x in room["det"][: self.n]]
         return out
 
-    def trajectory(self, seed: int, room_index: int, n_turns: int) -> List[List[int]]:
+    def trajectory(self, seed: int, room_index: int, n_turns: int, restart: bool = False,
+                   first_turn: int = 0) -> List[List[int]]:
         rooms = self.init_rooms(1)
         out = []
-        for t in range(n_turns):
-            self.run(rooms, seed, room_index, t, 1)
+        for t in range(first_turn, first_turn + n_turns):
+            self.run(rooms, seed, room_index, t, 1, restart=restart)
             out.append(self.project(rooms[0]))
         return out

@@ -63,5 +63,37 @@ def main():
                        "cases": cases}, f, separators=(",", ":"))
 
 
+def restart_cases():
+    """Steady-state mode (GE_FLAG_RESTART): when a room is finished, the NEXT turn belongs to a
+    brand-new room on the same slot whose clock starts at that turn.  Reference-side that is a
+    fresh RoomSession(turn0=...) — a new LangGraph thread — chained after the finished one."""
+    out = []
+    for game, n, turns in (("werewolf-(mafia)", 8, 260), ("two-truths-and-a-lie", 4, 200),
+                           ("werewolf-(mafia)", 12, 300)):
+        cases = []
+        for seed in SEEDS:
+            room = 77
+            sess = {v: RoomSession(game, n, seed, room, v) for v in ("v2", "v3")}
+            traj, games = [], 0
+            for t in range(turns):
+                if sess["v2"].end_turn >= 0:
+                    sess = {v: RoomSession(game, n, seed, room, v, turn0=t) for v in ("v2", "v3")}
+                    games += 1
+                for s_ in sess.values():
+                    s_.step()
+                pa = sess["v2"].project()
+                assert pa == sess["v3"].project()
+                traj.append(pa)
+            assert games >= 3
+            cases.append({"seed": seed, "room": room, "turns": traj, "games": games})
+            print("restart", game, n, hex(seed), "games", games, file=sys.stderr)
+        name = f"restart_{game.split('-(')[0].replace('-', '_')}_n{n}.json"
+        with open(os.path.join(GOLD, name), "w") as f:
+            json.dump({"game": game, "n_players": n, "rounds": 1, "restart": True,
+                       "source": "chained reference sessions (v2 + v3) under FixedPolicy, clock continuing",
+                       "cases": cases}, f, separators=(",", ":"))
+
+
 if __name__ == "__main__":
     main()
+    restart_cases()

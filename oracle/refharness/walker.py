@@ -88,7 +88,7 @@ class RoomSession:
     """One room (= one LangGraph thread, src/app/api/copilotkit/route.ts:24-37)."""
 
     def __init__(self, game: str, n_players: int, seed: int, room: int = 0,
-                 version: str = "v2", rounds: int = 1):
+                 version: str = "v2", rounds: int = 1, turn0: int = 0):
         from .. import dsl_table
         from .policy import FixedPolicy
         import yaml
@@ -97,8 +97,8 @@ class RoomSession:
         with open(os.path.join(REFERENCE_ROOT, "games", f"{game}.yaml"), encoding="utf-8") as f:
             self.table = dsl_table.compile_dsl(yaml.safe_load(f), rounds=rounds)
         self.policy = FixedPolicy(self.table, seed, room)
-        self.turn = 0
-        self.t_enter, self.prev_phase, self.end_turn = -1, 0, -1
+        self.turn = turn0              # the clock may start late: a new room on a recycled slot
+        self.t_enter, self.prev_phase, self.end_turn = turn0 - 1, 0, -1
         self.llm_calls = 0
         self.node_path: List[str] = []
         self.state: Dict[str, Any] = {

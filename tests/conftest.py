@@ -25,6 +25,10 @@ def golden_files():
     return sorted(f for f in os.listdir(GOLD) if f.startswith("traj_") and f.endswith(".json"))
 
 
+def restart_files():
+    return sorted(f for f in os.listdir(GOLD) if f.startswith("restart_") and f.endswith(".json"))
+
+
 def load_golden(name: str) -> dict:
     with open(os.path.join(GOLD, name)) as f:
         return json.load(f)

@@ -1,0 +1,39 @@
+"""Helpers shared by the GPU parity tests: oracle rooms -> the product's room-view layout."""
+import numpy as np
+
+from game_engine_amd.stepper import ROOM_VIEW_DTYPE
+
+
+def oracle_rooms_as_views(orc, rooms: np.ndarray) -> np.ndarray:
+    """oracle.oracle.ROOM_DTYPE array -> ROOM_VIEW_DTYPE array (vectorised), for whole-batch memcmp."""
+    ids = np.array(orc.ids, dtype=np.int32)
+    v = np.zeros(len(rooms), dtype=ROOM_VIEW_DTYPE)
+    v["phase_id"] = ids[rooms["phase"]]
+    v["prev_phase_id"] = ids[rooms["prev"]]
+    v["end_turn"] = rooms["end_turn"]
+    v["games"] = rooms["games"]
+    v["phase0_done"] = rooms["phase0_done"]
+    v["n_players"] = rooms["n"]
+    v["pack"] = orc.table.pack
+    v["players"] = rooms["p"]
+    v["players"][:, :, 11] = 0
+    v["det"] = rooms["det"]
+    return v
+
+
+def oracle_batch(orc, n_rooms, seed, first_room, turns, threads=0, restart=False):
+    rooms = orc.init_rooms(n_rooms)
+    orc.run(rooms, seed, first_room, 0, turns, threads=threads, restart=restart)
+    return oracle_rooms_as_views(orc, rooms)
+
+
+def assert_views_equal(got: np.ndarray, want: np.ndarray, what=""):
+    if got.tobytes() == want.tobytes():
+        return
+    for name in ROOM_VIEW_DTYPE.names:
+        bad = np.nonzero((got[name] != want[name]).reshape(len(got), -1).any(axis=1))[0]
+        if len(bad):
+            i = int(bad[0])
+            raise AssertionError(f"{what}: field {name!r} differs in {len(bad)} rooms; first room {i}: "
+                                 f"got {got[name][i].tolist()} want {want[name][i].tolist()}")
+    raise AssertionError(what + ": padding differs")

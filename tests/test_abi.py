@@ -1,0 +1,63 @@
+"""The C-ABI library loads, exports every symbol include/ge_step.h declares, and refuses to run
+without a GPU instead of falling back to a CPU path.  No compute calls."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+from game_engine_amd import GameTable, GeError, RoomBatch, _lib
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "ge_step.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ge_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    names = _declared()
+    assert set(names) == set(_lib.SYMBOLS)
+    for n in names:
+        assert getattr(lib, n) is not None
+    assert lib.ge_abi_version() == 1
+
+
+def test_struct_sizes_match_header():
+    # sizes the N-API / cgo / ctypes bindings rely on
+    from game_engine_amd.stepper import ROOM_VIEW_DTYPE
+    assert ROOM_VIEW_DTYPE.itemsize == 20 + 16 * 12 + 16
+    assert C.sizeof(_lib.PhaseRow) == 4 + 4 + 4 + 4 + 1 + 4 + 4 + 3 + 64
+    assert C.sizeof(_lib.Summary) == 8 * 41
+
+
+def test_strerror_and_argument_errors():
+    lib = _lib.load()
+    assert lib.ge_strerror(0) == b"ok"
+    assert b"no HIP device" in lib.ge_strerror(-3)
+    assert lib.ge_batch_create(None, None) == -1
+    assert lib.ge_batch_step(None, 1, None) == -1
+    assert lib.ge_table_compile_json(None, 0, 1, None, None, 0) == -1
+
+
+def test_no_cpu_fallback(dsl_ww):
+    """Without a GPU the product must fail loudly (GE_ERR_NO_DEVICE), never emulate."""
+    lib = _lib.load()
+    if lib.ge_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(GeError) as e:
+        RoomBatch([(GameTable(dsl_ww), 8, 16)])
+    assert e.value.status == -3
+
+
+def test_product_does_not_import_the_oracle():
+    """The oracle is test infrastructure: nothing under game_engine_amd/ may reference it."""
+    pkg = os.path.join(ROOT, "game_engine_amd")
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h", ".js", ".ts", ".cc")):
+                src = open(os.path.join(d, f), encoding="utf-8").read()
+                for bad in ("import oracle", "from oracle", "libge_oracle", "ge_oracle", "orc_run", "refharness"):
+                    assert bad not in src, (os.path.join(d, f), bad)

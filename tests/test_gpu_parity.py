@@ -1,0 +1,231 @@
+"""GPU parity (-m gpu): the HIP path, called through the C ABI, against
+  (1) the committed golden vectors (reference node coroutines under the fixed policy),
+  (2) the oracle on the same seeded inputs at sizes it finishes in seconds,
+  (3) size-independent properties at BASELINE.json's full sizes.
+Integer path: every comparison is bit-exact."""
+import numpy as np
+import pytest
+
+from conftest import golden_files, load_dsl, load_golden, restart_files
+from game_engine_amd import GameTable, GeError, RoomBatch
+from game_engine_amd.stepper import project_view
+from parity_util import assert_views_equal, oracle_batch
+
+pytestmark = pytest.mark.gpu
+SEEDS = [0, 1, 0xC0FFEE]
+
+
+def _oracle(dsl, n, rounds=1):
+    from oracle.oracle import Oracle
+    return Oracle(dsl, n, rounds=rounds)
+
+
+@pytest.mark.parametrize("name", golden_files())
+def test_golden_trajectories_turn_by_turn(name):
+    """Every turn of every committed reference trajectory, one launch per turn."""
+    g = load_golden(name)
+    tb = GameTable(load_dsl(g["game"]), rounds=g["rounds"])
+    for case in g["cases"]:
+        with RoomBatch([(tb, g["n_players"], 1)], seed=case["seed"], first_room=case["room"], max_fuse=1) as b:
+            for t, want in enumerate(case["turns"]):
+                b.step(1)
+                got = project_view(b.read_rooms(0, 1)[0])
+                assert got == want, f"{name} seed={case['seed']:#x} room={case['room']} turn={t}"
+
+
+@pytest.mark.parametrize("name", golden_files())
+def test_golden_trajectories_fused(name):
+    """Same end states when all turns run inside one launch (state kept in registers)."""
+    g = load_golden(name)
+    tb = GameTable(load_dsl(g["game"]), rounds=g["rounds"])
+    for case in g["cases"]:
+        T = len(case["turns"])
+        with RoomBatch([(tb, g["n_players"], 1)], seed=case["seed"], first_room=case["room"], max_fuse=T) as b:
+            b.step(T)
+            assert project_view(b.read_rooms(0, 1)[0]) == case["turns"][-1]
+
+
+@pytest.mark.parametrize("game,n,n_rooms,turns,rounds", [
+    ("werewolf-(mafia)", 8, 65536, 64, 1),          # BASELINE config C2
+    ("werewolf-(mafia)", 12, 20000, 80, 1),
+    ("werewolf-(mafia)", 4, 5000, 40, 1),
+    ("werewolf-(mafia)", 9, 3001, 64, 1),
+    ("two-truths-and-a-lie", 4, 65536, 64, 1),
+    ("two-truths-and-a-lie", 3, 777, 48, 1),
+    ("two-truths-and-a-lie", 7, 4099, 120, 2),
+    ("two-truths-and-a-lie", 12, 2048, 150, 1),
+])
+@pytest.mark.parametrize("seed", SEEDS)
+def test_batch_equals_oracle(game, n, n_rooms, turns, rounds, seed):
+    dsl = load_dsl(game)
+    first = 123456789 if seed else 0
+    with RoomBatch([(GameTable(dsl, rounds), n, n_rooms)], seed=seed, first_room=first) as b:
+        b.step(turns)
+        got = b.read_rooms()
+    want = oracle_batch(_oracle(dsl, n, rounds), n_rooms, seed, first, turns)
+    assert_views_equal(got, want, f"{game} n={n} seed={seed:#x}")
+
+
+@pytest.mark.parametrize("name", restart_files())
+def test_restart_mode_golden(name):
+    g = load_golden(name)
+    tb = GameTable(load_dsl(g["game"]))
+    for case in g["cases"]:
+        with RoomBatch([(tb, g["n_players"], 1)], seed=case["seed"], first_room=case["room"],
+                       max_fuse=1, restart=True) as b:
+            for t, want in enumerate(case["turns"]):
+                b.step(1)
+                assert project_view(b.read_rooms(0, 1)[0]) == want, f"{name} seed={case['seed']:#x} turn={t}"
+            assert int(b.read_rooms(0, 1)[0]["games"]) == case["games"]
+
+
+@pytest.mark.parametrize("game,n", [("werewolf-(mafia)", 8), ("werewolf-(mafia)", 12), ("two-truths-and-a-lie", 4)])
+def test_restart_mode_equals_oracle(game, n):
+    """The bench workload: steady state, finished rooms recycled, many fused launches."""
+    dsl = load_dsl(game)
+    R, turns, seed = 20000, 700, 0xC0FFEE
+    with RoomBatch([(GameTable(dsl), n, R)], seed=seed, restart=True) as b:
+        b.step(turns)
+        got = b.read_rooms()
+        s = b.summary()
+    want = oracle_batch(_oracle(dsl, n), R, seed, 0, turns, restart=True)
+    assert_views_equal(got, want, f"restart {game} n={n}")
+    assert s["games_recycled"] == int(want["games"].sum()) > R
+
+
+def test_fused_equals_unfused_and_chunked(dsl_ww):
+    tb = GameTable(dsl_ww)
+    outs = []
+    for fuse, chunks in ((1, [50]), (64, [50]), (7, [13, 1, 36]), (64, [1] * 50)):
+        with RoomBatch([(tb, 8, 10000)], seed=5, max_fuse=fuse) as b:
+            for c in chunks:
+                b.step(c)
+            assert b.turn == 50
+            outs.append(b.read_rooms().tobytes())
+    assert outs[0] == outs[1] == outs[2] == outs[3]
+
+
+def test_mixed_batch_one_launch(dsl_ww, dsl_tt):
+    """BASELINE config C5 shape: Werewolf and Two-Truths rooms (different phase graphs and record
+    layouts) advanced by the same launches; global room indices run across segments."""
+    ww, tt = GameTable(dsl_ww), GameTable(dsl_tt)
+    n_ww, n_tt, turns, seed, first = 3000, 5000, 64, 0xC0FFEE, 1 << 33
+    with RoomBatch([(ww, 8, n_ww), (tt, 4, n_tt), (ww, 12, 700)], seed=seed, first_room=first) as b:
+        b.step(turns)
+        got = b.read_rooms()
+        s = b.summary()
+    assert_views_equal(got[:n_ww], oracle_batch(_oracle(dsl_ww, 8), n_ww, seed, first, turns), "ww8 segment")
+    assert_views_equal(got[n_ww:n_ww + n_tt], oracle_batch(_oracle(dsl_tt, 4), n_tt, seed, first + n_ww, turns), "tt4 segment")
+    assert_views_equal(got[n_ww + n_tt:], oracle_batch(_oracle(dsl_ww, 12), 700, seed, first + n_ww + n_tt, turns), "ww12 segment")
+    assert s["rooms"] == n_ww + n_tt + 700 and s["finished"] == int((got["end_turn"] >= 0).sum())
+
+
+def test_summary_matches_readback(dsl_ww, dsl_tt):
+    for dsl, n, pack in ((dsl_ww, 8, 1), (dsl_tt, 4, 2)):
+        with RoomBatch([(GameTable(dsl), n, 30011)], seed=1) as b:
+            b.step(40)
+            r = b.read_rooms()
+            s = b.summary()
+        fin = r["end_turn"] >= 0
+        assert s["rooms"] == 30011 and s["turn"] == 40
+        assert s["finished"] == int(fin.sum()) and s["sum_end_turn"] == int(r["end_turn"][fin].sum())
+        hist = np.bincount(np.minimum(r["end_turn"][fin] // 8, 15), minlength=16)
+        assert s["end_turn_hist"] == hist.tolist()
+        if pack == 1:
+            alive = r["players"][:, :n, 2]
+            wolves_alive = ((r["players"][:, :n, 1] == 2) & (alive == 1)).sum(axis=1)
+            assert s["alive_players"] == int(alive.sum())
+            assert s["village_wins"] == int((fin & (wolves_alive == 0)).sum())
+            assert s["wolf_wins"] == int((fin & (wolves_alive > 0)).sum())
+            assert s["village_wins"] + s["wolf_wins"] == s["finished"]
+        else:
+            sc = np.bincount(np.minimum(r["players"][:, :n, 7].ravel(), 15), minlength=16)
+            assert s["score_hist"] == sc.tolist()
+
+
+def test_shard_invariance(dsl_ww):
+    """results do not depend on how rooms are split (RNG keyed by global room index);
+    summaries of shards add up to the whole-job summary, checksum included."""
+    tb = GameTable(dsl_ww)
+    R, turns, seed = 40000, 64, 7
+    with RoomBatch([(tb, 8, R)], seed=seed, first_room=1000) as b:
+        b.step(turns)
+        whole, sw = b.read_rooms(), b.summary_words()
+    parts, acc = [], np.zeros_like(sw)
+    for lo, hi in ((0, 12345), (12345, 12346), (12346, R)):
+        with RoomBatch([(tb, 8, hi - lo)], seed=seed, first_room=1000 + lo) as b:
+            b.step(turns)
+            parts.append(b.read_rooms())
+            w = b.summary_words()
+            acc[:-1] = acc[:-1] + w[:-1]          # wraps mod 2^64 like the device sum
+            acc[-1] = w[-1]
+    assert np.concatenate(parts).tobytes() == whole.tobytes()
+    assert acc.tolist() == sw.tolist()
+
+
+def test_write_read_roundtrip_and_restore(dsl_ww, dsl_tt):
+    """Checkpoint/restore through canonical views: restore mid-game, continue, same end state."""
+    for dsl, n in ((dsl_ww, 12), (dsl_ww, 6), (dsl_tt, 4), (dsl_tt, 8), (dsl_tt, 11)):
+        tb = GameTable(dsl)
+        with RoomBatch([(tb, n, 999)], seed=3, first_room=50) as a:
+            a.step(23)
+            mid = a.read_rooms()
+            a.step(41)
+            end = a.read_rooms()
+        with RoomBatch([(tb, n, 999)], seed=3, first_room=50) as b:
+            b.step(23)                                   # only to advance the turn counter
+            b.write_rooms(0, np.ascontiguousarray(mid[::-1])[::-1].copy())
+            assert b.read_rooms().tobytes() == mid.tobytes()
+            b.step(41)
+            assert b.read_rooms().tobytes() == end.tobytes()
+
+
+def test_invariants_at_full_sizes(dsl_ww, dsl_tt):
+    """BASELINE sizes C3 (1 048 576 Two-Truths x 4) and one GPU's share of C4 (2 097 152 Werewolf
+    x 12): size-independent properties instead of an oracle run."""
+    with RoomBatch([(GameTable(dsl_tt), 4, 1 << 20)], seed=1) as b:
+        b.step(64)
+        s1 = b.summary()
+        b.step(64)
+        s2 = b.summary()
+        sample = b.read_rooms(1 << 19, 4096)
+    assert s2["finished"] >= s1["finished"] > 0 and s2["finished"] == 1 << 20   # terminal is absorbing, all done by 128
+    assert sum(s2["score_hist"]) == 4 << 20
+    pts = sample["players"][:, :4, 7].astype(int).sum(axis=1)
+    assert (pts == 3 * 4).all()      # every vote gives exactly one point (voter if right, speaker if fooled)
+    assert (sample["players"][:, :4, 8] == 1).all() and (sample["phase_id"] == 99).all()
+
+    with RoomBatch([(GameTable(dsl_ww), 12, 1 << 21)], seed=0xC0FFEE, first_room=3 << 21) as b:
+        b.step(2)
+        r = b.read_rooms(0, 8192)
+        roles = r["players"][:, :12, 0]
+        assert ((roles == 2).sum(axis=1) == 3).all() and ((roles == 3).sum(axis=1) == 1).all()
+        assert ((roles == 4).sum(axis=1) == 1).all() and ((roles == 1).sum(axis=1) == 7).all()
+        b.step(62)
+        s1, alive1 = b.summary(), b.read_rooms(0, 8192)["players"][:, :12, 2].copy()
+        b.step(64)
+        s2, r2 = b.summary(), b.read_rooms(0, 8192)
+    assert s1["finished"] <= s2["finished"] and s2["village_wins"] + s2["wolf_wins"] == s2["finished"]
+    assert (r2["players"][:, :12, 2] <= alive1).all()                 # the dead stay dead
+    dead = r2["players"][:, :12, 2] == 0
+    assert (r2["players"][:, :12, 4][dead] == 0).all() and (r2["players"][:, :12, 3][dead] == 1).all()
+    assert s2["alive_players"] <= s1["alive_players"] <= 12 << 21
+
+
+def test_argument_and_range_errors(dsl_ww, dsl_tt):
+    tb = GameTable(dsl_ww)
+    for n in (3, 13):
+        with pytest.raises(GeError):
+            RoomBatch([(tb, n, 10)])
+    with pytest.raises(GeError):
+        RoomBatch([(tb, 8, 0)])
+    with pytest.raises(GeError):
+        RoomBatch([(GameTable(dsl_tt, rounds=15), 12, 4)])          # scores would not fit a byte
+    with RoomBatch([(tb, 8, 10)]) as b:
+        with pytest.raises(GeError) as e:
+            b.read_rooms(5, 6)
+        assert e.value.status == -6
+        b.step(0)
+        assert b.turn == 0
+        with pytest.raises(GeError):
+            b.step(70000)

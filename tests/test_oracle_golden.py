@@ -3,7 +3,7 @@ produced by running the REFERENCE's own node coroutines (game_agent_v2.py / v3) 
 fixed policy — turn by turn, bit-exact.  CPU only."""
 import pytest
 
-from conftest import golden_files, load_dsl, load_golden
+from conftest import golden_files, load_dsl, load_golden, restart_files
 from oracle.oracle import Oracle
 
 
@@ -28,3 +28,15 @@ def test_oracle_batched_equals_stepwise(dsl_ww):
         orc.run(b, 0xC0FFEE, 1000, t, 1, threads=4)
     assert a.tobytes() == b.tobytes()
     assert (a["end_turn"] >= 0).mean() > 0.5
+
+
+@pytest.mark.parametrize("name", restart_files())
+def test_oracle_restart_mode_matches_chained_reference_sessions(name):
+    """Steady-state mode: a finished room is replaced, on its next turn, by a new reference
+    session whose clock starts there."""
+    g = load_golden(name)
+    orc = Oracle(load_dsl(g["game"]), g["n_players"])
+    for case in g["cases"]:
+        got = orc.trajectory(case["seed"], case["room"], len(case["turns"]), restart=True)
+        for t, (a, b) in enumerate(zip(got, case["turns"])):
+            assert a == b, f"{name} seed={case['seed']:#x} turn={t}"

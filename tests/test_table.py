@@ -1,0 +1,79 @@
+"""DSL -> phase table: the product's compiler (ge_table_compile_json, C++) against the oracle's
+(oracle/dsl_table.py), on the reference's two shipped games.  CPU only (no kernels run)."""
+import copy
+import json
+
+import pytest
+
+from conftest import load_dsl
+from game_engine_amd import GameTable, GeError
+from oracle import dsl_table as T
+
+GAMES = ["werewolf-(mafia)", "two-truths-and-a-lie"]
+
+
+@pytest.mark.parametrize("game", GAMES)
+def test_product_table_equals_oracle_table(game):
+    dsl = load_dsl(game)
+    ot = T.compile_dsl(dsl)
+    pt = GameTable(dsl)
+    assert pt.pack == ot.pack and pt.n_phases == len(ot.phases)
+    for prow, op in zip(pt.rows(), ot.phases):
+        assert prow["phase_id"] == op.id and prow["name"] == op.name[:63]
+        assert (prow["completion"], prow["act"], prow["effect"]) == (op.completion, op.act, op.effect)
+        assert prow["terms"] == [(t.base, int(t.negate)) for t in op.terms]
+        assert prow["branches"] == [(b.resolver, b.target_idx) for b in op.branches]
+
+
+def test_werewolf_phase_graph(dsl_ww):
+    """18 phases, ids 0-16 and 99; player_action phases 2,3,4,7,10,11,12,15."""
+    rows = GameTable(dsl_ww).rows()
+    assert [r["phase_id"] for r in rows] == list(range(17)) + [99]
+    assert [r["phase_id"] for r in rows if r["completion"] == 2] == [2, 3, 4, 7, 10, 11, 12, 15]
+    assert [r["phase_id"] for r in rows if r["completion"] == 1] == [6, 14]
+    nine = rows[9]
+    assert [(res, rows[t]["phase_id"]) for res, t in nine["branches"]] == [(1, 99), (2, 99), (3, 10), (4, 14)]
+    assert rows[17]["branches"] == []
+    tb = GameTable(dsl_ww)
+    assert [tb.role_name(i) for i in range(5)] == ["", "Villager", "Werewolf", "Doctor", "Detective"]
+    assert list(tb.c.init_fields[:9]) == [0, 0, 1, 0, 1, 0, 0, 0, 0]      # ww:75-86 template
+
+
+def test_two_truths_phase_graph(dsl_tt):
+    rows = GameTable(dsl_tt).rows()
+    assert [r["phase_id"] for r in rows] == list(range(9)) + [99]
+    assert [r["phase_id"] for r in rows if r["completion"] == 2] == [2, 3, 5]
+    assert [(res, rows[t]["phase_id"]) for res, t in rows[8]["branches"]] == [(5, 99), (6, 1)]
+    assert list(GameTable(dsl_tt).c.init_fields[:9]) == [0, 0, 0, 0, 1, 0, 0, 0, 0]
+
+
+def test_int_and_str_phase_keys_compile_alike(dsl_ww):
+    """utils.py:29 / v2:1179-1188 accept int and str phase keys; so does the compiler."""
+    a = GameTable(dsl_ww).rows()
+    d = copy.deepcopy(dsl_ww)
+    d["phases"] = {int(k): v for k, v in d["phases"].items()}
+    assert GameTable(d).rows() == a
+
+
+@pytest.mark.parametrize("mutate,needle", [
+    (lambda d: d["phases"]["9"]["next_phase"].update({"When the moon is full": {"id": 99, "name": "x"}}), "no branch resolver"),
+    (lambda d: d["phases"]["2"]["completion_criteria"]["target_players"].update(condition="player.mood == 'angry'"), "not in rule pack"),
+    (lambda d: d["phases"]["2"]["completion_criteria"]["target_players"].update(condition="len(players) > 3"), "unsupported condition"),
+    (lambda d: d["phases"]["3"].update(next_phase={"id": 55, "name": "nowhere"}), "not in phases"),
+    (lambda d: d["phases"]["3"]["completion_criteria"].update(type="dice_roll"), "unknown completion type"),
+    (lambda d: d["declaration"].pop("player_states"), "no rule pack"),
+    (lambda d: d.pop("phases"), "needs top-level"),
+])
+def test_bad_dsl_is_an_error_not_a_guess(dsl_ww, mutate, needle):
+    d = copy.deepcopy(dsl_ww)
+    mutate(d)
+    with pytest.raises(GeError) as e:
+        GameTable(d)
+    assert e.value.status == -2 and needle in str(e.value)
+    with pytest.raises(T.DslError):
+        T.compile_dsl(d)
+
+
+def test_empty_dsl():
+    with pytest.raises(GeError):
+        GameTable({})
