@@ -91,20 +91,35 @@ __device__ __forceinline__ void ww_turn(WW<NB> &s, const DevRow *rows, uint32_t 
     const uint32_t r_vil = s.rb0 & ~s.rb1 & nrb2, r_wolf = ~s.rb0 & s.rb1 & nrb2;
     const uint32_t r_doc = s.rb0 & s.rb1 & nrb2, r_det = s.rb2 & ~s.rb1 & ~s.rb0;
 
-    // ---- who must act: target_players.condition AND alive, all players at once
+    // ---- who must act: target_players.condition AND alive, all players at once.
+    // The 12 base predicates are packed NB bits apart into 64-bit words; a term selects its
+    // mask with one shift (row.r1 holds word index and shift per term, filled per layout by
+    // the host).  Written as shifts, not as a select chain over the struct fields: the
+    // compiler turns such a chain into an indexed load and spills the whole room to scratch.
     uint32_t T = 0;
     if (comp == COMP_ACTION) {
+        uint64_t P0, P1, P2;
+        if (NB == 8) {
+            P0 = (uint64_t)(s.alive | (s.can_vote << 8) | (s.revealed << 16) | (s.secret << 24)) |
+                 ((uint64_t)(s.elig | (s.sub << 8) | (s.team_v << 16) | (s.team_w << 24)) << 32);
+            P1 = (uint64_t)((r_vil & 0xFFu) | ((r_wolf & 0xFFu) << 8) | ((r_doc & 0xFFu) << 16) | ((r_det & 0xFFu) << 24));
+            P2 = 0;
+        } else {
+            P0 = (uint64_t)s.alive | ((uint64_t)s.can_vote << 12) | ((uint64_t)s.revealed << 24) |
+                 ((uint64_t)s.secret << 36) | ((uint64_t)s.elig << 48);
+            P1 = (uint64_t)s.sub | ((uint64_t)s.team_v << 12) | ((uint64_t)s.team_w << 24) |
+                 ((uint64_t)(r_vil & 0xFFFu) << 36) | ((uint64_t)(r_wolf & 0xFFFu) << 48);
+            P2 = (uint64_t)(r_doc & 0xFFFu) | ((uint64_t)(r_det & 0xFFFu) << 12);
+        }
         T = s.alive;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const uint32_t b = (row.r1 >> (4 * j)) & 15u;
-            uint32_t m = s.alive;
-            m = b == 1 ? s.can_vote : m;  m = b == 2 ? s.revealed : m;  m = b == 3 ? s.secret : m;
-            m = b == 4 ? s.elig : m;      m = b == 5 ? s.sub : m;       m = b == 6 ? s.team_v : m;
-            m = b == 7 ? s.team_w : m;    m = b == 8 ? r_vil : m;       m = b == 9 ? r_wolf : m;
-            m = b == 10 ? r_doc : m;      m = b == 11 ? r_det : m;
-            m = ((row.r0 >> (16 + j)) & 1u) ? ~m : m;
-            T &= (uint32_t)j < nterms ? m : 0xFFFFFFFFu;
+        for (uint32_t j = 0; j < nterms; j++) {
+            const uint32_t e = (row.r1 >> (8u * j)) & 255u;
+            const uint32_t wi = e >> 6;
+            uint64_t word = wi == 0u ? P0 : P1;
+            word = wi == 2u ? P2 : word;
+            uint32_t m = (uint32_t)(word >> (e & 63u));
+            m = ((row.r0 >> (16u + j)) & 1u) ? ~m : m;
+            T &= m;
         }
         T &= ALL;
     }
@@ -225,15 +240,15 @@ __device__ __forceinline__ void tt_turn(TT<NB> &s, const DevRow *rows, uint32_t 
 
     uint32_t T = 0;
     if (comp == COMP_ACTION) {
+        // the 5 base predicates, NB bits apart in one 64-bit word (see ww_turn)
+        const uint64_t P0 = (uint64_t)s.speaker | ((uint64_t)s.submitted << NB) | ((uint64_t)s.revealed << (2 * NB)) |
+                            ((uint64_t)s.can_vote << (3 * NB)) | ((uint64_t)s.has_voted << (4 * NB));
         T = ALL;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const uint32_t b = (row.r1 >> (4 * j)) & 15u;
-            uint32_t m = s.speaker;
-            m = b == 1 ? s.submitted : m; m = b == 2 ? s.revealed : m;
-            m = b == 3 ? s.can_vote : m;  m = b == 4 ? s.has_voted : m;
-            m = ((row.r0 >> (16 + j)) & 1u) ? ~m : m;
-            T &= (uint32_t)j < nterms ? m : 0xFFFFFFFFu;
+        for (uint32_t j = 0; j < nterms; j++) {
+            const uint32_t e = (row.r1 >> (8u * j)) & 255u;
+            uint32_t m = (uint32_t)(P0 >> (e & 63u));
+            m = ((row.r0 >> (16u + j)) & 1u) ? ~m : m;
+            T &= m;
         }
         T &= ALL;
     }

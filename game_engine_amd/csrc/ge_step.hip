@@ -32,11 +32,9 @@ struct SegDev {
 };
 
 struct StepArgs {
-    SegDev seg[GE_MAX_SEGMENTS];
     uint32_t n_seg, turn0, n_turns, seed_lo, seed_hi, block_threads, restart;
+    uint32_t block_begin[GE_MAX_SEGMENTS];
 };
-
-constexpr int N_SUM = 5 + 16 + 16 + 1;     // ge_summary counters before `turn`
 
 template <int WORDS>
 __device__ __forceinline__ void load_words(const uint32_t *base, uint64_t rooms_padded, uint64_t room, uint32_t *w) {
@@ -68,7 +66,8 @@ __device__ __forceinline__ void store_words(uint32_t *base, uint64_t rooms_padde
 }
 
 template <int NB>
-__device__ __forceinline__ void run_ww(const SegDev &sg, const StepArgs &a, const DevRow *rows, uint64_t room) {
+__device__ __forceinline__ void run_ww(const SegDev *__restrict__ sgp, const StepArgs &a, const DevRow *rows, uint64_t room) {
+    const SegDev &sg = *sgp;
     using L = WWLayout<NB>;
     uint32_t w[L::WORDS];
     load_words<L::WORDS>(sg.base, sg.rooms_padded, room, w);
@@ -88,7 +87,8 @@ __device__ __forceinline__ void run_ww(const SegDev &sg, const StepArgs &a, cons
 }
 
 template <int NB>
-__device__ __forceinline__ void run_tt(const SegDev &sg, const StepArgs &a, const DevRow *rows, uint64_t room) {
+__device__ __forceinline__ void run_tt(const SegDev *__restrict__ sgp, const StepArgs &a, const DevRow *rows, uint64_t room) {
+    const SegDev &sg = *sgp;
     using L = TTLayout<NB>;
     uint32_t w[L::WORDS];
     load_words<L::WORDS>(sg.base, sg.rooms_padded, room, w);
@@ -109,23 +109,53 @@ __device__ __forceinline__ void run_tt(const SegDev &sg, const StepArgs &a, cons
 
 // One launch advances every room of every segment by a.n_turns turns.  Blocks are
 // segment-homogeneous (segments are padded to whole blocks), so a mixed Werewolf /
-// Two-Truths batch diverges per block, never inside a wavefront.
-__global__ void __launch_bounds__(256) ge_step_kernel(const StepArgs a, const DevTable *__restrict__ tables) {
+// Two-Truths batch diverges per block, never inside a wavefront.  Segment descriptors live in
+// device memory and are read with a block-uniform index (scalar loads): indexing the kernel
+// arguments dynamically would push them through scratch.
+template <int KIND>
+__device__ __forceinline__ void run_kind(const SegDev *__restrict__ sg, const StepArgs &a, const DevRow *rows, uint64_t room) {
+    if (KIND == K_WW8) run_ww<8>(sg, a, rows, room);
+    else if (KIND == K_WW12) run_ww<12>(sg, a, rows, room);
+    else if (KIND == K_TT4) run_tt<4>(sg, a, rows, room);
+    else if (KIND == K_TT8) run_tt<8>(sg, a, rows, room);
+    else run_tt<12>(sg, a, rows, room);
+}
+
+__device__ __forceinline__ void load_rows(DevRow *rows, const DevTable *tables, uint32_t table_idx) {
+    if (threadIdx.x < GE_MAX_PHASES) rows[threadIdx.x] = tables[table_idx].rows[threadIdx.x];
+    __syncthreads();
+}
+
+// single-kind batch (the benchmark configurations): one instantiation per record layout, so each
+// gets its own register allocation
+template <int KIND>
+__global__ void __launch_bounds__(256) ge_step_kernel(const StepArgs a, const SegDev *__restrict__ segs,
+                                                      const DevTable *__restrict__ tables) {
+    __shared__ DevRow rows[GE_MAX_PHASES];
+    load_rows(rows, tables, segs[0].table_idx);
+    const uint64_t room = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (room >= segs[0].rooms) return;
+    run_kind<KIND>(segs, a, rows, room);
+}
+
+// mixed batch: several segments (games / player counts) in one launch
+__global__ void __launch_bounds__(256) ge_step_kernel_mixed(const StepArgs a, const SegDev *__restrict__ segs,
+                                                            const DevTable *__restrict__ tables) {
     __shared__ DevRow rows[GE_MAX_PHASES];
     uint32_t si = 0;
     for (uint32_t k = 1; k < a.n_seg; k++)
-        if (blockIdx.x >= a.seg[k].block_begin) si = k;
-    const SegDev &sg = a.seg[si];
-    if (threadIdx.x < GE_MAX_PHASES) rows[threadIdx.x] = tables[sg.table_idx].rows[threadIdx.x];
-    __syncthreads();
-    const uint64_t room = (uint64_t)(blockIdx.x - sg.block_begin) * blockDim.x + threadIdx.x;
-    if (room >= sg.rooms) return;
-    switch (sg.kind) {
-    case K_WW8: run_ww<8>(sg, a, rows, room); break;
-    case K_WW12: run_ww<12>(sg, a, rows, room); break;
-    case K_TT4: run_tt<4>(sg, a, rows, room); break;
-    case K_TT8: run_tt<8>(sg, a, rows, room); break;
-    default: run_tt<12>(sg, a, rows, room); break;
+        if (blockIdx.x >= a.block_begin[k]) si = k;
+    si = __builtin_amdgcn_readfirstlane(si);
+    const SegDev *sg = segs + si;
+    load_rows(rows, tables, sg->table_idx);
+    const uint64_t room = (uint64_t)(blockIdx.x - a.block_begin[si]) * blockDim.x + threadIdx.x;
+    if (room >= sg->rooms) return;
+    switch (sg->kind) {
+    case K_WW8: run_kind<K_WW8>(sg, a, rows, room); break;
+    case K_WW12: run_kind<K_WW12>(sg, a, rows, room); break;
+    case K_TT4: run_kind<K_TT4>(sg, a, rows, room); break;
+    case K_TT8: run_kind<K_TT8>(sg, a, rows, room); break;
+    default: run_kind<K_TT12>(sg, a, rows, room); break;
     }
 }
 
@@ -160,20 +190,22 @@ template <int NB> __device__ __forceinline__ RoomStats stats_tt(const uint32_t *
     return r;
 }
 
-__global__ void __launch_bounds__(256) ge_summary_kernel(const StepArgs a, const DevTable *__restrict__ tables,
+__global__ void __launch_bounds__(256) ge_summary_kernel(const StepArgs a, const SegDev *__restrict__ segs,
+                                                         const DevTable *__restrict__ tables,
                                                          unsigned long long *__restrict__ out) {
     __shared__ DevRow rows[GE_MAX_PHASES];
     __shared__ uint32_t h_end[16], h_score[16];
     __shared__ unsigned long long acc[7];
     uint32_t si = 0;
     for (uint32_t k = 1; k < a.n_seg; k++)
-        if (blockIdx.x >= a.seg[k].block_begin) si = k;
-    const SegDev &sg = a.seg[si];
+        if (blockIdx.x >= a.block_begin[k]) si = k;
+    si = __builtin_amdgcn_readfirstlane(si);
+    const SegDev sg = segs[si];
     if (threadIdx.x < GE_MAX_PHASES) rows[threadIdx.x] = tables[sg.table_idx].rows[threadIdx.x];
     if (threadIdx.x < 16) { h_end[threadIdx.x] = 0; h_score[threadIdx.x] = 0; }
     if (threadIdx.x < 7) acc[threadIdx.x] = 0;
     __syncthreads();
-    const uint64_t room = (uint64_t)(blockIdx.x - sg.block_begin) * blockDim.x + threadIdx.x;
+    const uint64_t room = (uint64_t)(blockIdx.x - a.block_begin[si]) * blockDim.x + threadIdx.x;
     RoomStats r = {0, 0, 0, 0, END_NONE, 0};
     uint64_t ck = 0;
     if (room < sg.rooms) {
@@ -221,13 +253,16 @@ struct Segment {
     uint64_t local_first;      // index of the segment's room 0 inside the batch
 };
 
-DevRow to_dev_row(const ge_phase_row &r) {
+// nb = bits per player mask of the record layout (how far apart the predicate bases are packed)
+DevRow to_dev_row(const ge_phase_row &r, int nb) {
+    const int fpw = 64 / nb;            // whole fields per 64-bit word: 8 (nb 8), 5 (nb 12), 16 (nb 4)
     DevRow d = {0, 0, 0, 0};
     d.r0 = (r.completion & 3u) | ((r.act & 7u) << 2) | ((r.effect & 7u) << 5) | ((r.n_terms & 7u) << 8) |
            ((r.n_branches & 7u) << 11);
     for (int j = 0; j < GE_MAX_TERMS; j++) {
         d.r0 |= (uint32_t)(r.term_neg[j] & 1u) << (16 + j);
-        d.r1 |= (uint32_t)(r.term_base[j] & 15u) << (4 * j);
+        const uint32_t base = r.term_base[j];
+        d.r1 |= ((((base / fpw) & 3u) << 6) | (((base % fpw) * nb) & 63u)) << (8 * j);
     }
     for (int b = 0; b < GE_MAX_BRANCHES; b++) {
         d.r2 |= (uint32_t)(r.br_res[b] & 15u) << (4 * b);
@@ -365,6 +400,7 @@ struct ge_batch {
     void *state = nullptr;            // one allocation, segments back to back
     size_t state_bytes = 0;
     DevTable *tables = nullptr;
+    SegDev *segs_dev = nullptr;
     unsigned long long *sum_dev = nullptr;
     hipStream_t last_stream = nullptr;
     bool timing = false;
@@ -377,7 +413,7 @@ struct ge_batch {
 static int fill_args(const ge_batch *b, StepArgs &a, uint32_t turn0, uint32_t n_turns) {
     memset(&a, 0, sizeof a);
     a.n_seg = (uint32_t)b->segs.size();
-    for (uint32_t k = 0; k < a.n_seg; k++) a.seg[k] = b->segs[k].dev;
+    for (uint32_t k = 0; k < a.n_seg; k++) a.block_begin[k] = b->segs[k].dev.block_begin;
     a.turn0 = turn0; a.n_turns = n_turns;
     a.seed_lo = (uint32_t)b->seed; a.seed_hi = (uint32_t)(b->seed >> 32);
     a.block_threads = b->block_threads;
@@ -468,6 +504,7 @@ int ge_batch_create(const ge_batch_desc *desc, ge_batch **out) {
         hipError_t e = hipMalloc(&b->state, bytes);
         if (e != hipSuccess) { g_last_hip = (int)e; st = e == hipErrorOutOfMemory ? GE_ERR_NOMEM : GE_ERR_HIP; break; }
         if (hipMalloc(reinterpret_cast<void **>(&b->tables), sizeof(DevTable) * b->segs.size()) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void **>(&b->segs_dev), sizeof(SegDev) * GE_MAX_SEGMENTS) != hipSuccess ||
             hipMalloc(reinterpret_cast<void **>(&b->sum_dev), sizeof(unsigned long long) * 64) != hipSuccess) { st = GE_ERR_HIP; break; }
         std::vector<DevTable> host_tables(b->segs.size());
         for (size_t k = 0; k < b->segs.size(); k++) {
@@ -475,7 +512,8 @@ int ge_batch_create(const ge_batch_desc *desc, ge_batch **out) {
             s.dev.base = reinterpret_cast<uint32_t *>(static_cast<char *>(b->state) + reinterpret_cast<size_t>(s.dev.base));
             DevTable &dt = host_tables[k];
             memset(&dt, 0, sizeof dt);
-            for (int r = 0; r < s.table.n_phases; r++) dt.rows[r] = to_dev_row(s.table.rows[r]);
+            const int nb = (s.dev.kind == K_WW8 || s.dev.kind == K_TT8) ? 8 : (s.dev.kind == K_TT4 ? 4 : 12);
+            for (int r = 0; r < s.table.n_phases; r++) dt.rows[r] = to_dev_row(s.table.rows[r], nb);
             dt.n_phases = s.table.n_phases; dt.rounds = s.table.rounds; dt.n_players = (int32_t)s.dev.n_players;
         }
         if (hipMemcpy(b->tables, host_tables.data(), sizeof(DevTable) * host_tables.size(), hipMemcpyHostToDevice) != hipSuccess) { st = GE_ERR_HIP; break; }
@@ -513,6 +551,12 @@ int ge_batch_reset(ge_batch *b) {
             if (hipMemcpy(dst, plane.data(), plane.size() * 4, hipMemcpyHostToDevice) != hipSuccess) st = GE_ERR_HIP;
         }
     }
+    if (st == GE_OK) {
+        SegDev host[GE_MAX_SEGMENTS];
+        memset(host, 0, sizeof host);
+        for (size_t k = 0; k < b->segs.size(); k++) host[k] = b->segs[k].dev;
+        if (hipMemcpy(b->segs_dev, host, sizeof host, hipMemcpyHostToDevice) != hipSuccess) st = GE_ERR_HIP;
+    }
     return st;
 }
 
@@ -544,7 +588,18 @@ int ge_batch_step(ge_batch *b, uint32_t n_turns, void *hip_stream) {
             b->events_used++;
             HIP_TRY(hipEventRecord(e0, st));
         }
-        hipLaunchKernelGGL(ge_step_kernel, dim3(b->n_blocks), dim3(b->block_threads), 0, st, a, b->tables);
+        const dim3 grid(b->n_blocks), block(b->block_threads);
+        if (b->segs.size() > 1) {
+            hipLaunchKernelGGL(ge_step_kernel_mixed, grid, block, 0, st, a, b->segs_dev, b->tables);
+        } else {
+            switch (b->segs[0].dev.kind) {
+            case K_WW8: hipLaunchKernelGGL(ge_step_kernel<K_WW8>, grid, block, 0, st, a, b->segs_dev, b->tables); break;
+            case K_WW12: hipLaunchKernelGGL(ge_step_kernel<K_WW12>, grid, block, 0, st, a, b->segs_dev, b->tables); break;
+            case K_TT4: hipLaunchKernelGGL(ge_step_kernel<K_TT4>, grid, block, 0, st, a, b->segs_dev, b->tables); break;
+            case K_TT8: hipLaunchKernelGGL(ge_step_kernel<K_TT8>, grid, block, 0, st, a, b->segs_dev, b->tables); break;
+            default: hipLaunchKernelGGL(ge_step_kernel<K_TT12>, grid, block, 0, st, a, b->segs_dev, b->tables); break;
+            }
+        }
         HIP_TRY(hipGetLastError());
         if (b->timing) HIP_TRY(hipEventRecord(e1, st));
         b->launches++;
@@ -650,10 +705,10 @@ int ge_batch_summary(ge_batch *b, ge_summary *out) {
     // the summary kernel uses 256-thread blocks of its own
     uint32_t blocks = 0;
     for (uint32_t k = 0; k < a.n_seg; k++) {
-        a.seg[k].block_begin = blocks;
-        blocks += (uint32_t)((a.seg[k].rooms + 255u) / 256u);
+        a.block_begin[k] = blocks;
+        blocks += (uint32_t)((b->segs[k].dev.rooms + 255u) / 256u);
     }
-    hipLaunchKernelGGL(ge_summary_kernel, dim3(blocks), dim3(256), 0, st, a, b->tables, b->sum_dev);
+    hipLaunchKernelGGL(ge_summary_kernel, dim3(blocks), dim3(256), 0, st, a, b->segs_dev, b->tables, b->sum_dev);
     HIP_TRY(hipGetLastError());
     unsigned long long h[64];
     HIP_TRY(hipMemcpyAsync(h, b->sum_dev, sizeof h, hipMemcpyDeviceToHost, st));
@@ -684,6 +739,7 @@ void ge_batch_destroy(ge_batch *b) {
     for (auto &ev : b->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     if (b->state) (void)hipFree(b->state);
     if (b->tables) (void)hipFree(b->tables);
+    if (b->segs_dev) (void)hipFree(b->segs_dev);
     if (b->sum_dev) (void)hipFree(b->sum_dev);
     delete b;
 }
