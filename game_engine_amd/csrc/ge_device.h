@@ -78,11 +78,11 @@ __device__ __forceinline__ uint32_t plurality(nib_t votes, uint32_t voters) {
 
 // ------------------------------------------------------------------ werewolf
 template <int NB>
-__device__ __forceinline__ void ww_turn(WW<NB> &s, const DevRow *rows, uint32_t n, uint32_t nw,
+__device__ __forceinline__ void ww_turn(WW<NB> &s, DevRow &row, const DevRow *rows, uint32_t n, uint32_t nw,
                                         uint32_t phase0_idx, uint32_t rkey, uint32_t turn) {
+    // `row` is the table row of s.phase, kept in registers across turns: LDS is read only on a transition
     using nib_t = typename WW<NB>::nib_t;
     const uint32_t ALL = (1u << n) - 1u;
-    const DevRow row = rows[s.phase];
     const uint32_t comp = row.r0 & 3u, act = (row.r0 >> 2) & 7u, p_eff = (row.r0 >> 5) & 7u;
     const uint32_t nterms = (row.r0 >> 8) & 7u, nbr = (row.r0 >> 11) & 7u;
     const uint32_t tk = turn_key(rkey, turn);
@@ -131,37 +131,34 @@ __device__ __forceinline__ void ww_turn(WW<NB> &s, const DevRow *rows, uint32_t 
         const uint32_t known = s.det_v | s.det_w;
         const uint32_t kw_alive = s.det_w & s.alive;
         const uint32_t non_wolf = s.alive & ~s.team_w;
+        // per-lane constants of the loop, selected once (no branches inside the loop body)
+        const bool a_wolf = act == ACT_WOLF_TARGET, a_det = act == ACT_DETECTIVE, a_day = act == ACT_DAY_VOTE;
+        const bool night = act <= ACT_DETECTIVE;
+        const uint32_t lo_kw = kw_alive & (0u - kw_alive);       // lowest known living werewolf
         while (todo) {
             const uint32_t i = ctz(todo);
             const uint32_t me = 1u << i;
             todo &= todo - 1u;
             const uint32_t d = draw(tk, i);
-            if ((d & 3u) == 0u) continue;
-            uint32_t cand = s.alive;                                   // ACT_DOCTOR_PROTECT
-            if (act == ACT_WOLF_TARGET) cand = non_wolf;
-            if (act == ACT_DETECTIVE) {
-                const uint32_t others = s.alive & ~me;
-                cand = others & ~known;
-                cand = cand ? cand : others;
-            }
-            if (act == ACT_DAY_VOTE) {
-                cand = s.alive & ~me;
-                if (s.team_w & me) cand = non_wolf;
-                else if ((r_det & me) && kw_alive) cand = kw_alive & (0u - kw_alive);
-            }
+            const bool go = (d & 3u) != 0u;
+            const uint32_t others = s.alive & ~me;
+            uint32_t cand = s.alive;                              // ACT_DOCTOR_PROTECT
+            cand = a_wolf ? non_wolf : cand;
+            const uint32_t fresh = others & ~known;
+            cand = a_det ? (fresh ? fresh : others) : cand;
+            const uint32_t vote = (s.team_w & me) ? non_wolf : (((r_det & me) && lo_kw) ? lo_kw : others);
+            cand = a_day ? vote : cand;
             cand = cand ? cand : s.alive;
             const uint32_t c = nth_set_bit<NB>(cand, pick(d, popc(cand))) + 1u;
             const uint32_t sh = 4u * i;
-            s.choice = (s.choice & ~(nib_t(15) << sh)) | (nib_t(c) << sh);
-            newly |= me;
+            const nib_t clr = ~(nib_t(15) << sh), put = nib_t(c) << sh;
+            s.choice = go ? ((s.choice & clr) | put) : s.choice;
+            newly |= go ? me : 0u;
             // RefereeNode (A): record the action (bt:204-225 update_player_state)
-            if (act <= ACT_DETECTIVE) {
-                s.sel = (s.sel & ~(nib_t(15) << sh)) | (nib_t(c) << sh);
-                if (act == ACT_DETECTIVE) {
-                    const uint32_t tb = 1u << (c - 1u);
-                    if (s.team_w & tb) new_det_w |= tb; else new_det_v |= tb;
-                }
-            }
+            s.sel = (go && night) ? ((s.sel & clr) | put) : s.sel;
+            const uint32_t tb = (go && a_det) ? (1u << (c - 1u)) : 0u;
+            new_det_w |= tb & s.team_w;
+            new_det_v |= tb & ~s.team_w;
         }
     }
     s.acted |= newly;
@@ -191,7 +188,8 @@ __device__ __forceinline__ void ww_turn(WW<NB> &s, const DevRow *rows, uint32_t 
     if (q == s.phase) return;
 
     // ---- RefereeNode (B): effect of entering q
-    const uint32_t q0 = rows[q].r0;
+    const DevRow qrow = rows[q];
+    const uint32_t q0 = qrow.r0;
     const uint32_t eff = (q0 >> 5) & 7u;
     if (eff == EFF_ASSIGN_ROLES) {
         uint32_t rem = ALL, wolves = 0, doc = 0, det = 0;
@@ -225,15 +223,15 @@ __device__ __forceinline__ void ww_turn(WW<NB> &s, const DevRow *rows, uint32_t 
     s.flags = (s.flags & FLAG_PHASE0_DONE) | (p_eff << 1);
     s.prev = s.phase;
     s.phase = q;
+    row = qrow;
     if (((q0 >> 11) & 7u) == 0u && s.end_turn == END_NONE) s.end_turn = turn < 0xFFFEu ? turn : 0xFFFEu;
 }
 
 // ------------------------------------------------------------------ two truths and a lie
 template <int NB>
-__device__ __forceinline__ void tt_turn(TT<NB> &s, const DevRow *rows, uint32_t n, uint32_t rounds,
+__device__ __forceinline__ void tt_turn(TT<NB> &s, DevRow &row, const DevRow *rows, uint32_t n, uint32_t rounds,
                                         uint32_t phase0_idx, uint32_t rkey, uint32_t turn) {
     const uint32_t ALL = (1u << n) - 1u;
-    const DevRow row = rows[s.phase];
     const uint32_t comp = row.r0 & 3u, act = (row.r0 >> 2) & 7u, p_eff = (row.r0 >> 5) & 7u;
     const uint32_t nterms = (row.r0 >> 8) & 7u, nbr = (row.r0 >> 11) & 7u;
     const uint32_t tk = turn_key(rkey, turn);
@@ -256,17 +254,19 @@ __device__ __forceinline__ void tt_turn(TT<NB> &s, const DevRow *rows, uint32_t 
     uint32_t newly = 0;
     {
         uint32_t todo = T & ~s.acted;
+        const bool a_stm = act == ACT_TT_STATEMENTS, a_lie = act == ACT_TT_LIE, a_vote = act == ACT_TT_VOTE;
         while (todo) {
             const uint32_t i = ctz(todo);
             todo &= todo - 1u;
             const uint32_t d = draw(tk, i);
-            if ((d & 3u) == 0u) continue;
-            const uint32_t c = act == ACT_TT_STATEMENTS ? 1u : 1u + pick(d, 3u);
+            const bool go = (d & 3u) != 0u;
+            const uint32_t c = a_stm ? 1u : 1u + pick(d, 3u);
             const uint32_t sh = 2u * i;
-            s.choice = (s.choice & ~(3u << sh)) | (c << sh);
-            newly |= 1u << i;
-            if (act == ACT_TT_LIE) s.lie = (s.lie & ~(3u << sh)) | (c << sh);
-            if (act == ACT_TT_VOTE) s.vote = (s.vote & ~(3u << sh)) | (c << sh);
+            const uint32_t clr = ~(3u << sh), put = c << sh;
+            s.choice = go ? ((s.choice & clr) | put) : s.choice;
+            newly |= go ? (1u << i) : 0u;
+            s.lie = (go && a_lie) ? ((s.lie & clr) | put) : s.lie;
+            s.vote = (go && a_vote) ? ((s.vote & clr) | put) : s.vote;
         }
     }
     s.acted |= newly;
@@ -295,7 +295,8 @@ __device__ __forceinline__ void tt_turn(TT<NB> &s, const DevRow *rows, uint32_t 
     }
     if (q == s.phase) return;
 
-    const uint32_t q0 = rows[q].r0;
+    const DevRow qrow = rows[q];
+    const uint32_t q0 = qrow.r0;
     const uint32_t eff = (q0 >> 5) & 7u;
     if (eff == EFF_TT_ROUND_START) {
         uint32_t speaker = 0;
@@ -330,6 +331,7 @@ __device__ __forceinline__ void tt_turn(TT<NB> &s, const DevRow *rows, uint32_t 
     s.flags = (s.flags & FLAG_PHASE0_DONE) | (p_eff << 1);
     s.prev = s.phase;
     s.phase = q;
+    row = qrow;
     if (((q0 >> 11) & 7u) == 0u && s.end_turn == END_NONE) s.end_turn = turn < 0xFFFEu ? turn : 0xFFFEu;
 }
 #endif  // __HIPCC__

@@ -74,13 +74,15 @@ __device__ __forceinline__ void run_ww(const SegDev *__restrict__ sgp, const Ste
     WW<NB> s;
     L::unpack(w, s);
     const uint32_t rk = room_key(a.seed_lo, a.seed_hi, sg.first_global + room);
+    DevRow row = rows[s.phase];
     for (uint32_t t = 0; t < a.n_turns; t++) {
-        if (a.restart && ((rows[s.phase].r0 >> 11) & 7u) == 0u) {      // recycle a finished room
+        if (a.restart && ((row.r0 >> 11) & 7u) == 0u) {      // recycle a finished room
             const uint32_t g = s.games;
             L::unpack(sg.init_words, s);
             s.games = g < 0xFFFFu ? g + 1u : g;
+            row = rows[s.phase];
         }
-        ww_turn<NB>(s, rows, sg.n_players, sg.nw, sg.phase0_idx, rk, a.turn0 + t);
+        ww_turn<NB>(s, row, rows, sg.n_players, sg.nw, sg.phase0_idx, rk, a.turn0 + t);
     }
     L::pack(s, w);
     store_words<L::WORDS>(sg.base, sg.rooms_padded, room, w);
@@ -95,13 +97,15 @@ __device__ __forceinline__ void run_tt(const SegDev *__restrict__ sgp, const Ste
     TT<NB> s;
     L::unpack(w, s);
     const uint32_t rk = room_key(a.seed_lo, a.seed_hi, sg.first_global + room);
+    DevRow row = rows[s.phase];
     for (uint32_t t = 0; t < a.n_turns; t++) {
-        if (a.restart && ((rows[s.phase].r0 >> 11) & 7u) == 0u) {
+        if (a.restart && ((row.r0 >> 11) & 7u) == 0u) {
             const uint32_t g = s.games;
             L::unpack(sg.init_words, s);
             s.games = g < 0xFFFFu ? g + 1u : g;
+            row = rows[s.phase];
         }
-        tt_turn<NB>(s, rows, sg.n_players, sg.rounds, sg.phase0_idx, rk, a.turn0 + t);
+        tt_turn<NB>(s, row, rows, sg.n_players, sg.rounds, sg.phase0_idx, rk, a.turn0 + t);
     }
     L::pack(s, w);
     store_words<L::WORDS>(sg.base, sg.rooms_padded, room, w);

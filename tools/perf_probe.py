@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""Quick device-time probe of the step kernels over batch shapes (not the bench contract).
+python tools/perf_probe.py [game:n:rooms ...]"""
+import json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from game_engine_amd import GameTable, RoomBatch
+
+def dsl(game):
+    with open(os.path.join(ROOT, "tests", "golden", "dsl", f"{game}.json"), encoding="utf-8") as f:
+        return json.load(f)
+
+SHORT = {"ww": "werewolf-(mafia)", "tt": "two-truths-and-a-lie"}
+specs = sys.argv[1:] or ["ww:8:65536", "ww:8:1048576", "ww:12:2097152", "tt:4:1048576"]
+for spec in specs:
+    g, n, rooms = spec.split(":"); n, rooms = int(n), int(rooms)
+    tb = GameTable(dsl(SHORT[g]))
+    for fuse, steps in ((64, 1024), (1, 256)):
+        b = RoomBatch([(tb, n, rooms)], seed=0xC0FFEE, max_fuse=fuse, restart=True)
+        b.step(256); b.sync()
+        b.set_timing(True); b.kernel_time(reset=True)
+        t0 = time.perf_counter(); b.step(steps); b.sync(); wall = time.perf_counter() - t0
+        ms, launches = b.kernel_time(reset=True)
+        bpr = b.bytes_per_room(0)
+        per_turn_us = ms * 1e3 / steps
+        print(f"{spec:>16} fuse={fuse:<3} kernel {per_turn_us:8.3f} us/turn  {rooms*steps/(ms*1e-3):.3e} steps/s (device)  "
+              f"{rooms*steps/wall:.3e} (wall)  alg {2*bpr*rooms/per_turn_us/1e3:8.1f} GB/s = {2*bpr*rooms/per_turn_us/1e3/80:.1f}% of 8 TB/s", flush=True)
+        b.close()
