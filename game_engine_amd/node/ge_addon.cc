@@ -1,0 +1,314 @@
+// ge_addon.cc — thin N-API binding of include/ge_step.h for the TypeScript/Node host.
+//
+// Where it sits in the reference: src/app/api/copilotkit/route.ts:22-47 builds a
+// LangGraphAgent per request that forwards the room's AgentState over HTTP to the Python
+// LangGraph server (agent/langgraph.json:5-8 -> game_agent_v2.py:graph).  A host that wants the
+// GPU stepper instead calls this addon (see index.js / index.d.ts and INTEGRATION.md).
+// No game logic here: every export is a 1:1 wrapper of a C-ABI entry point; stepping runs on the
+// libuv pool (napi_create_async_work) so the event loop is never blocked.
+#include <node_api.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/ge_step.h"
+
+namespace {
+
+#define NAPI_OK(call)                                                        \
+    do {                                                                     \
+        if ((call) != napi_ok) {                                             \
+            napi_throw_error(env, "GE_NAPI", "N-API call failed: " #call);   \
+            return nullptr;                                                  \
+        }                                                                    \
+    } while (0)
+
+napi_value throw_status(napi_env env, int st, const char *what, const char *detail = nullptr) {
+    std::string msg = std::string(what) + ": " + ge_strerror(st);
+    if (detail && *detail) msg += std::string(" (") + detail + ")";
+    char code[16];
+    snprintf(code, sizeof code, "GE%d", st);
+    napi_throw_error(env, code, msg.c_str());
+    return nullptr;
+}
+
+bool get_u64(napi_env env, napi_value v, uint64_t *out) {
+    napi_valuetype t;
+    if (napi_typeof(env, v, &t) != napi_ok) return false;
+    if (t == napi_bigint) {
+        bool lossless;
+        return napi_get_value_bigint_uint64(env, v, out, &lossless) == napi_ok;
+    }
+    if (t == napi_number) {
+        double d;
+        if (napi_get_value_double(env, v, &d) != napi_ok || d < 0) return false;
+        *out = (uint64_t)d;
+        return true;
+    }
+    return false;
+}
+
+bool get_prop_u64(napi_env env, napi_value obj, const char *name, uint64_t *out, uint64_t dflt) {
+    bool has = false;
+    napi_value v;
+    *out = dflt;
+    if (napi_has_named_property(env, obj, name, &has) != napi_ok || !has) return true;
+    if (napi_get_named_property(env, obj, name, &v) != napi_ok) return false;
+    napi_valuetype t;
+    napi_typeof(env, v, &t);
+    if (t == napi_undefined || t == napi_null) return true;
+    if (t == napi_boolean) { bool b; napi_get_value_bool(env, v, &b); *out = b; return true; }
+    return get_u64(env, v, out);
+}
+
+void finalize_batch(napi_env, void *data, void *) { ge_batch_destroy(static_cast<ge_batch *>(data)); }
+void finalize_table(napi_env, void *data, void *) { free(data); }
+
+// compileTable(dslJson: string, rounds?: number): External<ge_game_table>
+napi_value CompileTable(napi_env env, napi_callback_info info) {
+    size_t argc = 2;
+    napi_value argv[2];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    if (argc < 1) return throw_status(env, GE_ERR_ARG, "compileTable");
+    size_t len = 0;
+    NAPI_OK(napi_get_value_string_utf8(env, argv[0], nullptr, 0, &len));
+    std::string json(len, '\0');
+    NAPI_OK(napi_get_value_string_utf8(env, argv[0], &json[0], len + 1, &len));
+    uint64_t rounds = 1;
+    if (argc > 1 && !get_u64(env, argv[1], &rounds)) rounds = 1;
+    ge_game_table *t = static_cast<ge_game_table *>(calloc(1, sizeof(ge_game_table)));
+    char err[512];
+    int st = ge_table_compile_json(json.data(), json.size(), (int)rounds, t, err, sizeof err);
+    if (st != GE_OK) { free(t); return throw_status(env, st, "compileTable", err); }
+    napi_value ext;
+    NAPI_OK(napi_create_external(env, t, finalize_table, nullptr, &ext));
+    return ext;
+}
+
+// tableInfo(table): { pack, rounds, minPlayers, roleNames[], phases:[{id,name,completion,act,effect}] }
+napi_value TableInfo(napi_env env, napi_callback_info info) {
+    size_t argc = 1;
+    napi_value argv[1];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    ge_game_table *t = nullptr;
+    if (argc < 1 || napi_get_value_external(env, argv[0], reinterpret_cast<void **>(&t)) != napi_ok || !t)
+        return throw_status(env, GE_ERR_ARG, "tableInfo");
+    napi_value out, phases, roles, v;
+    NAPI_OK(napi_create_object(env, &out));
+    NAPI_OK(napi_create_int32(env, t->pack, &v)); NAPI_OK(napi_set_named_property(env, out, "pack", v));
+    NAPI_OK(napi_create_int32(env, t->rounds, &v)); NAPI_OK(napi_set_named_property(env, out, "rounds", v));
+    NAPI_OK(napi_create_int32(env, t->min_players, &v)); NAPI_OK(napi_set_named_property(env, out, "minPlayers", v));
+    NAPI_OK(napi_create_array_with_length(env, 5, &roles));
+    for (uint32_t i = 0; i < 5; i++) {
+        NAPI_OK(napi_create_string_utf8(env, t->role_names[i], NAPI_AUTO_LENGTH, &v));
+        NAPI_OK(napi_set_element(env, roles, i, v));
+    }
+    NAPI_OK(napi_set_named_property(env, out, "roleNames", roles));
+    NAPI_OK(napi_create_array_with_length(env, t->n_phases, &phases));
+    for (int i = 0; i < t->n_phases; i++) {
+        napi_value ph;
+        NAPI_OK(napi_create_object(env, &ph));
+        NAPI_OK(napi_create_int32(env, t->rows[i].phase_id, &v)); NAPI_OK(napi_set_named_property(env, ph, "id", v));
+        NAPI_OK(napi_create_string_utf8(env, t->rows[i].name, NAPI_AUTO_LENGTH, &v)); NAPI_OK(napi_set_named_property(env, ph, "name", v));
+        NAPI_OK(napi_create_int32(env, t->rows[i].completion, &v)); NAPI_OK(napi_set_named_property(env, ph, "completion", v));
+        NAPI_OK(napi_create_int32(env, t->rows[i].act, &v)); NAPI_OK(napi_set_named_property(env, ph, "act", v));
+        NAPI_OK(napi_create_int32(env, t->rows[i].effect, &v)); NAPI_OK(napi_set_named_property(env, ph, "effect", v));
+        NAPI_OK(napi_set_element(env, phases, i, ph));
+    }
+    NAPI_OK(napi_set_named_property(env, out, "phases", phases));
+    return out;
+}
+
+// createBatch({seed, firstRoom, device, maxFuse, restart, segments:[{table, nPlayers, nRooms}]}): External<ge_batch>
+napi_value CreateBatch(napi_env env, napi_callback_info info) {
+    size_t argc = 1;
+    napi_value argv[1];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    if (argc < 1) return throw_status(env, GE_ERR_ARG, "createBatch");
+    ge_batch_desc d;
+    memset(&d, 0, sizeof d);
+    uint64_t dev = 0, fuse = 0, restart = 0;
+    if (!get_prop_u64(env, argv[0], "seed", &d.seed, 0) || !get_prop_u64(env, argv[0], "firstRoom", &d.first_room, 0) ||
+        !get_prop_u64(env, argv[0], "device", &dev, 0) || !get_prop_u64(env, argv[0], "maxFuse", &fuse, 0) ||
+        !get_prop_u64(env, argv[0], "restart", &restart, 0))
+        return throw_status(env, GE_ERR_ARG, "createBatch");
+    d.device = (int32_t)dev; d.max_fuse = (uint32_t)fuse; d.flags = restart ? GE_FLAG_RESTART : GE_FLAG_NONE;
+    napi_value segs;
+    uint32_t n = 0;
+    bool is_arr = false;
+    if (napi_get_named_property(env, argv[0], "segments", &segs) != napi_ok ||
+        napi_is_array(env, segs, &is_arr) != napi_ok || !is_arr ||
+        napi_get_array_length(env, segs, &n) != napi_ok || n == 0 || n > GE_MAX_SEGMENTS)
+        return throw_status(env, GE_ERR_ARG, "createBatch", "segments");
+    d.n_segments = n;
+    for (uint32_t k = 0; k < n; k++) {
+        napi_value sg, tv;
+        uint64_t np = 0, nr = 0;
+        ge_game_table *t = nullptr;
+        if (napi_get_element(env, segs, k, &sg) != napi_ok ||
+            napi_get_named_property(env, sg, "table", &tv) != napi_ok ||
+            napi_get_value_external(env, tv, reinterpret_cast<void **>(&t)) != napi_ok || !t ||
+            !get_prop_u64(env, sg, "nPlayers", &np, 0) || !get_prop_u64(env, sg, "nRooms", &nr, 0))
+            return throw_status(env, GE_ERR_ARG, "createBatch", "segment");
+        d.seg[k].table = t; d.seg[k].n_players = (uint32_t)np; d.seg[k].n_rooms = nr;
+    }
+    ge_batch *b = nullptr;
+    int st = ge_batch_create(&d, &b);
+    if (st != GE_OK) return throw_status(env, st, "createBatch");
+    napi_value ext;
+    NAPI_OK(napi_create_external(env, b, finalize_batch, nullptr, &ext));
+    return ext;
+}
+
+ge_batch *batch_arg(napi_env env, napi_value v) {
+    ge_batch *b = nullptr;
+    if (napi_get_value_external(env, v, reinterpret_cast<void **>(&b)) != napi_ok) return nullptr;
+    return b;
+}
+
+struct StepWork {
+    napi_async_work work;
+    napi_deferred deferred;
+    ge_batch *batch;
+    uint32_t turns;
+    int status;
+};
+
+void step_execute(napi_env, void *data) {
+    StepWork *w = static_cast<StepWork *>(data);
+    w->status = ge_batch_step(w->batch, w->turns, nullptr);
+    if (w->status == GE_OK) w->status = ge_batch_sync(w->batch);
+}
+
+void step_complete(napi_env env, napi_status, void *data) {
+    StepWork *w = static_cast<StepWork *>(data);
+    napi_value v;
+    if (w->status == GE_OK) {
+        uint64_t turn = 0;
+        ge_batch_turn(w->batch, &turn);
+        napi_create_double(env, (double)turn, &v);
+        napi_resolve_deferred(env, w->deferred, v);
+    } else {
+        napi_value msg;
+        napi_create_string_utf8(env, ge_strerror(w->status), NAPI_AUTO_LENGTH, &msg);
+        napi_create_error(env, nullptr, msg, &v);
+        napi_reject_deferred(env, w->deferred, v);
+    }
+    napi_delete_async_work(env, w->work);
+    delete w;
+}
+
+// step(batch, nTurns): Promise<number /* turn counter */>
+napi_value Step(napi_env env, napi_callback_info info) {
+    size_t argc = 2;
+    napi_value argv[2];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    ge_batch *b = argc >= 1 ? batch_arg(env, argv[0]) : nullptr;
+    uint64_t turns = 1;
+    if (!b || (argc > 1 && !get_u64(env, argv[1], &turns))) return throw_status(env, GE_ERR_ARG, "step");
+    StepWork *w = new StepWork();
+    w->batch = b; w->turns = (uint32_t)turns; w->status = GE_OK;
+    napi_value promise, name;
+    NAPI_OK(napi_create_promise(env, &w->deferred, &promise));
+    NAPI_OK(napi_create_string_utf8(env, "ge_batch_step", NAPI_AUTO_LENGTH, &name));
+    NAPI_OK(napi_create_async_work(env, nullptr, name, step_execute, step_complete, w, &w->work));
+    NAPI_OK(napi_queue_async_work(env, w->work));
+    return promise;
+}
+
+// stepSync(batch, nTurns): number
+napi_value StepSync(napi_env env, napi_callback_info info) {
+    size_t argc = 2;
+    napi_value argv[2];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    ge_batch *b = argc >= 1 ? batch_arg(env, argv[0]) : nullptr;
+    uint64_t turns = 1;
+    if (!b || (argc > 1 && !get_u64(env, argv[1], &turns))) return throw_status(env, GE_ERR_ARG, "stepSync");
+    int st = ge_batch_step(b, (uint32_t)turns, nullptr);
+    if (st == GE_OK) st = ge_batch_sync(b);
+    if (st != GE_OK) return throw_status(env, st, "stepSync");
+    uint64_t turn = 0;
+    ge_batch_turn(b, &turn);
+    napi_value v;
+    NAPI_OK(napi_create_double(env, (double)turn, &v));
+    return v;
+}
+
+// readRooms(batch, first, count): ArrayBuffer (count * sizeof(ge_room_view) bytes)
+napi_value ReadRooms(napi_env env, napi_callback_info info) {
+    size_t argc = 3;
+    napi_value argv[3];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    ge_batch *b = argc >= 1 ? batch_arg(env, argv[0]) : nullptr;
+    uint64_t first = 0, count = 0;
+    if (!b || argc < 3 || !get_u64(env, argv[1], &first) || !get_u64(env, argv[2], &count))
+        return throw_status(env, GE_ERR_ARG, "readRooms");
+    void *data = nullptr;
+    napi_value buf;
+    NAPI_OK(napi_create_arraybuffer(env, (size_t)count * sizeof(ge_room_view), &data, &buf));
+    int st = ge_batch_read_rooms(b, first, count, static_cast<ge_room_view *>(data), (size_t)count * sizeof(ge_room_view));
+    if (st != GE_OK) return throw_status(env, st, "readRooms");
+    return buf;
+}
+
+// summary(batch): BigUint64Array-compatible ArrayBuffer of ge_summary words
+napi_value Summary(napi_env env, napi_callback_info info) {
+    size_t argc = 1;
+    napi_value argv[1];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    ge_batch *b = argc >= 1 ? batch_arg(env, argv[0]) : nullptr;
+    if (!b) return throw_status(env, GE_ERR_ARG, "summary");
+    void *data = nullptr;
+    napi_value buf;
+    NAPI_OK(napi_create_arraybuffer(env, sizeof(ge_summary), &data, &buf));
+    int st = ge_batch_summary(b, static_cast<ge_summary *>(data));
+    if (st != GE_OK) return throw_status(env, st, "summary");
+    return buf;
+}
+
+napi_value Reset(napi_env env, napi_callback_info info) {
+    size_t argc = 1;
+    napi_value argv[1];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    ge_batch *b = argc >= 1 ? batch_arg(env, argv[0]) : nullptr;
+    if (!b) return throw_status(env, GE_ERR_ARG, "reset");
+    int st = ge_batch_reset(b);
+    if (st != GE_OK) return throw_status(env, st, "reset");
+    return nullptr;
+}
+
+napi_value DeviceCount(napi_env env, napi_callback_info) {
+    napi_value v;
+    NAPI_OK(napi_create_int32(env, ge_device_count(), &v));
+    return v;
+}
+
+napi_value RoomViewSize(napi_env env, napi_callback_info) {
+    napi_value v;
+    NAPI_OK(napi_create_int32(env, (int32_t)sizeof(ge_room_view), &v));
+    return v;
+}
+
+napi_value Init(napi_env env, napi_value exports) {
+    napi_property_descriptor props[] = {
+        {"compileTable", nullptr, CompileTable, nullptr, nullptr, nullptr, napi_default, nullptr},
+        {"tableInfo", nullptr, TableInfo, nullptr, nullptr, nullptr, napi_default, nullptr},
+        {"createBatch", nullptr, CreateBatch, nullptr, nullptr, nullptr, napi_default, nullptr},
+        {"step", nullptr, Step, nullptr, nullptr, nullptr, napi_default, nullptr},
+        {"stepSync", nullptr, StepSync, nullptr, nullptr, nullptr, napi_default, nullptr},
+        {"readRooms", nullptr, ReadRooms, nullptr, nullptr, nullptr, napi_default, nullptr},
+        {"summary", nullptr, Summary, nullptr, nullptr, nullptr, napi_default, nullptr},
+        {"reset", nullptr, Reset, nullptr, nullptr, nullptr, napi_default, nullptr},
+        {"deviceCount", nullptr, DeviceCount, nullptr, nullptr, nullptr, napi_default, nullptr},
+        {"roomViewSize", nullptr, RoomViewSize, nullptr, nullptr, nullptr, napi_default, nullptr},
+    };
+    napi_define_properties(env, exports, sizeof props / sizeof props[0], props);
+    return exports;
+}
+
+}  // namespace
+
+NAPI_MODULE(NODE_GYP_MODULE_NAME, Init)

@@ -1,0 +1,53 @@
+// Type declarations for the Node/TypeScript host of the MI355X batch stepper.
+// The state shapes mirror the reference's TS AgentState (src/lib/canvas/types.ts:338-360).
+
+export interface WerewolfPlayerState {
+  role: string; team: '' | 'villagers' | 'werewolves'; is_alive: boolean; role_revealed: boolean;
+  can_vote: boolean; has_secret_role: boolean; night_action_eligible: boolean;
+  night_action_submitted: boolean; selected_target_id: number;
+  investigated_alignments: Record<string, string>;
+}
+export interface TwoTruthsPlayerState {
+  is_speaker: boolean; statements_submitted: boolean; lie_index: number; lie_revealed: boolean;
+  can_vote: boolean; vote_choice: number; has_voted: boolean; total_score: number; rounds_as_speaker: number;
+}
+export interface RoomState {
+  current_phase_id: number;
+  current_phase_name: string;
+  previous_phase_id: number;
+  end_turn: number;                 // -1 while the game runs
+  games: number;
+  player_states: Record<string, WerewolfPlayerState | TwoTruthsPlayerState>;
+  acted: number[];                  // this visit's action log, per player
+  choice: number[];
+}
+export interface Summary {
+  rooms: bigint; finished: bigint; village_wins: bigint; wolf_wins: bigint; alive_players: bigint;
+  sum_end_turn: bigint; end_turn_hist: bigint[]; score_hist: bigint[]; checksum: bigint; turn: bigint;
+  games_recycled: bigint;
+}
+export interface PhaseInfo { id: number; name: string; completion: number; act: number; effect: number; }
+
+export class GameTable {
+  constructor(dsl: object, rounds?: number);
+  static fromGamename(gamename: string, gamesDir?: string, rounds?: number): GameTable;
+  readonly info: { pack: number; rounds: number; minPlayers: number; roleNames: string[]; phases: PhaseInfo[] };
+  phaseName(id: number): string;
+}
+export interface Segment { table: GameTable; nPlayers: number; nRooms: number; }
+export interface BatchOptions {
+  segments: Segment[]; seed?: bigint | number; firstRoom?: bigint | number; device?: number;
+  maxFuse?: number; restart?: boolean;
+}
+export class RoomBatch {
+  constructor(opts: BatchOptions);
+  readonly nRooms: number;
+  step(nTurns?: number): Promise<number>;
+  stepSync(nTurns?: number): number;
+  reset(): void;
+  readRoom(room: number): RoomState;
+  readRooms(first: number, count: number): RoomState[];
+  summary(): Summary;
+}
+export function loadDslByGamename(gamename: string, gamesDir?: string): object;
+export function deviceCount(): number;

@@ -1,0 +1,40 @@
+'use strict';
+// node selftest.js <dsl.json> [golden.json]   — used by tests/test_node_host.py
+const fs = require('fs');
+const { GameTable, RoomBatch, deviceCount } = require('./index.js');
+const dsl = JSON.parse(fs.readFileSync(process.argv[2], 'utf8'));
+const table = new GameTable(dsl);
+const out = { phases: table.info.phases.length, pack: table.info.pack, devices: deviceCount() };
+if (deviceCount() === 0) {
+  try { new RoomBatch({ segments: [{ table, nPlayers: 8, nRooms: 4 }] }); out.noDevice = 'created?!'; } catch (e) { out.noDevice = e.code; }
+  console.log(JSON.stringify(out));
+  process.exit(0);
+}
+(async () => {
+  const golden = JSON.parse(fs.readFileSync(process.argv[3], 'utf8'));
+  let checked = 0;
+  for (const c of golden.cases) {
+    const b = new RoomBatch({ segments: [{ table, nPlayers: golden.n_players, nRooms: 1 }], seed: BigInt(c.seed), firstRoom: BigInt(c.room), maxFuse: 1 });
+    for (let t = 0; t < c.turns.length; t++) {
+      await b.step(1);
+      const r = b.readRoom(0);
+      const want = c.turns[t];
+      if (r.current_phase_id !== want[0] || r.previous_phase_id !== want[1] || r.end_turn !== want[3]) throw new Error(`phase mismatch turn ${t}`);
+      const n = golden.n_players;
+      for (let i = 0; i < n; i++) {
+        const ps = r.player_states[String(i + 1)], w = want.slice(4 + 11 * i, 15 + 11 * i);
+        if (golden.game.startsWith('werewolf')) {
+          if (ps.is_alive !== !!w[2] || ps.selected_target_id !== w[8] || ps.role !== table.info.roleNames[w[0]]) throw new Error(`player ${i + 1} turn ${t}`);
+        } else if (ps.total_score !== w[7] || ps.vote_choice !== w[5] || ps.is_speaker !== !!w[0]) throw new Error(`player ${i + 1} turn ${t}`);
+        if (r.acted[i] !== w[9] || r.choice[i] !== w[10]) throw new Error(`log ${i + 1} turn ${t}`);
+      }
+      checked++;
+    }
+  }
+  const big = new RoomBatch({ segments: [{ table, nPlayers: golden.n_players, nRooms: 10000 }], seed: 7n });
+  await big.step(64);
+  const s = big.summary();
+  out.checked = checked; out.finished = Number(s.finished); out.turn = Number(s.turn);
+  out.sample = big.readRoom(123).current_phase_name;
+  console.log(JSON.stringify(out));
+})().catch((e) => { console.error(e); process.exit(1); });

@@ -1,0 +1,40 @@
+"""The TypeScript/Node host (game_engine_amd/node: N-API addon over the same C ABI).
+CPU: the addon loads, compiles the DSL, and refuses to create a batch without a GPU.
+GPU (-m gpu): steps golden rooms turn by turn through node and checks the AgentState it returns."""
+import json
+import os
+import shutil
+import subprocess
+
+import pytest
+
+from conftest import GOLD, ROOT
+
+NODE_DIR = os.path.join(ROOT, "game_engine_amd", "node")
+needs_node = pytest.mark.skipif(shutil.which("node") is None or not os.path.exists(os.path.join(NODE_DIR, "ge_addon.node")),
+                                reason="node or the built addon is not available")
+
+
+def _run(*args):
+    out = subprocess.run(["node", os.path.join(NODE_DIR, "selftest.js"), *args], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    return json.loads(out.stdout.strip().splitlines()[-1])
+
+
+@needs_node
+def test_addon_loads_and_compiles_without_gpu():
+    r = _run(os.path.join(GOLD, "dsl", "werewolf-(mafia).json"), os.path.join(GOLD, "traj_werewolf_n8.json"))
+    assert r["phases"] == 18 and r["pack"] == 1
+    if r["devices"] == 0:
+        assert r["noDevice"] == "GE-3"          # GE_ERR_NO_DEVICE: no CPU fallback in the JS host either
+
+
+@needs_node
+@pytest.mark.gpu
+@pytest.mark.parametrize("dsl,gold", [("werewolf-(mafia).json", "traj_werewolf_n8.json"),
+                                      ("two-truths-and-a-lie.json", "traj_two_truths_and_a_lie_n4.json")])
+def test_node_host_matches_golden(dsl, gold):
+    r = _run(os.path.join(GOLD, "dsl", dsl), os.path.join(GOLD, gold))
+    g = json.load(open(os.path.join(GOLD, gold)))
+    assert r["devices"] >= 1 and r["checked"] == sum(len(c["turns"]) for c in g["cases"])
+    assert r["turn"] == 64 and r["finished"] > 0 and isinstance(r["sample"], str)
