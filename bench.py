@@ -81,6 +81,7 @@ def main():
     ap.add_argument("--fuse", type=int, default=64, help="turns fused per launch (1 = one launch per turn)")
     ap.add_argument("--rooms", type=int, default=ROOMS_PER_GPU, help="rooms per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-unfused", action="store_true", help="skip the one-launch-per-turn reference point")
     args = ap.parse_args()
 
     import torch
@@ -136,7 +137,7 @@ def main():
 
     # un-fused reference point: one launch per turn, same workload, short
     unfused = None
-    if rank == 0:
+    if rank == 0 and not args.no_unfused:
         b1 = RoomBatch([(table, N_PLAYERS, rooms)], seed=SEED, device=local_rank, max_fuse=1, restart=True)
         b1.step(64, stream); b1.sync()
         b1.set_timing(True); b1.kernel_time(reset=True)
