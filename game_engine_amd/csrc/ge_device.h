@@ -76,10 +76,52 @@ __device__ __forceinline__ uint32_t plurality(nib_t votes, uint32_t voters) {
     return arg;
 }
 
-// ------------------------------------------------------------------ werewolf
+// Per-wavefront LDS scratch of the bot-action work queue.  Lane = room leaves the action step
+// badly balanced: the mean number of due (room, player) actions is ~1 per room and turn, but a
+// room on the first turn of a vote has 8-12, and a per-lane loop runs max-over-lanes iterations.
+// So the wavefront compacts all due actions of its 64 rooms into one queue in LDS, every lane
+// takes one item per round (reading the owning room's context from LDS), and results go back
+// with LDS atomic ORs.  Wavefront-private: no block barrier, only wave-level ordering.
+struct WaveLds {
+    uint4 ctx[64];            // {alive | team_w<<16, known | r_det<<16, lo_kw | act<<16, turn key}
+    uint4 res[64];            // {go mask, choice nibbles lo, choice nibbles hi, -}
+    uint16_t queue[64 * 12];  // lane | player << 6
+};
+
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// candidate choice of one bot action (POLICY.md §3); shared by the per-lane loop and the queue
 template <int NB>
-__device__ __forceinline__ void ww_turn(WW<NB> &s, DevRow &row, const DevRow *rows, uint32_t n, uint32_t nw,
-                                        uint32_t phase0_idx, uint32_t rkey, uint32_t turn) {
+__device__ __forceinline__ uint32_t ww_choose(uint32_t act, uint32_t i, uint32_t d, uint32_t alive, uint32_t team_w,
+                                              uint32_t known, uint32_t lo_kw, uint32_t r_det) {
+    const uint32_t me = 1u << i;
+    const uint32_t others = alive & ~me, non_wolf = alive & ~team_w;
+    uint32_t cand = alive;                                    // ACT_DOCTOR_PROTECT
+    cand = act == ACT_WOLF_TARGET ? non_wolf : cand;
+    const uint32_t fresh = others & ~known;
+    cand = act == ACT_DETECTIVE ? (fresh ? fresh : others) : cand;
+    const uint32_t vote = (team_w & me) ? non_wolf : (((r_det & me) && lo_kw) ? lo_kw : others);
+    cand = act == ACT_DAY_VOTE ? vote : cand;
+    cand = cand ? cand : alive;
+    return nth_set_bit<NB>(cand, pick(d, popc(cand))) + 1u;
+}
+
+// nibble mask (0xF per player) of the non-zero nibbles of x
+__device__ __forceinline__ uint32_t nib_nonzero(uint32_t x) {
+    uint32_t m = x | (x >> 1); m |= m >> 2; m &= 0x11111111u; return (m << 4) - m;
+}
+__device__ __forceinline__ uint64_t nib_nonzero(uint64_t x) {
+    uint64_t m = x | (x >> 1); m |= m >> 2; m &= 0x1111111111111111ull; return (m << 4) - m;
+}
+
+// ------------------------------------------------------------------ werewolf
+template <int NB, bool QUEUE>
+__device__ __forceinline__ void ww_turn(WW<NB> &s, DevRow &row, const DevRow *rows, WaveLds *lw, bool valid, uint32_t n,
+                                        uint32_t nw, uint32_t phase0_idx, uint32_t rkey, uint32_t turn) {
     // `row` is the table row of s.phase, kept in registers across turns: LDS is read only on a transition
     using nib_t = typename WW<NB>::nib_t;
     const uint32_t ALL = (1u << n) - 1u;
@@ -127,42 +169,84 @@ __device__ __forceinline__ void ww_turn(WW<NB> &s, DevRow &row, const DevRow *ro
     // ---- BotBehaviorNode: every due bot acts with probability 3/4, one action per visit
     uint32_t newly = 0, new_det_v = 0, new_det_w = 0;
     {
-        uint32_t todo = T & ~s.acted;
+        uint32_t todo = valid ? (T & ~s.acted) : 0u;
         const uint32_t known = s.det_v | s.det_w;
         const uint32_t kw_alive = s.det_w & s.alive;
-        const uint32_t non_wolf = s.alive & ~s.team_w;
-        // per-lane constants of the loop, selected once (no branches inside the loop body)
-        const bool a_wolf = act == ACT_WOLF_TARGET, a_det = act == ACT_DETECTIVE, a_day = act == ACT_DAY_VOTE;
-        const bool night = act <= ACT_DETECTIVE;
         const uint32_t lo_kw = kw_alive & (0u - kw_alive);       // lowest known living werewolf
-        while (todo) {
-            const uint32_t i = ctz(todo);
-            const uint32_t me = 1u << i;
-            todo &= todo - 1u;
-            const uint32_t d = draw(tk, i);
-            const bool go = (d & 3u) != 0u;
-            const uint32_t others = s.alive & ~me;
-            uint32_t cand = s.alive;                              // ACT_DOCTOR_PROTECT
-            cand = a_wolf ? non_wolf : cand;
-            const uint32_t fresh = others & ~known;
-            cand = a_det ? (fresh ? fresh : others) : cand;
-            const uint32_t vote = (s.team_w & me) ? non_wolf : (((r_det & me) && lo_kw) ? lo_kw : others);
-            cand = a_day ? vote : cand;
-            cand = cand ? cand : s.alive;
-            const uint32_t c = nth_set_bit<NB>(cand, pick(d, popc(cand))) + 1u;
-            const uint32_t sh = 4u * i;
-            const nib_t clr = ~(nib_t(15) << sh), put = nib_t(c) << sh;
-            s.choice = go ? ((s.choice & clr) | put) : s.choice;
-            newly |= go ? me : 0u;
-            // RefereeNode (A): record the action (bt:204-225 update_player_state)
-            s.sel = (go && night) ? ((s.sel & clr) | put) : s.sel;
-            const uint32_t tb = (go && a_det) ? (1u << (c - 1u)) : 0u;
-            new_det_w |= tb & s.team_w;
-            new_det_v |= tb & ~s.team_w;
+        const bool night = act >= ACT_WOLF_TARGET && act <= ACT_DETECTIVE;
+        if (!QUEUE) {
+            while (todo) {
+                const uint32_t i = ctz(todo);
+                todo &= todo - 1u;
+                const uint32_t d = draw(tk, i);
+                const bool go = (d & 3u) != 0u;
+                const uint32_t c = ww_choose<NB>(act, i, d, s.alive, s.team_w, known, lo_kw, r_det);
+                const uint32_t sh = 4u * i;
+                const nib_t clr = ~(nib_t(15) << sh), put = nib_t(c) << sh;
+                s.choice = go ? ((s.choice & clr) | put) : s.choice;
+                newly |= go ? (1u << i) : 0u;
+                // RefereeNode (A): record the action (bt:204-225 update_player_state)
+                s.sel = (go && night) ? ((s.sel & clr) | put) : s.sel;
+                const uint32_t tb = (go && act == ACT_DETECTIVE) ? (1u << (c - 1u)) : 0u;
+                new_det_w |= tb & s.team_w;
+                new_det_v |= tb & ~s.team_w;
+            }
+        } else {
+            // exclusive prefix sum of the per-room item counts (<= 12) over the wavefront:
+            // one ballot per bit of the count, mbcnt for the lanes below
+            const uint32_t lane = __lane_id();
+            const uint32_t cnt = popc(todo);
+            uint32_t off = 0, total = 0;
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const unsigned long long m = __ballot((cnt >> b) & 1u);
+                off += __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)) << b;
+                total += (uint32_t)__popcll(m) << b;
+            }
+            if (total != 0u) {                                  // wave-uniform
+                lw->ctx[lane] = make_uint4(s.alive | (s.team_w << 16), known | (r_det << 16), lo_kw | (act << 16), tk);
+                lw->res[lane] = make_uint4(0u, 0u, 0u, 0u);
+                while (todo) {
+                    const uint32_t i = ctz(todo);
+                    todo &= todo - 1u;
+                    lw->queue[off++] = (uint16_t)(lane | (i << 6));
+                }
+                wave_sync();
+                for (uint32_t base = 0; base < total; base += 64u) {
+                    const uint32_t k = base + lane;
+                    if (k < total) {
+                        const uint32_t item = lw->queue[k];
+                        const uint32_t L = item & 63u, i = item >> 6;
+                        const uint4 c4 = lw->ctx[L];
+                        const uint32_t d = draw(c4.w, i);
+                        if ((d & 3u) != 0u) {
+                            const uint32_t c = ww_choose<NB>(c4.z >> 16, i, d, c4.x & 0xFFFFu, c4.x >> 16,
+                                                             c4.y & 0xFFFFu, c4.z & 0xFFFFu, c4.y >> 16);
+                            uint32_t *r = reinterpret_cast<uint32_t *>(&lw->res[L]);
+                            atomicOr(r, 1u << i);
+                            atomicOr(r + 1 + (i >> 3), c << (4u * (i & 7u)));
+                        }
+                    }
+                }
+                wave_sync();
+                const uint4 r = lw->res[lane];
+                newly = r.x;
+                const nib_t got = NB > 8 ? (nib_t)(((uint64_t)r.z << 32) | r.y) : (nib_t)r.y;
+                const nib_t m15 = nib_nonzero(got);              // c >= 1, so a nibble is set iff that player acted
+                s.choice = (s.choice & ~m15) | got;
+                // RefereeNode (A): record the action (bt:204-225 update_player_state)
+                s.sel = night ? ((s.sel & ~m15) | got) : s.sel;
+                if (act == ACT_DETECTIVE && newly) {
+                    const uint32_t c = (uint32_t)(got >> (4u * ctz(newly))) & 15u;
+                    const uint32_t tb = 1u << (c - 1u);
+                    new_det_w = tb & s.team_w;
+                    new_det_v = tb & ~s.team_w;
+                }
+            }
         }
     }
     s.acted |= newly;
-    if (act >= ACT_WOLF_TARGET && act <= ACT_DETECTIVE) s.sub |= newly;
+    if (act >= ACT_WOLF_TARGET && act <= ACT_DETECTIVE) s.sub |= newly;   // act is ACT_NONE outside action phases
 
     // ---- PhaseNode: phase-0 guard (v2:1025-1052): first turn only records phase 0, Referee skipped
     if (s.phase == phase0_idx && !(s.flags & FLAG_PHASE0_DONE)) {
@@ -229,7 +313,7 @@ __device__ __forceinline__ void ww_turn(WW<NB> &s, DevRow &row, const DevRow *ro
 
 // ------------------------------------------------------------------ two truths and a lie
 template <int NB>
-__device__ __forceinline__ void tt_turn(TT<NB> &s, DevRow &row, const DevRow *rows, uint32_t n, uint32_t rounds,
+__device__ __forceinline__ void tt_turn(TT<NB> &s, DevRow &row, const DevRow *rows, bool valid, uint32_t n, uint32_t rounds,
                                         uint32_t phase0_idx, uint32_t rkey, uint32_t turn) {
     const uint32_t ALL = (1u << n) - 1u;
     const uint32_t comp = row.r0 & 3u, act = (row.r0 >> 2) & 7u, p_eff = (row.r0 >> 5) & 7u;
