@@ -58,20 +58,30 @@ template <int NB> __device__ __forceinline__ uint32_t nth_set_bit(uint32_t m, ui
 // (<= 12 voters), so the whole tally is one or two registers.
 template <int NB, typename nib_t>
 __device__ __forceinline__ uint32_t plurality(nib_t votes, uint32_t voters) {
-    nib_t tally = 0;
-#pragma unroll
-    for (int i = 0; i < NB; i++) {
-        uint32_t c = (uint32_t)(votes >> (4 * i)) & 15u;
-        bool ok = ((voters >> i) & 1u) && c != 0u;
-        tally += ok ? (nib_t(1) << (4u * (c - 1u))) : nib_t(0);
+    // keep only the voters' nibbles: spread the voter bits to nibble position 0, times 15
+    nib_t vm;
+    if (NB <= 8) {
+        uint32_t x = voters & 0xFFu;
+        x = (x | (x << 12)) & 0x000F000Fu; x = (x | (x << 6)) & 0x03030303u; x = (x | (x << 3)) & 0x11111111u;
+        vm = (nib_t)((x << 4) - x);
+    } else {
+        uint64_t x = voters & 0xFFFFu;
+        x = (x | (x << 24)) & 0x000000FF000000FFull; x = (x | (x << 12)) & 0x000F000F000F000Full;
+        x = (x | (x << 6)) & 0x0303030303030303ull; x = (x | (x << 3)) & 0x1111111111111111ull;
+        vm = (nib_t)((x << 4) - x);
     }
+    const nib_t v = votes & vm;
+    // tally: counter k (a nibble) counts votes for player id k; nibble 0 collects "no vote"
+    uint64_t tally = 0;
+#pragma unroll
+    for (int i = 0; i < NB; i++) tally += uint64_t(1) << (4u * ((uint32_t)(v >> (4 * i)) & 15u));
     uint32_t best = 0, arg = 0;
 #pragma unroll
-    for (int k = 0; k < NB; k++) {
-        uint32_t cnt = (uint32_t)(tally >> (4 * k)) & 15u;
-        bool gt = cnt > best;
+    for (int k = 1; k <= NB; k++) {
+        const uint32_t cnt = (uint32_t)(tally >> (4 * k)) & 15u;
+        const bool gt = cnt > best;
         best = gt ? cnt : best;
-        arg = gt ? (uint32_t)(k + 1) : arg;
+        arg = gt ? (uint32_t)k : arg;
     }
     return arg;
 }
@@ -134,35 +144,35 @@ __device__ __forceinline__ void ww_turn(WW<NB> &s, DevRow &row, const DevRow *ro
     const uint32_t r_doc = s.rb0 & s.rb1 & nrb2, r_det = s.rb2 & ~s.rb1 & ~s.rb0;
 
     // ---- who must act: target_players.condition AND alive, all players at once.
-    // The 12 base predicates are packed NB bits apart into 64-bit words; a term selects its
-    // mask with one shift (row.r1 holds word index and shift per term, filled per layout by
-    // the host).  Written as shifts, not as a select chain over the struct fields: the
-    // compiler turns such a chain into an indexed load and spills the whole room to scratch.
+    // The 12 base predicates are packed 4 (NB 8) or 2 (NB 12) per 32-bit word; a term selects
+    // its mask with a word select and one shift (row.r1: per term {word [7:5], shift [4:0]},
+    // filled per layout by the host; word 7 = constant all-ones for unused terms).  Written as
+    // shifts, not as a select chain over the struct fields: the compiler turns such a chain
+    // into an indexed load and spills the whole room to scratch.
     uint32_t T = 0;
     if (comp == COMP_ACTION) {
-        uint64_t P0, P1, P2;
+        uint32_t W[6];
         if (NB == 8) {
-            P0 = (uint64_t)(s.alive | (s.can_vote << 8) | (s.revealed << 16) | (s.secret << 24)) |
-                 ((uint64_t)(s.elig | (s.sub << 8) | (s.team_v << 16) | (s.team_w << 24)) << 32);
-            P1 = (uint64_t)((r_vil & 0xFFu) | ((r_wolf & 0xFFu) << 8) | ((r_doc & 0xFFu) << 16) | ((r_det & 0xFFu) << 24));
-            P2 = 0;
+            W[0] = s.alive | (s.can_vote << 8) | (s.revealed << 16) | (s.secret << 24);
+            W[1] = s.elig | (s.sub << 8) | (s.team_v << 16) | (s.team_w << 24);
+            W[2] = (r_vil & 0xFFu) | ((r_wolf & 0xFFu) << 8) | ((r_doc & 0xFFu) << 16) | ((r_det & 0xFFu) << 24);
+            W[3] = W[4] = W[5] = 0xFFFFFFFFu;
         } else {
-            P0 = (uint64_t)s.alive | ((uint64_t)s.can_vote << 12) | ((uint64_t)s.revealed << 24) |
-                 ((uint64_t)s.secret << 36) | ((uint64_t)s.elig << 48);
-            P1 = (uint64_t)s.sub | ((uint64_t)s.team_v << 12) | ((uint64_t)s.team_w << 24) |
-                 ((uint64_t)(r_vil & 0xFFFu) << 36) | ((uint64_t)(r_wolf & 0xFFFu) << 48);
-            P2 = (uint64_t)(r_doc & 0xFFFu) | ((uint64_t)(r_det & 0xFFFu) << 12);
+            W[0] = s.alive | (s.can_vote << 16); W[1] = s.revealed | (s.secret << 16);
+            W[2] = s.elig | (s.sub << 16);       W[3] = s.team_v | (s.team_w << 16);
+            W[4] = (r_vil & 0xFFFu) | ((r_wolf & 0xFFFu) << 16); W[5] = (r_doc & 0xFFFu) | ((r_det & 0xFFFu) << 16);
         }
-        T = s.alive;
-        for (uint32_t j = 0; j < nterms; j++) {
+        auto term = [&](uint32_t j) -> uint32_t {
             const uint32_t e = (row.r1 >> (8u * j)) & 255u;
-            const uint32_t wi = e >> 6;
-            uint64_t word = wi == 0u ? P0 : P1;
-            word = wi == 2u ? P2 : word;
-            uint32_t m = (uint32_t)(word >> (e & 63u));
-            m = ((row.r0 >> (16u + j)) & 1u) ? ~m : m;
-            T &= m;
-        }
+            const uint32_t wi = e >> 5;
+            uint32_t word = 0xFFFFFFFFu;                       // wi == 7: no term
+            word = wi == 0u ? W[0] : word; word = wi == 1u ? W[1] : word; word = wi == 2u ? W[2] : word;
+            if (NB > 8) { word = wi == 3u ? W[3] : word; word = wi == 4u ? W[4] : word; word = wi == 5u ? W[5] : word; }
+            const uint32_t m = word >> (e & 31u);
+            return ((row.r0 >> (16u + j)) & 1u) ? ~m : m;
+        };
+        T = s.alive & term(0) & term(1);
+        if (nterms > 2u) T &= term(2) & term(3);               // no shipped phase has more than two terms
         T &= ALL;
     }
 
@@ -322,16 +332,18 @@ __device__ __forceinline__ void tt_turn(TT<NB> &s, DevRow &row, const DevRow *ro
 
     uint32_t T = 0;
     if (comp == COMP_ACTION) {
-        // the 5 base predicates, NB bits apart in one 64-bit word (see ww_turn)
-        const uint64_t P0 = (uint64_t)s.speaker | ((uint64_t)s.submitted << NB) | ((uint64_t)s.revealed << (2 * NB)) |
-                            ((uint64_t)s.can_vote << (3 * NB)) | ((uint64_t)s.has_voted << (4 * NB));
-        T = ALL;
-        for (uint32_t j = 0; j < nterms; j++) {
+        // the 5 base predicates, two per 32-bit word (see ww_turn)
+        const uint32_t W0 = s.speaker | (s.submitted << 16), W1 = s.revealed | (s.can_vote << 16), W2 = s.has_voted;
+        auto term = [&](uint32_t j) -> uint32_t {
             const uint32_t e = (row.r1 >> (8u * j)) & 255u;
-            uint32_t m = (uint32_t)(P0 >> (e & 63u));
-            m = ((row.r0 >> (16u + j)) & 1u) ? ~m : m;
-            T &= m;
-        }
+            const uint32_t wi = e >> 5;
+            uint32_t word = 0xFFFFFFFFu;
+            word = wi == 0u ? W0 : word; word = wi == 1u ? W1 : word; word = wi == 2u ? W2 : word;
+            const uint32_t m = word >> (e & 31u);
+            return ((row.r0 >> (16u + j)) & 1u) ? ~m : m;
+        };
+        T = term(0) & term(1);
+        if (nterms > 2u) T &= term(2) & term(3);
         T &= ALL;
     }
 

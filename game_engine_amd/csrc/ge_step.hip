@@ -43,17 +43,21 @@ struct StepArgs {
     uint32_t block_begin[GE_MAX_SEGMENTS];
 };
 
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
 template <int WORDS>
 __device__ __forceinline__ void load_words(const uint32_t *base, uint64_t rooms_padded, uint64_t room, uint32_t *w) {
     constexpr int NP = (WORDS + 3) / 4;
 #pragma unroll
     for (int j = 0; j < NP; j++) {
+        // global (address space 1), not flat, accesses: the base pointer was itself loaded from memory
         const char *plane = reinterpret_cast<const char *>(base) + plane_offset(rooms_padded, j);
         if (WORDS - 4 * j >= 4) {
-            const uint4 v = reinterpret_cast<const uint4 *>(plane)[room];
+            const u32x4 v = ((const __attribute__((address_space(1))) u32x4 *)(uintptr_t)plane)[room];
             w[4 * j] = v.x; w[4 * j + 1] = v.y; w[4 * j + 2] = v.z; w[4 * j + 3] = v.w;
         } else {
-            const uint2 v = reinterpret_cast<const uint2 *>(plane)[room];
+            const u32x2 v = ((const __attribute__((address_space(1))) u32x2 *)(uintptr_t)plane)[room];
             w[4 * j] = v.x; w[4 * j + 1] = v.y;
         }
     }
@@ -65,10 +69,13 @@ __device__ __forceinline__ void store_words(uint32_t *base, uint64_t rooms_padde
 #pragma unroll
     for (int j = 0; j < NP; j++) {
         char *plane = reinterpret_cast<char *>(base) + plane_offset(rooms_padded, j);
-        if (WORDS - 4 * j >= 4)
-            reinterpret_cast<uint4 *>(plane)[room] = make_uint4(w[4 * j], w[4 * j + 1], w[4 * j + 2], w[4 * j + 3]);
-        else
-            reinterpret_cast<uint2 *>(plane)[room] = make_uint2(w[4 * j], w[4 * j + 1]);
+        if (WORDS - 4 * j >= 4) {
+            u32x4 v; v.x = w[4 * j]; v.y = w[4 * j + 1]; v.z = w[4 * j + 2]; v.w = w[4 * j + 3];
+            ((__attribute__((address_space(1))) u32x4 *)(uintptr_t)plane)[room] = v;
+        } else {
+            u32x2 v; v.x = w[4 * j]; v.y = w[4 * j + 1];
+            ((__attribute__((address_space(1))) u32x2 *)(uintptr_t)plane)[room] = v;
+        }
     }
 }
 
@@ -87,12 +94,19 @@ __device__ __forceinline__ void run_ww(const SegDev *__restrict__ sgp, const Ste
     L::unpack(w, s);
     const uint32_t rk = room_key(a.seed_lo, a.seed_hi, sg.first_global + room);
     DevRow row = rows[s.phase];
+    // the fresh room a finished one is recycled into: wave-uniform, kept in scalar registers
+    uint32_t iw[L::WORDS];
+#pragma unroll
+    for (int j = 0; j < L::WORDS; j++) iw[j] = __builtin_amdgcn_readfirstlane(sg.init_words[j]);
+    WW<NB> s0;
+    L::unpack(iw, s0);
+    const DevRow row0 = rows[sg.phase0_idx];
     for (uint32_t t = 0; t < a.n_turns; t++) {
         if (a.restart && ((row.r0 >> 11) & 7u) == 0u) {      // recycle a finished room
             const uint32_t g = s.games;
-            L::unpack(sg.init_words, s);
+            s = s0;
             s.games = g < 0xFFFFu ? g + 1u : g;
-            row = rows[s.phase];
+            row = row0;
         }
         ww_turn<NB, GE_WAVE_QUEUE>(s, row, rows, lw, valid, sg.n_players, sg.nw, sg.phase0_idx, rk, a.turn0 + t);
     }
@@ -113,12 +127,18 @@ __device__ __forceinline__ void run_tt(const SegDev *__restrict__ sgp, const Ste
     L::unpack(w, s);
     const uint32_t rk = room_key(a.seed_lo, a.seed_hi, sg.first_global + room);
     DevRow row = rows[s.phase];
+    uint32_t iw[L::WORDS];
+#pragma unroll
+    for (int j = 0; j < L::WORDS; j++) iw[j] = __builtin_amdgcn_readfirstlane(sg.init_words[j]);
+    TT<NB> s0;
+    L::unpack(iw, s0);
+    const DevRow row0 = rows[sg.phase0_idx];
     for (uint32_t t = 0; t < a.n_turns; t++) {
         if (a.restart && ((row.r0 >> 11) & 7u) == 0u) {
             const uint32_t g = s.games;
-            L::unpack(sg.init_words, s);
+            s = s0;
             s.games = g < 0xFFFFu ? g + 1u : g;
-            row = rows[s.phase];
+            row = row0;
         }
         tt_turn<NB>(s, row, rows, valid, sg.n_players, sg.rounds, sg.phase0_idx, rk, a.turn0 + t);
     }
@@ -275,16 +295,18 @@ struct Segment {
     uint64_t local_first;      // index of the segment's room 0 inside the batch
 };
 
-// nb = bits per player mask of the record layout (how far apart the predicate bases are packed)
-DevRow to_dev_row(const ge_phase_row &r, int nb) {
-    const int fpw = 64 / nb;            // whole fields per 64-bit word: 8 (nb 8), 5 (nb 12), 16 (nb 4)
+DevRow to_dev_row(const ge_phase_row &r, bool bytes4) {
+    // predicate masks per 32-bit word (ge_device.h): 4 bytes (werewolf N<=8) or 2 half-words (all others)
+    const int fpw = bytes4 ? 4 : 2;
+    const int stride = bytes4 ? 8 : 16;
     DevRow d = {0, 0, 0, 0};
     d.r0 = (r.completion & 3u) | ((r.act & 7u) << 2) | ((r.effect & 7u) << 5) | ((r.n_terms & 7u) << 8) |
            ((r.n_branches & 7u) << 11);
     for (int j = 0; j < GE_MAX_TERMS; j++) {
-        d.r0 |= (uint32_t)(r.term_neg[j] & 1u) << (16 + j);
+        if (j < r.n_terms) d.r0 |= (uint32_t)(r.term_neg[j] & 1u) << (16 + j);
         const uint32_t base = r.term_base[j];
-        d.r1 |= ((((base / fpw) & 3u) << 6) | (((base % fpw) * nb) & 63u)) << (8 * j);
+        const uint32_t enc = j < r.n_terms ? ((((base / fpw) & 7u) << 5) | (((base % fpw) * stride) & 31u)) : (7u << 5);
+        d.r1 |= enc << (8 * j);
     }
     for (int b = 0; b < GE_MAX_BRANCHES; b++) {
         d.r2 |= (uint32_t)(r.br_res[b] & 15u) << (4 * b);
@@ -534,8 +556,7 @@ int ge_batch_create(const ge_batch_desc *desc, ge_batch **out) {
             s.dev.base = reinterpret_cast<uint32_t *>(static_cast<char *>(b->state) + reinterpret_cast<size_t>(s.dev.base));
             DevTable &dt = host_tables[k];
             memset(&dt, 0, sizeof dt);
-            const int nb = (s.dev.kind == K_WW8 || s.dev.kind == K_TT8) ? 8 : (s.dev.kind == K_TT4 ? 4 : 12);
-            for (int r = 0; r < s.table.n_phases; r++) dt.rows[r] = to_dev_row(s.table.rows[r], nb);
+            for (int r = 0; r < s.table.n_phases; r++) dt.rows[r] = to_dev_row(s.table.rows[r], s.dev.kind == K_WW8);
             dt.n_phases = s.table.n_phases; dt.rounds = s.table.rounds; dt.n_players = (int32_t)s.dev.n_players;
         }
         if (hipMemcpy(b->tables, host_tables.data(), sizeof(DevTable) * host_tables.size(), hipMemcpyHostToDevice) != hipSuccess) { st = GE_ERR_HIP; break; }
