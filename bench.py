@@ -94,12 +94,21 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the stepper has no CPU path")
-    torch.cuda.set_device(local_rank)
+    # one process per GPU; GE_DIST_BACKEND=gloo is only for rehearsing the multi-process flow on a
+    # box with fewer GPUs than ranks (ranks then share devices and collectives run on CPU tensors)
+    backend = os.environ.get("GE_DIST_BACKEND", "nccl")
+    device_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(device_index)
+    coll_device = torch.device("cuda", device_index) if backend == "nccl" else torch.device("cpu")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend)
 
     def barrier():
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -108,7 +117,7 @@ def main():
     table = GameTable(dsl)
     rooms = args.rooms
     batch = RoomBatch([(table, N_PLAYERS, rooms)], seed=SEED, first_room=shard_first_room(rooms, rank),
-                      device=local_rank, max_fuse=args.fuse, restart=True)
+                      device=device_index, max_fuse=args.fuse, restart=True)
     bytes_per_room = batch.bytes_per_room(0)          # record size; B = 2x (read + written once per turn)
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -124,7 +133,7 @@ def main():
     kernel_ms, launches = batch.kernel_time(reset=True)
     batch.set_timing(False)
 
-    t_el = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    t_el = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
     if world > 1:
         dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
     elapsed = float(t_el.item())
@@ -138,7 +147,7 @@ def main():
     # un-fused reference point: one launch per turn, same workload, short
     unfused = None
     if rank == 0 and not args.no_unfused:
-        b1 = RoomBatch([(table, N_PLAYERS, rooms)], seed=SEED, device=local_rank, max_fuse=1, restart=True)
+        b1 = RoomBatch([(table, N_PLAYERS, rooms)], seed=SEED, device=device_index, max_fuse=1, restart=True)
         b1.step(64, stream); b1.sync()
         b1.set_timing(True); b1.kernel_time(reset=True)
         t1 = time.perf_counter()
