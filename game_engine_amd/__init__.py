@@ -5,7 +5,7 @@ loop of liruihan000/game_engine (agent/game_agent_v2.py:1571-1587).  All compute
 libge_step.so (HIP, gfx950) behind the C ABI of include/ge_step.h; there is no CPU fallback.
 """
 from .stepper import (GameTable, RoomBatch, GeError, load_dsl_by_gamename, library_path,
-                      ROOM_VIEW_DTYPE, WW_FIELDS, TT_FIELDS)
+                      ROOM_VIEW_DTYPE, EVENT_DTYPE, WW_FIELDS, TT_FIELDS)
 
 __all__ = ["GameTable", "RoomBatch", "GeError", "load_dsl_by_gamename", "library_path",
-           "ROOM_VIEW_DTYPE", "WW_FIELDS", "TT_FIELDS"]
+           "ROOM_VIEW_DTYPE", "EVENT_DTYPE", "WW_FIELDS", "TT_FIELDS"]

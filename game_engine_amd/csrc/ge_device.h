@@ -131,7 +131,9 @@ __device__ __forceinline__ uint64_t nib_nonzero(uint64_t x) {
 // ------------------------------------------------------------------ werewolf
 template <int NB, bool QUEUE>
 __device__ __forceinline__ void ww_turn(WW<NB> &s, DevRow &row, const DevRow *rows, WaveLds *lw, bool valid, uint32_t n,
-                                        uint32_t nw, uint32_t phase0_idx, uint32_t rkey, uint32_t turn) {
+                                        uint32_t nw, uint32_t phase0_idx, uint32_t rkey, uint32_t turn,
+                                        bool trace, uint32_t &ev_newly, uint64_t &ev_choice) {
+    // ev_*: this turn's logged actions (who acted, what they chose) for the optional event trace
     // `row` is the table row of s.phase, kept in registers across turns: LDS is read only on a transition
     using nib_t = typename WW<NB>::nib_t;
     const uint32_t ALL = (1u << n) - 1u;
@@ -257,6 +259,14 @@ __device__ __forceinline__ void ww_turn(WW<NB> &s, DevRow &row, const DevRow *ro
     }
     s.acted |= newly;
     if (act >= ACT_WOLF_TARGET && act <= ACT_DETECTIVE) s.sub |= newly;   // act is ACT_NONE outside action phases
+    ev_newly = newly;
+    if (trace) {                                              // wave-uniform
+        uint32_t x = newly;                                   // nibble mask of the new actors
+        uint64_t m = 0;
+#pragma unroll
+        for (int i = 0; i < NB; i++) m |= (uint64_t)((x >> i) & 1u) << (4 * i);
+        ev_choice = (uint64_t)s.choice & ((m << 4) - m);
+    }
 
     // ---- PhaseNode: phase-0 guard (v2:1025-1052): first turn only records phase 0, Referee skipped
     if (s.phase == phase0_idx && !(s.flags & FLAG_PHASE0_DONE)) {
@@ -324,7 +334,8 @@ __device__ __forceinline__ void ww_turn(WW<NB> &s, DevRow &row, const DevRow *ro
 // ------------------------------------------------------------------ two truths and a lie
 template <int NB>
 __device__ __forceinline__ void tt_turn(TT<NB> &s, DevRow &row, const DevRow *rows, bool valid, uint32_t n, uint32_t rounds,
-                                        uint32_t phase0_idx, uint32_t rkey, uint32_t turn) {
+                                        uint32_t phase0_idx, uint32_t rkey, uint32_t turn,
+                                        bool trace, uint32_t &ev_newly, uint64_t &ev_choice) {
     const uint32_t ALL = (1u << n) - 1u;
     const uint32_t comp = row.r0 & 3u, act = (row.r0 >> 2) & 7u, p_eff = (row.r0 >> 5) & 7u;
     const uint32_t nterms = (row.r0 >> 8) & 7u, nbr = (row.r0 >> 11) & 7u;
@@ -366,6 +377,14 @@ __device__ __forceinline__ void tt_turn(TT<NB> &s, DevRow &row, const DevRow *ro
         }
     }
     s.acted |= newly;
+    ev_newly = newly;
+    if (trace) {
+        uint64_t c4 = 0;                                      // 2-bit choices widened to the nibble form of the trace
+#pragma unroll
+        for (int i = 0; i < NB; i++)
+            c4 |= (uint64_t)(((newly >> i) & 1u) ? ((s.choice >> (2 * i)) & 3u) : 0u) << (4 * i);
+        ev_choice = c4;
+    }
     if (act == ACT_TT_STATEMENTS) s.submitted |= newly;
     if (act == ACT_TT_VOTE) s.has_voted |= newly;
 

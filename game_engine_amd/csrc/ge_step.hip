@@ -36,10 +36,11 @@ struct SegDev {
     uint32_t kind, n_players, nw, rounds;
     uint32_t phase0_idx, block_begin, table_idx, words;
     uint32_t init_words[12];   // the initial record (player_states_template, phase 0)
+    uint32_t *trace;           // GE_FLAG_TRACE: [turn in launch][rooms_padded] x 4 words, else null
 };
 
 struct StepArgs {
-    uint32_t n_seg, turn0, n_turns, seed_lo, seed_hi, block_threads, restart;
+    uint32_t n_seg, turn0, n_turns, seed_lo, seed_hi, block_threads, restart, trace;
     uint32_t block_begin[GE_MAX_SEGMENTS];
 };
 
@@ -79,6 +80,15 @@ __device__ __forceinline__ void store_words(uint32_t *base, uint64_t rooms_padde
     }
 }
 
+// event trace (GE_FLAG_TRACE): one 16-byte record per room and turn of the launch, coalesced
+__device__ __forceinline__ void store_event(uint32_t *trace, uint64_t rooms_padded, uint32_t t, uint64_t room, uint32_t turn,
+                                            uint32_t p, uint32_t q, uint32_t restarted, uint32_t newly, uint64_t choice) {
+    u32x4 v;
+    v.x = turn; v.y = p | (q << 8) | (restarted << 16) | (newly << 20);
+    v.z = (uint32_t)choice; v.w = (uint32_t)(choice >> 32);
+    ((__attribute__((address_space(1))) u32x4 *)(uintptr_t)trace)[(uint64_t)t * rooms_padded + room] = v;
+}
+
 template <int NB>
 __device__ __forceinline__ void run_ww(const SegDev *__restrict__ sgp, const StepArgs &a, const DevRow *rows, WaveLds *lw,
                                        uint64_t room_in) {
@@ -102,13 +112,20 @@ __device__ __forceinline__ void run_ww(const SegDev *__restrict__ sgp, const Ste
     L::unpack(iw, s0);
     const DevRow row0 = rows[sg.phase0_idx];
     for (uint32_t t = 0; t < a.n_turns; t++) {
+        uint32_t restarted = 0;
         if (a.restart && ((row.r0 >> 11) & 7u) == 0u) {      // recycle a finished room
             const uint32_t g = s.games;
             s = s0;
             s.games = g < 0xFFFFu ? g + 1u : g;
             row = row0;
+            restarted = 1;
         }
-        ww_turn<NB, GE_WAVE_QUEUE>(s, row, rows, lw, valid, sg.n_players, sg.nw, sg.phase0_idx, rk, a.turn0 + t);
+        const uint32_t p = s.phase;
+        uint32_t ev_newly = 0;
+        uint64_t ev_choice = 0;
+        ww_turn<NB, GE_WAVE_QUEUE>(s, row, rows, lw, valid, sg.n_players, sg.nw, sg.phase0_idx, rk, a.turn0 + t,
+                                   a.trace != 0u, ev_newly, ev_choice);
+        if (a.trace && valid) store_event(sg.trace, sg.rooms_padded, t, room, a.turn0 + t, p, s.phase, restarted, ev_newly, ev_choice);
     }
     if (!valid) return;
     L::pack(s, w);
@@ -134,13 +151,19 @@ __device__ __forceinline__ void run_tt(const SegDev *__restrict__ sgp, const Ste
     L::unpack(iw, s0);
     const DevRow row0 = rows[sg.phase0_idx];
     for (uint32_t t = 0; t < a.n_turns; t++) {
+        uint32_t restarted = 0;
         if (a.restart && ((row.r0 >> 11) & 7u) == 0u) {
             const uint32_t g = s.games;
             s = s0;
             s.games = g < 0xFFFFu ? g + 1u : g;
             row = row0;
+            restarted = 1;
         }
-        tt_turn<NB>(s, row, rows, valid, sg.n_players, sg.rounds, sg.phase0_idx, rk, a.turn0 + t);
+        const uint32_t p = s.phase;
+        uint32_t ev_newly = 0;
+        uint64_t ev_choice = 0;
+        tt_turn<NB>(s, row, rows, valid, sg.n_players, sg.rounds, sg.phase0_idx, rk, a.turn0 + t, a.trace != 0u, ev_newly, ev_choice);
+        if (a.trace && valid) store_event(sg.trace, sg.rooms_padded, t, room, a.turn0 + t, p, s.phase, restarted, ev_newly, ev_choice);
     }
     if (!valid) return;
     L::pack(s, w);
@@ -442,6 +465,8 @@ struct ge_batch {
     uint32_t max_fuse = 64, block_threads = 256, n_blocks = 0, flags = 0;
     std::vector<Segment> segs;
     void *state = nullptr;            // one allocation, segments back to back
+    void *trace = nullptr;            // GE_FLAG_TRACE: per segment [max_fuse][rooms_padded] x 16 B
+    uint32_t last_step_turns = 0;     // turns of the most recent ge_batch_step (what the trace holds)
     size_t state_bytes = 0;
     DevTable *tables = nullptr;
     SegDev *segs_dev = nullptr;
@@ -462,6 +487,7 @@ static int fill_args(const ge_batch *b, StepArgs &a, uint32_t turn0, uint32_t n_
     a.seed_lo = (uint32_t)b->seed; a.seed_hi = (uint32_t)(b->seed >> 32);
     a.block_threads = b->block_threads;
     a.restart = (b->flags & GE_FLAG_RESTART) ? 1u : 0u;
+    a.trace = (b->flags & GE_FLAG_TRACE) ? 1u : 0u;
     return GE_OK;
 }
 
@@ -550,6 +576,16 @@ int ge_batch_create(const ge_batch_desc *desc, ge_batch **out) {
         if (hipMalloc(reinterpret_cast<void **>(&b->tables), sizeof(DevTable) * b->segs.size()) != hipSuccess ||
             hipMalloc(reinterpret_cast<void **>(&b->segs_dev), sizeof(SegDev) * GE_MAX_SEGMENTS) != hipSuccess ||
             hipMalloc(reinterpret_cast<void **>(&b->sum_dev), sizeof(unsigned long long) * 64) != hipSuccess) { st = GE_ERR_HIP; break; }
+        if (b->flags & GE_FLAG_TRACE) {
+            size_t tb = 0;
+            for (Segment &s : b->segs) tb += (size_t)b->max_fuse * s.dev.rooms_padded * 16u;
+            if (hipMalloc(&b->trace, tb) != hipSuccess) { st = GE_ERR_NOMEM; break; }
+            size_t off = 0;
+            for (Segment &s : b->segs) {
+                s.dev.trace = reinterpret_cast<uint32_t *>(static_cast<char *>(b->trace) + off);
+                off += (size_t)b->max_fuse * s.dev.rooms_padded * 16u;
+            }
+        }
         std::vector<DevTable> host_tables(b->segs.size());
         for (size_t k = 0; k < b->segs.size(); k++) {
             Segment &s = b->segs[k];
@@ -612,6 +648,8 @@ int ge_batch_set_timing(ge_batch *b, int on) {
 int ge_batch_step(ge_batch *b, uint32_t n_turns, void *hip_stream) {
     if (!b) return GE_ERR_ARG;
     if (b->turn + n_turns > 0xFFFFFFFFull) return GE_ERR_RANGE;
+    if ((b->flags & GE_FLAG_TRACE) && n_turns > b->max_fuse) return GE_ERR_RANGE;   // the trace holds one launch
+    b->last_step_turns = n_turns;
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     HIP_TRY(hipSetDevice(b->device));
     b->last_stream = st;
@@ -738,6 +776,44 @@ int ge_batch_write_rooms(ge_batch *b, uint64_t first, uint64_t count, const ge_r
     return rooms_io(b, first, count, nullptr, src);
 }
 
+int ge_batch_read_events(ge_batch *b, uint64_t first, uint64_t count, uint32_t *n_turns, ge_turn_event *dst, size_t cap_bytes) {
+    if (!b || !n_turns || (!dst && count)) return GE_ERR_ARG;
+    if (!(b->flags & GE_FLAG_TRACE)) return GE_ERR_UNSUPPORTED;
+    if (first + count > b->n_rooms || first + count < first) return GE_ERR_RANGE;
+    const uint32_t T = b->last_step_turns;
+    *n_turns = T;
+    if (cap_bytes / sizeof(ge_turn_event) < count * (uint64_t)T) return GE_ERR_ARG;
+    int st = ge_batch_sync(b);
+    if (st != GE_OK) return st;
+    std::vector<uint32_t> buf;
+    for (Segment &s : b->segs) {
+        const uint64_t lo = first > s.local_first ? first : s.local_first;
+        const uint64_t hi = (first + count) < (s.local_first + s.dev.rooms) ? (first + count) : (s.local_first + s.dev.rooms);
+        if (lo >= hi) continue;
+        const uint64_t r0 = lo - s.local_first, nr = hi - lo;
+        buf.resize((size_t)nr * 4);
+        const bool tt = s.table.pack == GE_PACK_TWO_TRUTHS;
+        for (uint32_t t = 0; t < T; t++) {
+            const char *dev = reinterpret_cast<const char *>(s.dev.trace) + ((uint64_t)t * s.dev.rooms_padded + r0) * 16u;
+            HIP_TRY(hipMemcpy(buf.data(), dev, (size_t)nr * 16u, hipMemcpyDeviceToHost));
+            for (uint64_t r = 0; r < nr; r++) {
+                const uint32_t *w = &buf[r * 4];
+                ge_turn_event &e = dst[(lo - first + r) * T + t];
+                memset(&e, 0, sizeof e);
+                e.turn = w[0];
+                e.from_phase_id = s.table.rows[w[1] & 255u].phase_id;
+                e.to_phase_id = s.table.rows[(w[1] >> 8) & 255u].phase_id;
+                e.restarted = (w[1] >> 16) & 1u;
+                e.acted_now = (uint16_t)(w[1] >> 20);
+                const uint64_t ch = (uint64_t)w[2] | ((uint64_t)w[3] << 32);
+                for (int i = 0; i < 16; i++) e.choice[i] = (uint8_t)((ch >> (4 * i)) & 15u);
+                (void)tt;
+            }
+        }
+    }
+    return GE_OK;
+}
+
 int ge_batch_summary(ge_batch *b, ge_summary *out) {
     if (!b || !out) return GE_ERR_ARG;
     HIP_TRY(hipSetDevice(b->device));
@@ -781,6 +857,7 @@ void ge_batch_destroy(ge_batch *b) {
     (void)hipSetDevice(b->device);
     for (auto &ev : b->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     if (b->state) (void)hipFree(b->state);
+    if (b->trace) (void)hipFree(b->trace);
     if (b->tables) (void)hipFree(b->tables);
     if (b->segs_dev) (void)hipFree(b->segs_dev);
     if (b->sum_dev) (void)hipFree(b->sum_dev);

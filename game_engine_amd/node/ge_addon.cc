@@ -130,12 +130,13 @@ napi_value CreateBatch(napi_env env, napi_callback_info info) {
     if (argc < 1) return throw_status(env, GE_ERR_ARG, "createBatch");
     ge_batch_desc d;
     memset(&d, 0, sizeof d);
-    uint64_t dev = 0, fuse = 0, restart = 0;
+    uint64_t dev = 0, fuse = 0, restart = 0, trace = 0;
     if (!get_prop_u64(env, argv[0], "seed", &d.seed, 0) || !get_prop_u64(env, argv[0], "firstRoom", &d.first_room, 0) ||
         !get_prop_u64(env, argv[0], "device", &dev, 0) || !get_prop_u64(env, argv[0], "maxFuse", &fuse, 0) ||
-        !get_prop_u64(env, argv[0], "restart", &restart, 0))
+        !get_prop_u64(env, argv[0], "restart", &restart, 0) || !get_prop_u64(env, argv[0], "trace", &trace, 0))
         return throw_status(env, GE_ERR_ARG, "createBatch");
-    d.device = (int32_t)dev; d.max_fuse = (uint32_t)fuse; d.flags = restart ? GE_FLAG_RESTART : GE_FLAG_NONE;
+    d.device = (int32_t)dev; d.max_fuse = (uint32_t)fuse;
+    d.flags = (restart ? GE_FLAG_RESTART : GE_FLAG_NONE) | (trace ? GE_FLAG_TRACE : GE_FLAG_NONE);
     napi_value segs;
     uint32_t n = 0;
     bool is_arr = false;
@@ -254,6 +255,31 @@ napi_value ReadRooms(napi_env env, napi_callback_info info) {
     return buf;
 }
 
+// readEvents(batch, first, count): { nTurns, buffer: ArrayBuffer of count*nTurns ge_turn_event }
+napi_value ReadEvents(napi_env env, napi_callback_info info) {
+    size_t argc = 3;
+    napi_value argv[3];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    ge_batch *b = argc >= 1 ? batch_arg(env, argv[0]) : nullptr;
+    uint64_t first = 0, count = 0;
+    if (!b || argc < 3 || !get_u64(env, argv[1], &first) || !get_u64(env, argv[2], &count))
+        return throw_status(env, GE_ERR_ARG, "readEvents");
+    uint32_t nt = 0;
+    int st = ge_batch_read_events(b, first, 0, &nt, nullptr, 0);
+    if (st != GE_OK) return throw_status(env, st, "readEvents");
+    void *data = nullptr;
+    napi_value buf, out, v;
+    const size_t bytes = (size_t)count * nt * sizeof(ge_turn_event);
+    NAPI_OK(napi_create_arraybuffer(env, bytes, &data, &buf));
+    st = ge_batch_read_events(b, first, count, &nt, static_cast<ge_turn_event *>(data), bytes);
+    if (st != GE_OK) return throw_status(env, st, "readEvents");
+    NAPI_OK(napi_create_object(env, &out));
+    NAPI_OK(napi_create_uint32(env, nt, &v));
+    NAPI_OK(napi_set_named_property(env, out, "nTurns", v));
+    NAPI_OK(napi_set_named_property(env, out, "buffer", buf));
+    return out;
+}
+
 // summary(batch): BigUint64Array-compatible ArrayBuffer of ge_summary words
 napi_value Summary(napi_env env, napi_callback_info info) {
     size_t argc = 1;
@@ -300,6 +326,7 @@ napi_value Init(napi_env env, napi_value exports) {
         {"step", nullptr, Step, nullptr, nullptr, nullptr, napi_default, nullptr},
         {"stepSync", nullptr, StepSync, nullptr, nullptr, nullptr, napi_default, nullptr},
         {"readRooms", nullptr, ReadRooms, nullptr, nullptr, nullptr, napi_default, nullptr},
+        {"readEvents", nullptr, ReadEvents, nullptr, nullptr, nullptr, napi_default, nullptr},
         {"summary", nullptr, Summary, nullptr, nullptr, nullptr, napi_default, nullptr},
         {"reset", nullptr, Reset, nullptr, nullptr, nullptr, napi_default, nullptr},
         {"deviceCount", nullptr, DeviceCount, nullptr, nullptr, nullptr, napi_default, nullptr},

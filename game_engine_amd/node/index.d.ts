@@ -26,6 +26,10 @@ export interface Summary {
   sum_end_turn: bigint; end_turn_hist: bigint[]; score_hist: bigint[]; checksum: bigint; turn: bigint;
   games_recycled: bigint;
 }
+export interface TurnEvent {
+  turn: number; from_phase_id: number; to_phase_id: number; acted_now: number; restarted: number; choice: number[];
+}
+export interface ToolCall { name: 'update_player_actions' | 'set_next_phase' | 'update_player_state' | 'add_game_note'; args: Record<string, unknown>; }
 export interface PhaseInfo { id: number; name: string; completion: number; act: number; effect: number; }
 
 export class GameTable {
@@ -37,7 +41,7 @@ export class GameTable {
 export interface Segment { table: GameTable; nPlayers: number; nRooms: number; }
 export interface BatchOptions {
   segments: Segment[]; seed?: bigint | number; firstRoom?: bigint | number; device?: number;
-  maxFuse?: number; restart?: boolean;
+  maxFuse?: number; restart?: boolean; trace?: boolean;
 }
 export class RoomBatch {
   constructor(opts: BatchOptions);
@@ -47,7 +51,9 @@ export class RoomBatch {
   reset(): void;
   readRoom(room: number): RoomState;
   readRooms(first: number, count: number): RoomState[];
+  readEvents(first: number, count: number): TurnEvent[][];
   summary(): Summary;
 }
+export function turnToolCalls(table: GameTable, before: RoomState, after: RoomState, event: TurnEvent): ToolCall[];
 export function loadDslByGamename(gamename: string, gamesDir?: string): object;
 export function deviceCount(): number;

@@ -85,12 +85,63 @@ function decodeRoom(table, buf, off) {
   };
 }
 
+const EVENT_SIZE = 32;
+
+function actionText(act, player, c) {
+  if (act === 1 || act === 4) return `voted to eliminate Player ${c}`;
+  if (act === 2) return `chose to protect Player ${c}`;
+  if (act === 3) return `investigated Player ${c}`;
+  if (act === 5) return 'shared three statements: ' + [1, 2, 3].map((s) => `'Statement ${s} of Player ${player}'`).join(', ');
+  if (act === 6) return `chose statement ${c} as the lie`;
+  return `voted that statement ${c} is the lie`;
+}
+
+/**
+ * One stepped turn of one room as the reference's backend tool calls
+ * (agent/tools/backend_tools.py:10-157), in node order: update_player_actions* ->
+ * set_next_phase -> update_player_state* -> add_game_note*.  Same rendering as the Python host
+ * (game_engine_amd/toolcalls.py); applying the calls to the reference's dict state reproduces
+ * the GPU state.  `before`/`after`: RoomState; `event`: from RoomBatch.readEvents().
+ */
+function turnToolCalls(table, before, after, event) {
+  const calls = [];
+  const ids = Object.keys(after.player_states).sort((a, b) => Number(a) - Number(b));
+  const from = table.info.phases.find((x) => x.id === event.from_phase_id);
+  ids.forEach((pid, i) => {
+    if ((event.acted_now >> i) & 1) {
+      const c = event.choice[i];
+      calls.push({ name: 'update_player_actions', args: { player_id: pid, actions: `[t=${event.turn}|c=${c}] ${actionText(from.act, i + 1, c)}`, phase: from.name } });
+    }
+  });
+  const moved = event.to_phase_id !== event.from_phase_id;
+  calls.push({ name: 'set_next_phase', args: { transition: moved, next_phase_id: event.to_phase_id, transition_reason: moved ? 'phase complete' : 'waiting' } });
+  const deaths = [];
+  ids.forEach((pid, i) => {
+    const b = before.player_states[pid], a = after.player_states[pid];
+    for (const name of Object.keys(a)) {
+      if (JSON.stringify(b[name]) !== JSON.stringify(a[name])) calls.push({ name: 'update_player_state', args: { player_id: pid, state_name: name, state_value: a[name] } });
+    }
+    if ('is_alive' in a && b.is_alive && !a.is_alive) deaths.push([pid, a.role]);
+    if ('statements_submitted' in a) {
+      if (a.statements_submitted && !b.statements_submitted) {
+        const st = {}; [1, 2, 3].forEach((s) => { st[String(s)] = `Statement ${s} of Player ${i + 1}`; });
+        calls.push({ name: 'update_player_state', args: { player_id: pid, state_name: 'statements', state_value: st } });
+      } else if (b.statements_submitted && !a.statements_submitted) {
+        calls.push({ name: 'update_player_state', args: { player_id: pid, state_name: 'statements', state_value: {} } });
+      }
+    }
+  });
+  if (moved) calls.push({ name: 'add_game_note', args: { note_type: 'PHASE_STATUS', content: `[t=${event.turn}] phase ${event.from_phase_id} -> ${event.to_phase_id}` } });
+  deaths.forEach(([pid, role]) => calls.push({ name: 'add_game_note', args: { note_type: 'CRITICAL', content: `Player ${pid} (${role}) eliminated - marked is_alive=false` } }));
+  return calls;
+}
+
 class RoomBatch {
   /** segments: [{table: GameTable, nPlayers, nRooms}] */
-  constructor({ segments, seed = 0n, firstRoom = 0n, device = 0, maxFuse = 0, restart = false }) {
+  constructor({ segments, seed = 0n, firstRoom = 0n, device = 0, maxFuse = 0, restart = false, trace = false }) {
     this.segments = segments;
     this.handle = addon.createBatch({
-      seed, firstRoom, device, maxFuse, restart,
+      seed, firstRoom, device, maxFuse, restart, trace,
       segments: segments.map((s) => ({ table: s.table.handle, nPlayers: s.nPlayers, nRooms: s.nRooms })),
     });
     this.nRooms = segments.reduce((a, s) => a + s.nRooms, 0);
@@ -112,6 +163,22 @@ class RoomBatch {
     for (let i = 0; i < count; i++) out.push(decodeRoom(this.tableOf(first + i), buf, i * VIEW.size));
     return out;
   }
+  /** [room][turn] events of the most recent step() (batch created with trace: true). */
+  readEvents(first, count) {
+    const { nTurns, buffer } = addon.readEvents(this.handle, first, count);
+    const out = [];
+    for (let r = 0; r < count; r++) {
+      const row = [];
+      for (let t = 0; t < nTurns; t++) {
+        const off = (r * nTurns + t) * EVENT_SIZE;
+        const dv = new DataView(buffer, off, EVENT_SIZE);
+        row.push({ turn: dv.getUint32(0, true), from_phase_id: dv.getInt32(4, true), to_phase_id: dv.getInt32(8, true),
+                   acted_now: dv.getUint16(12, true), restarted: dv.getUint8(14), choice: Array.from(new Uint8Array(buffer, off + 16, 16)) });
+      }
+      out.push(row);
+    }
+    return out;
+  }
   summary() {
     const w = new BigUint64Array(addon.summary(this.handle));
     return {
@@ -122,4 +189,4 @@ class RoomBatch {
   }
 }
 
-module.exports = { GameTable, RoomBatch, loadDslByGamename, deviceCount: addon.deviceCount, addon };
+module.exports = { GameTable, RoomBatch, loadDslByGamename, turnToolCalls, deviceCount: addon.deviceCount, addon };

@@ -1,7 +1,7 @@
 'use strict';
 // node selftest.js <dsl.json> [golden.json]   — used by tests/test_node_host.py
 const fs = require('fs');
-const { GameTable, RoomBatch, deviceCount } = require('./index.js');
+const { GameTable, RoomBatch, deviceCount, turnToolCalls } = require('./index.js');
 const dsl = JSON.parse(fs.readFileSync(process.argv[2], 'utf8'));
 const table = new GameTable(dsl);
 const out = { phases: table.info.phases.length, pack: table.info.pack, devices: deviceCount() };
@@ -30,6 +30,16 @@ if (deviceCount() === 0) {
       }
       checked++;
     }
+  }
+  // tool calls of a traced single room (the drop-in case: one LangGraph thread), for comparison with the Python host
+  const one = new RoomBatch({ segments: [{ table, nPlayers: golden.n_players, nRooms: 1 }], seed: 5n, firstRoom: 9n, maxFuse: 1, trace: true });
+  out.calls = [];
+  let before = one.readRoom(0);
+  for (let t = 0; t < 30; t++) {
+    one.stepSync(1);
+    const after = one.readRoom(0);
+    out.calls.push(turnToolCalls(table, before, after, one.readEvents(0, 1)[0][0]));
+    before = after;
   }
   const big = new RoomBatch({ segments: [{ table, nPlayers: golden.n_players, nRooms: 10000 }], seed: 7n });
   await big.step(64);

@@ -22,6 +22,9 @@ ROOM_VIEW_DTYPE = np.dtype([("phase_id", "<i4"), ("prev_phase_id", "<i4"), ("end
                             ("phase0_done", "u1"), ("n_players", "u1"), ("pack", "u1"), ("pad", "u1"),
                             ("players", "u1", (16, 12)), ("det", "u1", (16,))])
 
+EVENT_DTYPE = np.dtype([("turn", "<u4"), ("from_phase_id", "<i4"), ("to_phase_id", "<i4"), ("acted_now", "<u2"),
+                        ("restarted", "u1"), ("pad", "u1"), ("choice", "u1", (16,))])
+
 PACK_WEREWOLF, PACK_TWO_TRUTHS = 1, 2
 WW_FIELDS = ["role", "team", "is_alive", "role_revealed", "can_vote", "has_secret_role",
              "night_action_eligible", "night_action_submitted", "selected_target_id"]
@@ -119,14 +122,14 @@ class RoomBatch:
     (= one LangGraph run per room in the reference)."""
 
     def __init__(self, segments: Sequence[Segment], seed: int = 0, first_room: int = 0,
-                 device: int = 0, max_fuse: int = 0, restart: bool = False):
+                 device: int = 0, max_fuse: int = 0, restart: bool = False, trace: bool = False):
         lib = _lib.load()
         if not 1 <= len(segments) <= _lib.GE_MAX_SEGMENTS:
             raise GeError(-1, "segments")
         self.segments = list(segments)
         d = _lib.BatchDesc()
         d.seed, d.first_room, d.n_segments, d.device, d.max_fuse = seed, first_room, len(segments), device, max_fuse
-        d.flags = 1 if restart else 0
+        d.flags = (1 if restart else 0) | (2 if trace else 0)
         for k, (tb, n_players, n_rooms) in enumerate(segments):
             d.seg[k].table = C.pointer(tb.c)
             d.seg[k].n_players, d.seg[k].n_rooms = n_players, n_rooms
@@ -183,6 +186,17 @@ class RoomBatch:
     def write_rooms(self, first: int, views: np.ndarray):
         assert views.dtype == ROOM_VIEW_DTYPE and views.flags.c_contiguous
         _check(self._lib.ge_batch_write_rooms(self._h, first, len(views), views.ctypes.data), "ge_batch_write_rooms")
+
+    def read_events(self, first: int = 0, count: Optional[int] = None) -> np.ndarray:
+        """[count, n_turns] events of the most recent step() call (batch created with trace=True)."""
+        count = self.n_rooms - first if count is None else count
+        n = C.c_uint32()
+        st = self._lib.ge_batch_read_events(self._h, first, 0, C.byref(n), None, 0)
+        _check(st, "ge_batch_read_events")
+        out = np.zeros((count, max(n.value, 1)), dtype=EVENT_DTYPE)
+        _check(self._lib.ge_batch_read_events(self._h, first, count, C.byref(n), out.ctypes.data, out.nbytes),
+               "ge_batch_read_events")
+        return out[:, : n.value]
 
     def summary(self) -> Dict[str, Any]:
         s = _lib.Summary()

@@ -120,6 +120,17 @@ typedef struct ge_room_view {
     uint8_t det[16];
 } ge_room_view;
 
+/* What one turn of one room logged and decided (GE_FLAG_TRACE). */
+typedef struct ge_turn_event {
+    uint32_t turn;
+    int32_t from_phase_id;                /* current_phase_id when the turn started */
+    int32_t to_phase_id;                  /* ... when it ended (== from: no transition) */
+    uint16_t acted_now;                   /* bit i: player i+1 logged an action this turn (BotBehaviorNode) */
+    uint8_t restarted;                    /* GE_FLAG_RESTART: the slot was re-initialised at the start of this turn */
+    uint8_t pad;
+    uint8_t choice[16];                   /* the choice each of those players logged (player id / statement no.) */
+} ge_turn_event;
+
 typedef struct ge_segment_desc {
     const ge_game_table *table;           /* copied at create; need not outlive the call */
     uint32_t n_players;                   /* werewolf 4..12, two-truths 3..12 */
@@ -133,6 +144,11 @@ typedef struct ge_segment_desc {
  * DSL template (a new game on the same slot; the turn counter and hence the RNG stream keep
  * running).  Off: terminal phases are absorbing, as in the reference. */
 #define GE_FLAG_RESTART 1u
+/* keep, for every room, one ge_turn_event per turn of the most recent ge_batch_step call (which
+ * must then not exceed max_fuse turns): what the turn logged and decided, so that a host can
+ * surface it as the reference's backend tool calls (update_player_actions / set_next_phase /
+ * update_player_state, agent/tools/backend_tools.py:10-157).  Costs 16 B of HBM writes per room-turn. */
+#define GE_FLAG_TRACE 2u
 
 typedef struct ge_batch_desc {
     uint64_t seed;
@@ -185,6 +201,11 @@ int ge_batch_read_rooms(ge_batch *b, uint64_t first, uint64_t count, ge_room_vie
 
 /* Overwrites rooms from canonical views (checkpoint restore, tests of hand-built states). */
 int ge_batch_write_rooms(ge_batch *b, uint64_t first, uint64_t count, const ge_room_view *src);
+
+/* GE_FLAG_TRACE: events of the most recent ge_batch_step call, dst[(room - first) * *n_turns + t].
+ * cap_bytes >= count * n_turns * sizeof(ge_turn_event).  Synchronises. */
+int ge_batch_read_events(ge_batch *b, uint64_t first, uint64_t count, uint32_t *n_turns,
+                         ge_turn_event *dst, size_t cap_bytes);
 
 /* Device-side reduction of the whole batch.  Synchronises. */
 int ge_batch_summary(ge_batch *b, ge_summary *out);

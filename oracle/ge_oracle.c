@@ -65,6 +65,10 @@ typedef struct {
     int32_t games;            /* restart mode: games completed on this slot before the current one */
     uint8_t p[16][12];
     uint8_t det[16];          /* 0 unknown, 1 villagers, 2 werewolves (the detective's memory) */
+    /* what the most recent turn logged and decided (not part of the projection) */
+    uint8_t ev_from, ev_to, ev_restarted, ev_pad;
+    uint16_t ev_newly, ev_pad2;
+    uint8_t ev_choice[16];
 } orc_room;
 
 /* ---- RNG: POLICY.md §RNG (restated from the text, cf. oracle/rng.py) ---- */
@@ -144,6 +148,9 @@ void orc_room_step(const orc_table *tb, orc_room *r, uint64_t seed, uint64_t roo
     const orc_phase *ph = &tb->ph[p];
     const uint32_t tk = turn_key(room_key(seed, room), turn);
     uint8_t newly[16] = {0};
+    r->ev_from = r->ev_to = (uint8_t)p;
+    r->ev_newly = 0;
+    memset(r->ev_choice, 0, sizeof r->ev_choice);
 
     /* ---- BotBehaviorNode (v2:468-617): due bots act, one action per player per visit */
     if (ph->completion == COMP_ACTION) {
@@ -196,7 +203,10 @@ void orc_room_step(const orc_table *tb, orc_room *r, uint64_t seed, uint64_t roo
             newly[i] = 1;
         }
         for (int i = 0; i < n; i++)
-            if (newly[i]) { r->p[i][F_ACTED] = 1; r->p[i][F_CHOICE] = choice[i]; }
+            if (newly[i]) {
+                r->p[i][F_ACTED] = 1; r->p[i][F_CHOICE] = choice[i];
+                r->ev_newly |= (uint16_t)(1u << i); r->ev_choice[i] = choice[i];
+            }
     }
 
     /* ---- PhaseNode (v2:987-1241) */
@@ -327,6 +337,7 @@ void orc_room_step(const orc_table *tb, orc_room *r, uint64_t seed, uint64_t roo
     for (int i = 0; i < n; i++) { r->p[i][F_ACTED] = 0; r->p[i][F_CHOICE] = 0; }
     r->prev = (uint8_t)p;
     r->phase = (uint8_t)q;
+    r->ev_to = (uint8_t)q;
     if (!qh->n_branches && r->end_turn < 0) r->end_turn = turn < 0xFFFEu ? (int32_t)turn : 0xFFFE;
 }
 
@@ -340,7 +351,9 @@ void orc_run(const orc_table *tb, uint64_t seed, uint64_t first_room, uint64_t n
     for (int64_t i = 0; i < (int64_t)n_rooms; i++)
         for (uint32_t t = 0; t < n_turns; t++) {
             orc_room *r = &rooms[i];
+            int restarted = 0;
             if (restart && !tb->ph[r->phase].n_branches) {
+                restarted = 1;
                 /* steady state: a finished room becomes a NEW room on the same slot; the clock
                  * (turn index) keeps running, so the new game draws fresh random numbers */
                 int32_t g = r->games < 0xFFFF ? r->games + 1 : r->games;
@@ -348,6 +361,7 @@ void orc_run(const orc_table *tb, uint64_t seed, uint64_t first_room, uint64_t n
                 r->games = g;
             }
             orc_room_step(tb, r, seed, first_room + (uint64_t)i, first_turn + t);
+            r->ev_restarted = (uint8_t)restarted;
         }
     (void)threads;
 }

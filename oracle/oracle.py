@@ -37,7 +37,9 @@ class _Table(C.Structure):
 
 
 ROOM_DTYPE = np.dtype([("phase", "u1"), ("prev", "u1"), ("phase0_done", "u1"), ("n", "u1"),
-                       ("end_turn", "<i4"), ("games", "<i4"), ("p", "u1", (16, 12)), ("det", "u1", (16,))])
+                       ("end_turn", "<i4"), ("games", "<i4"), ("p", "u1", (16, 12)), ("det", "u1", (16,)),
+                       ("ev_from", "u1"), ("ev_to", "u1"), ("ev_restarted", "u1"), ("ev_pad", "u1"),
+                       ("ev_newly", "<u2"), ("ev_pad2", "<u2"), ("ev_choice", "u1", (16,))])
 
 
 def build(force: bool = False) -> str:

@@ -37,3 +37,17 @@ def assert_views_equal(got: np.ndarray, want: np.ndarray, what=""):
             raise AssertionError(f"{what}: field {name!r} differs in {len(bad)} rooms; first room {i}: "
                                  f"got {got[name][i].tolist()} want {want[name][i].tolist()}")
     raise AssertionError(what + ": padding differs")
+
+
+def oracle_events(orc, rooms: np.ndarray, turn: int) -> np.ndarray:
+    """The oracle's record of the turn it just ran, in the product's ge_turn_event layout."""
+    from game_engine_amd.stepper import EVENT_DTYPE
+    ids = np.array(orc.ids, dtype=np.int32)
+    e = np.zeros(len(rooms), dtype=EVENT_DTYPE)
+    e["turn"] = turn
+    e["from_phase_id"] = ids[rooms["ev_from"]]
+    e["to_phase_id"] = ids[rooms["ev_to"]]
+    e["acted_now"] = rooms["ev_newly"]
+    e["restarted"] = rooms["ev_restarted"]
+    e["choice"] = rooms["ev_choice"]
+    return e

@@ -38,3 +38,16 @@ def test_node_host_matches_golden(dsl, gold):
     g = json.load(open(os.path.join(GOLD, gold)))
     assert r["devices"] >= 1 and r["checked"] == sum(len(c["turns"]) for c in g["cases"])
     assert r["turn"] == 64 and r["finished"] > 0 and isinstance(r["sample"], str)
+    # the JS host renders the same backend tool calls as the Python host for the same traced room
+    from conftest import load_dsl
+    from game_engine_amd import GameTable, RoomBatch
+    from game_engine_amd.toolcalls import turn_tool_calls
+    tb = GameTable(load_dsl(dsl[:-5]))
+    with RoomBatch([(tb, g["n_players"], 1)], seed=5, first_room=9, max_fuse=1, trace=True) as b:
+        before = b.read_rooms(0, 1)[0].copy()
+        for t in range(30):
+            b.step(1)
+            after = b.read_rooms(0, 1)[0].copy()
+            want = turn_tool_calls(tb, before, after, b.read_events(0, 1)[0][0])
+            assert r["calls"][t] == json.loads(json.dumps(want)), t
+            before = after
