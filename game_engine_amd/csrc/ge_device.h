@@ -218,10 +218,15 @@ __device__ __forceinline__ void ww_turn(WW<NB> &s, DevRow &row, const DevRow *ro
             if (total != 0u) {                                  // wave-uniform
                 lw->ctx[lane] = make_uint4(s.alive | (s.team_w << 16), known | (r_det << 16), lo_kw | (act << 16), tk);
                 lw->res[lane] = make_uint4(0u, 0u, 0u, 0u);
-                while (todo) {
-                    const uint32_t i = ctz(todo);
-                    todo &= todo - 1u;
-                    lw->queue[off++] = (uint16_t)(lane | (i << 6));
+                // straight-line, predicated: a loop's taken back-edges are what a lone wavefront
+                // per SIMD (the 65 536-room shape) cannot hide
+#pragma unroll
+                for (int j = 0; j < NB; j++) {
+                    if (todo) {
+                        const uint32_t i = ctz(todo);
+                        todo &= todo - 1u;
+                        lw->queue[off + j] = (uint16_t)(lane | (i << 6));
+                    }
                 }
                 wave_sync();
                 for (uint32_t base = 0; base < total; base += 64u) {
@@ -297,12 +302,14 @@ __device__ __forceinline__ void ww_turn(WW<NB> &s, DevRow &row, const DevRow *ro
     const uint32_t eff = (q0 >> 5) & 7u;
     if (eff == EFF_ASSIGN_ROLES) {
         uint32_t rem = ALL, wolves = 0, doc = 0, det = 0;
-        for (uint32_t j = 0; j < nw + 2u; j++) {
+#pragma unroll
+        for (uint32_t j = 0; j < (NB > 8 ? 5u : 4u); j++) {           // nw + 2 picks, nw <= NB / 4
             const uint32_t k = popc(rem);
-            if (k == 0u) break;
-            const uint32_t bit = 1u << nth_set_bit<NB>(rem, pick(draw(tk, 16u + j), k));
-            rem &= ~bit;
-            if (j < nw) wolves |= bit; else if (j == nw) doc = bit; else det = bit;
+            if (j < nw + 2u && k != 0u) {
+                const uint32_t bit = 1u << nth_set_bit<NB>(rem, pick(draw(tk, 16u + j), k));
+                rem &= ~bit;
+                if (j < nw) wolves |= bit; else if (j == nw) doc = bit; else det = bit;
+            }
         }
         s.rb0 = rem | doc; s.rb1 = wolves | doc; s.rb2 = det;
         s.team_w = wolves; s.team_v = ALL & ~wolves;

@@ -77,3 +77,20 @@ def test_bad_dsl_is_an_error_not_a_guess(dsl_ww, mutate, needle):
 def test_empty_dsl():
     with pytest.raises(GeError):
         GameTable({})
+
+
+def test_reference_draft_dsl_is_rejected_not_guessed():
+    """game_draft/werewolf-(mafia).yaml declares a different player_states schema (has_night_action,
+    known_alignments, ...): no rule pack matches, and both compilers say so instead of guessing."""
+    import os
+    path = "/root/reference/game_draft/werewolf-(mafia).yaml"
+    if not os.path.exists(path):
+        pytest.skip("needs the reference checkout (build container)")
+    import yaml
+    with open(path, encoding="utf-8") as f:
+        d = yaml.safe_load(f)
+    with pytest.raises(GeError) as e:
+        GameTable(d)
+    assert "no rule pack" in str(e.value)
+    with pytest.raises(T.DslError):
+        T.compile_dsl(d)
