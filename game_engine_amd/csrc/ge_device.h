@@ -95,7 +95,7 @@ __device__ __forceinline__ uint32_t plurality(nib_t votes, uint32_t voters) {
 struct WaveLds {
     uint4 ctx[64];            // {alive | team_w<<16, known | r_det<<16, lo_kw | act<<16, turn key}
     uint4 res[64];            // {go mask, choice nibbles lo, choice nibbles hi, -}
-    uint16_t queue[64 * 12];  // lane | player << 6
+    uint16_t queue[64 * 13];  // lane | player << 6 ; the last 64 entries are per-lane dummies
 };
 
 __device__ __forceinline__ void wave_sync() {
@@ -132,7 +132,7 @@ __device__ __forceinline__ uint64_t nib_nonzero(uint64_t x) {
 template <int NB, bool QUEUE>
 __device__ __forceinline__ void ww_turn(WW<NB> &s, DevRow &row, const DevRow *rows, WaveLds *lw, bool valid, uint32_t n,
                                         uint32_t nw, uint32_t phase0_idx, uint32_t rkey, uint32_t turn,
-                                        bool trace, uint32_t &ev_newly, uint64_t &ev_choice) {
+                                        bool trace, bool lowocc, uint32_t &ev_newly, uint64_t &ev_choice) {
     // ev_*: this turn's logged actions (who acted, what they chose) for the optional event trace
     // `row` is the table row of s.phase, kept in registers across turns: LDS is read only on a transition
     using nib_t = typename WW<NB>::nib_t;
@@ -220,29 +220,41 @@ __device__ __forceinline__ void ww_turn(WW<NB> &s, DevRow &row, const DevRow *ro
                 lw->res[lane] = make_uint4(0u, 0u, 0u, 0u);
                 // straight-line, predicated: a loop's taken back-edges are what a lone wavefront
                 // per SIMD (the 65 536-room shape) cannot hide
+                if (lowocc) {
+                    // one wavefront per SIMD: every branch instruction stalls it (~50 cycles, nothing
+                    // else to issue), so write unconditionally; an exhausted lane hits its dummy slot
 #pragma unroll
-                for (int j = 0; j < NB; j++) {
-                    if (todo) {
-                        const uint32_t i = ctz(todo);
+                    for (int j = 0; j < NB; j++) {
+                        const uint32_t i = ctz(todo | 0x80000000u);
+                        lw->queue[todo ? off + j : 64u * 12u + lane] = (uint16_t)(lane | (i << 6));
                         todo &= todo - 1u;
-                        lw->queue[off + j] = (uint16_t)(lane | (i << 6));
+                    }
+                } else {
+                    // many wavefronts per SIMD: branches are hidden, LDS write slots are not
+#pragma unroll
+                    for (int j = 0; j < NB; j++) {
+                        if (todo) {
+                            const uint32_t i = ctz(todo);
+                            todo &= todo - 1u;
+                            lw->queue[off + j] = (uint16_t)(lane | (i << 6));
+                        }
                     }
                 }
                 wave_sync();
                 for (uint32_t base = 0; base < total; base += 64u) {
                     const uint32_t k = base + lane;
-                    if (k < total) {
-                        const uint32_t item = lw->queue[k];
-                        const uint32_t L = item & 63u, i = item >> 6;
-                        const uint4 c4 = lw->ctx[L];
-                        const uint32_t d = draw(c4.w, i);
-                        if ((d & 3u) != 0u) {
-                            const uint32_t c = ww_choose<NB>(c4.z >> 16, i, d, c4.x & 0xFFFFu, c4.x >> 16,
-                                                             c4.y & 0xFFFFu, c4.z & 0xFFFFu, c4.y >> 16);
-                            uint32_t *r = reinterpret_cast<uint32_t *>(&lw->res[L]);
-                            atomicOr(r, 1u << i);
-                            atomicOr(r + 1 + (i >> 3), c << (4u * (i & 7u)));
-                        }
+                    // slots past `total` hold stale but in-range entries: read them anyway and drop
+                    // the result, so that the whole item is one predicated block
+                    const uint32_t item = lw->queue[k < total ? k : 64u * 12u + lane];
+                    const uint32_t L = item & 63u, i = (item >> 6) & 15u;
+                    const uint4 c4 = lw->ctx[L];
+                    const uint32_t d = draw(c4.w, i);
+                    if (k < total && (d & 3u) != 0u) {
+                        const uint32_t c = ww_choose<NB>(c4.z >> 16, i, d, c4.x & 0xFFFFu, c4.x >> 16,
+                                                         c4.y & 0xFFFFu, c4.z & 0xFFFFu, c4.y >> 16);
+                        uint32_t *r = reinterpret_cast<uint32_t *>(&lw->res[L]);
+                        atomicOr(r, 1u << i);
+                        atomicOr(r + 1 + (i >> 3), c << (4u * (i & 7u)));
                     }
                 }
                 wave_sync();
@@ -253,9 +265,9 @@ __device__ __forceinline__ void ww_turn(WW<NB> &s, DevRow &row, const DevRow *ro
                 s.choice = (s.choice & ~m15) | got;
                 // RefereeNode (A): record the action (bt:204-225 update_player_state)
                 s.sel = night ? ((s.sel & ~m15) | got) : s.sel;
-                if (act == ACT_DETECTIVE && newly) {
-                    const uint32_t c = (uint32_t)(got >> (4u * ctz(newly))) & 15u;
-                    const uint32_t tb = 1u << (c - 1u);
+                {
+                    const uint32_t c = (uint32_t)(got >> (4u * ctz(newly | 0x80000000u))) & 15u;
+                    const uint32_t tb = (act == ACT_DETECTIVE && newly) ? (1u << ((c - 1u) & 15u)) : 0u;
                     new_det_w = tb & s.team_w;
                     new_det_v = tb & ~s.team_w;
                 }
@@ -274,12 +286,11 @@ __device__ __forceinline__ void ww_turn(WW<NB> &s, DevRow &row, const DevRow *ro
     }
 
     // ---- PhaseNode: phase-0 guard (v2:1025-1052): first turn only records phase 0, Referee skipped
-    if (s.phase == phase0_idx && !(s.flags & FLAG_PHASE0_DONE)) {
-        s.flags |= FLAG_PHASE0_DONE;
-        return;
-    }
+    const bool guard = s.phase == phase0_idx && !(s.flags & FLAG_PHASE0_DONE);
+    s.flags |= FLAG_PHASE0_DONE;                               // set by the guard turn; already set afterwards
     uint32_t q = s.phase;
-    if (nbr != 0u && (comp != COMP_ACTION || (T & ~s.acted) == 0u)) {
+    {   // evaluated for every lane, selected at the end (one branch less than a guarded block)
+        const bool open = !guard && nbr != 0u && (comp != COMP_ACTION || (T & ~s.acted) == 0u);
         const uint32_t w = popc(s.alive & s.team_w), g = popc(s.alive & s.team_v);
         const uint32_t prev_eff = (s.flags >> 1) & 7u;
         const uint32_t C = 1u | ((w == 0u) << RES_WOLVES_ZERO) | ((w >= g) << RES_WOLVES_GE_VILLAGERS) |
@@ -288,11 +299,11 @@ __device__ __forceinline__ void ww_turn(WW<NB> &s, DevRow &row, const DevRow *ro
 #pragma unroll
         for (int b = 3; b >= 0; b--) {
             const uint32_t res = (row.r2 >> (4 * b)) & 15u;
-            const bool ok = (uint32_t)b < nbr && ((C >> res) & 1u);
+            const bool ok = open && (uint32_t)b < nbr && ((C >> res) & 1u);
             q = ok ? ((row.r3 >> (8 * b)) & 255u) : q;
         }
     }
-    s.det_v |= new_det_v;
+    s.det_v |= new_det_v;                                      // (the guard turn has no actions: both are 0)
     s.det_w |= new_det_w;
     if (q == s.phase) return;
 
@@ -305,37 +316,34 @@ __device__ __forceinline__ void ww_turn(WW<NB> &s, DevRow &row, const DevRow *ro
 #pragma unroll
         for (uint32_t j = 0; j < (NB > 8 ? 5u : 4u); j++) {           // nw + 2 picks, nw <= NB / 4
             const uint32_t k = popc(rem);
-            if (j < nw + 2u && k != 0u) {
-                const uint32_t bit = 1u << nth_set_bit<NB>(rem, pick(draw(tk, 16u + j), k));
-                rem &= ~bit;
-                if (j < nw) wolves |= bit; else if (j == nw) doc = bit; else det = bit;
-            }
+            const bool on = j < nw + 2u && k != 0u;            // selects, not branches (see `lowocc`)
+            const uint32_t bit = on ? (1u << nth_set_bit<NB>(rem | (1u << 31), pick(draw(tk, 16u + j), k | (k == 0u)))) : 0u;
+            rem &= ~bit;
+            wolves |= j < nw ? bit : 0u;
+            doc = j == nw ? bit : doc;
+            det = j == nw + 1u ? bit : det;
         }
         s.rb0 = rem | doc; s.rb1 = wolves | doc; s.rb2 = det;
         s.team_w = wolves; s.team_v = ALL & ~wolves;
         s.secret = ALL & ~rem; s.elig = ALL & ~rem;
-    } else if (eff == EFF_NIGHT_BEGIN) {
-        s.sub = 0; s.sel = 0;
     } else if (eff == EFF_NIGHT_RESOLVE || eff == EFF_DAY_RESOLVE) {
         const bool day = eff == EFF_DAY_RESOLVE;
         const uint32_t voters = day ? (s.alive & s.acted) : (s.alive & r_wolf);
         const uint32_t victim = plurality<NB, nib_t>(day ? s.choice : s.sel, voters);
-        uint32_t protect = 0;
-        if (!day) {
-            const uint32_t docs = s.alive & r_doc;
-            if (docs) protect = (uint32_t)(s.sel >> (4u * (31u - (uint32_t)__clz((int)docs)))) & 15u;
-        }
-        if (victim != 0u && victim != protect) {
-            const uint32_t bit = 1u << (victim - 1u);
-            s.alive &= ~bit; s.can_vote &= ~bit; s.elig &= ~bit; s.revealed |= bit;
-        }
+        const uint32_t docs = s.alive & r_doc;                 // the highest-id living Doctor protects
+        const uint32_t guarded = (uint32_t)(s.sel >> (4u * (31u - (uint32_t)__clz((int)(docs | 1u))))) & 15u;
+        const uint32_t protect = (!day && docs) ? guarded : 0u;
+        const uint32_t bit = (victim != 0u && victim != protect) ? (1u << ((victim - 1u) & 15u)) : 0u;
+        s.alive &= ~bit; s.can_vote &= ~bit; s.elig &= ~bit; s.revealed |= bit;
     }
+    const bool nbeg = eff == EFF_NIGHT_BEGIN;
+    s.sub = nbeg ? 0u : s.sub; s.sel = nbeg ? nib_t(0) : s.sel;
     s.acted = 0; s.choice = 0;
     s.flags = (s.flags & FLAG_PHASE0_DONE) | (p_eff << 1);
     s.prev = s.phase;
     s.phase = q;
     row = qrow;
-    if (((q0 >> 11) & 7u) == 0u && s.end_turn == END_NONE) s.end_turn = turn < 0xFFFEu ? turn : 0xFFFEu;
+    s.end_turn = (((q0 >> 11) & 7u) == 0u && s.end_turn == END_NONE) ? (turn < 0xFFFEu ? turn : 0xFFFEu) : s.end_turn;
 }
 
 // ------------------------------------------------------------------ two truths and a lie

@@ -40,7 +40,7 @@ struct SegDev {
 };
 
 struct StepArgs {
-    uint32_t n_seg, turn0, n_turns, seed_lo, seed_hi, block_threads, restart, trace;
+    uint32_t n_seg, turn0, n_turns, seed_lo, seed_hi, block_threads, restart, trace, lowocc;
     uint32_t block_begin[GE_MAX_SEGMENTS];
 };
 
@@ -124,7 +124,7 @@ __device__ __forceinline__ void run_ww(const SegDev *__restrict__ sgp, const Ste
         uint32_t ev_newly = 0;
         uint64_t ev_choice = 0;
         ww_turn<NB, GE_WAVE_QUEUE>(s, row, rows, lw, valid, sg.n_players, sg.nw, sg.phase0_idx, rk, a.turn0 + t,
-                                   a.trace != 0u, ev_newly, ev_choice);
+                                   a.trace != 0u, a.lowocc != 0u, ev_newly, ev_choice);
         if (a.trace && valid) store_event(sg.trace, sg.rooms_padded, t, room, a.turn0 + t, p, s.phase, restarted, ev_newly, ev_choice);
     }
     if (!valid) return;
@@ -488,6 +488,7 @@ static int fill_args(const ge_batch *b, StepArgs &a, uint32_t turn0, uint32_t n_
     a.block_threads = b->block_threads;
     a.restart = (b->flags & GE_FLAG_RESTART) ? 1u : 0u;
     a.trace = (b->flags & GE_FLAG_TRACE) ? 1u : 0u;
+    a.lowocc = b->n_rooms < 3u * 1024u * 64u ? 1u : 0u;      // fewer than ~3 wavefronts per SIMD on 256 CUs
     return GE_OK;
 }
 
