@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--rooms", type=int, default=ROOMS_PER_GPU, help="rooms per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-unfused", action="store_true", help="skip the one-launch-per-turn reference point")
+    ap.add_argument("--no-other-shapes", action="store_true", help="skip the informational larger shapes")
     args = ap.parse_args()
 
     import torch
@@ -158,6 +159,25 @@ def main():
                    "achieved_GBs": 2 * bytes_per_room * rooms / (k1 * 1e-3 / max(l1, 1)) / 1e9}
         b1.close()
 
+    # other BASELINE shapes on one GPU (device time, informational; `value` above is the contract number)
+    other = None
+    if rank == 0 and world == 1 and not args.no_other_shapes:
+        other = {}
+        tt_dsl = json.load(open(os.path.join(ROOT, "tests", "golden", "dsl", "two-truths-and-a-lie.json"), encoding="utf-8"))
+        for label, tb, n, r in (("1048576 Werewolf x8", table, 8, 1 << 20),
+                                ("2097152 Werewolf x12 (one GPU's share of C4)", table, 12, 1 << 21),
+                                ("1048576 Two-Truths x4 (C3)", GameTable(tt_dsl), 4, 1 << 20)):
+            bb = RoomBatch([(tb, n, r)], seed=SEED, device=device_index, max_fuse=args.fuse, restart=True)
+            bb.step(128, stream); bb.sync()
+            bb.set_timing(True); bb.kernel_time(reset=True)
+            bb.step(512, stream); bb.sync()
+            ms, nl = bb.kernel_time(reset=True)
+            bpr = bb.bytes_per_room(0)
+            other[label] = {"value": r * 512 / (ms * 1e-3), "unit": "room-phase steps/s (device time)",
+                            "achieved_GBs": 2 * bpr * r * 512 / (ms * 1e-3) / 1e9,
+                            "frac": 2 * bpr * r * 512 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "bytes_per_room_record": bpr}
+            bb.close()
+
     if rank == 0:
         total_steps = rooms * world * args.steps
         per_launch_units = rooms * (args.steps / max(launches, 1))
@@ -180,6 +200,7 @@ def main():
                          "note": "algorithmic bytes = 2 x record x rooms x turns in the launch; with fused turns the "
                                  "state stays in registers, so real HBM traffic is ~1/fuse of this (see traffic)"},
             "unfused": unfused,
+            "other_shapes": other,
             "summary": {k: summary[k] for k in ("rooms", "finished", "village_wins", "wolf_wins", "games_recycled", "checksum")},
             "summary_allgather_ms": summary_ms,
         }
