@@ -303,8 +303,12 @@ __device__ __forceinline__ void ww_turn(WW<NB> &s, DevRow &row, const DevRow *ro
             q = ok ? ((row.r3 >> (8 * b)) & 255u) : q;
         }
     }
-    s.det_v |= new_det_v;                                      // (the guard turn has no actions: both are 0)
-    s.det_w |= new_det_w;
+    {   // investigated_alignments[c] = team(c): an assignment, so a stale entry is replaced
+        // (the guard turn has no actions: both masks are 0)
+        const uint32_t seen = new_det_v | new_det_w;
+        s.det_v = (s.det_v & ~seen) | new_det_v;
+        s.det_w = (s.det_w & ~seen) | new_det_w;
+    }
     if (q == s.phase) return;
 
     // ---- RefereeNode (B): effect of entering q

@@ -51,3 +51,19 @@ def oracle_events(orc, rooms: np.ndarray, turn: int) -> np.ndarray:
     e["restarted"] = rooms["ev_restarted"]
     e["choice"] = rooms["ev_choice"]
     return e
+
+
+def views_as_oracle_rooms(orc, views: np.ndarray) -> np.ndarray:
+    """ROOM_VIEW_DTYPE array -> oracle ROOM_DTYPE array (inverse of oracle_rooms_as_views)."""
+    from oracle.oracle import ROOM_DTYPE
+    idx_of = {pid: i for i, pid in enumerate(orc.ids)}
+    r = np.zeros(len(views), dtype=ROOM_DTYPE)
+    r["phase"] = [idx_of[int(x)] for x in views["phase_id"]]
+    r["prev"] = [idx_of[int(x)] for x in views["prev_phase_id"]]
+    r["phase0_done"] = views["phase0_done"]
+    r["n"] = views["n_players"]
+    r["end_turn"] = views["end_turn"]
+    r["games"] = views["games"]
+    r["p"] = views["players"]
+    r["det"] = views["det"]
+    return r
