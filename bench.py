@@ -28,9 +28,18 @@ N_PLAYERS = 8
 GAME = "werewolf-(mafia)"
 SEED = 0xC0FFEE
 
+# BASELINE.json configs as per-GPU workloads: [(game, players, rooms per GPU)], rooms grouped by game.
+# c2 is the contract workload (default); the others are optional extra lines, same JSON format.
+WORKLOADS = {
+    "c2": [("werewolf-(mafia)", 8, 65536)],
+    "c3": [("two-truths-and-a-lie", 4, 1048576)],
+    "c4": [("werewolf-(mafia)", 12, 2097152)],                                   # 16 777 216 rooms over 8 GPUs
+    "c5": [("werewolf-(mafia)", 8, 524288), ("two-truths-and-a-lie", 4, 524288)],  # 50/50 mix, one launch
+}
 
-def load_dsl():
-    with open(os.path.join(ROOT, "tests", "golden", "dsl", f"{GAME}.json"), encoding="utf-8") as f:
+
+def load_dsl(game=GAME):
+    with open(os.path.join(ROOT, "tests", "golden", "dsl", f"{game}.json"), encoding="utf-8") as f:
         return json.load(f)
 
 
@@ -79,7 +88,8 @@ def main():
     ap.add_argument("--steps", type=int, default=4096)
     ap.add_argument("--warmup", type=int, default=256)
     ap.add_argument("--fuse", type=int, default=64, help="turns fused per launch (1 = one launch per turn)")
-    ap.add_argument("--rooms", type=int, default=ROOMS_PER_GPU, help="rooms per GPU")
+    ap.add_argument("--rooms", type=int, default=None, help="rooms per GPU (overrides the workload's count; c2 only)")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2", help="BASELINE.json config (default c2 = configs[1])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-unfused", action="store_true", help="skip the one-launch-per-turn reference point")
     ap.add_argument("--no-other-shapes", action="store_true", help="skip the informational larger shapes")
@@ -116,10 +126,16 @@ def main():
 
     dsl = load_dsl()
     table = GameTable(dsl)
-    rooms = args.rooms
-    batch = RoomBatch([(table, N_PLAYERS, rooms)], seed=SEED, first_room=shard_first_room(rooms, rank),
+    spec = [list(x) for x in WORKLOADS[args.workload]]
+    if args.rooms:
+        spec[0][2] = args.rooms
+    tables = {g: GameTable(load_dsl(g)) for g, _, _ in spec}
+    segments = [(tables[g], n, r) for g, n, r in spec]
+    rooms = sum(r for _, _, r in spec)
+    batch = RoomBatch(segments, seed=SEED, first_room=shard_first_room(rooms, rank),
                       device=device_index, max_fuse=args.fuse, restart=True)
-    bytes_per_room = batch.bytes_per_room(0)          # record size; B = 2x (read + written once per turn)
+    # algorithmic bytes per room-phase step: record read + written once (room-weighted mean over segments)
+    bytes_per_room = sum(batch.bytes_per_room(k) * r for k, (_, _, r) in enumerate(spec)) / rooms
     stream = torch.cuda.current_stream().cuda_stream
 
     batch.step(args.warmup, stream)                   # untimed; also brings the batch to steady state
@@ -148,7 +164,7 @@ def main():
     # un-fused reference point: one launch per turn, same workload, short
     unfused = None
     if rank == 0 and not args.no_unfused:
-        b1 = RoomBatch([(table, N_PLAYERS, rooms)], seed=SEED, device=device_index, max_fuse=1, restart=True)
+        b1 = RoomBatch(segments, seed=SEED, device=device_index, max_fuse=1, restart=True)
         b1.step(64, stream); b1.sync()
         b1.set_timing(True); b1.kernel_time(reset=True)
         t1 = time.perf_counter()
@@ -161,7 +177,7 @@ def main():
 
     # other BASELINE shapes on one GPU (device time, informational; `value` above is the contract number)
     other = None
-    if rank == 0 and world == 1 and not args.no_other_shapes:
+    if rank == 0 and world == 1 and not args.no_other_shapes and args.workload == "c2":
         other = {}
         tt_dsl = json.load(open(os.path.join(ROOT, "tests", "golden", "dsl", "two-truths-and-a-lie.json"), encoding="utf-8"))
         for label, tb, n, r in (("1048576 Werewolf x8", table, 8, 1 << 20),
@@ -189,9 +205,9 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-            "config": {"workload": f"{rooms} Werewolf rooms x {N_PLAYERS} players per GPU, games/werewolf-(mafia).yaml, "
-                                   "steady state (finished rooms recycled), fixed policy, seed 0xC0FFEE",
-                       "rooms_per_gpu": rooms, "n_players": N_PLAYERS, "turns_fused_per_launch": args.fuse,
+            "config": {"workload": args.workload + ": " + " + ".join(f"{r} {g} rooms x {n} players" for g, n, r in spec) +
+                                   " per GPU, steady state (finished rooms recycled), fixed policy, seed 0xC0FFEE",
+                       "rooms_per_gpu": rooms, "n_players": [n for _, n, _ in spec], "turns_fused_per_launch": args.fuse,
                        "bytes_per_room_record": bytes_per_room, "sharding": f"rooms x{world}, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(bytes_per_room),
@@ -204,7 +220,7 @@ def main():
             "summary": {k: summary[k] for k in ("rooms", "finished", "village_wins", "wolf_wins", "games_recycled", "checksum")},
             "summary_allgather_ms": summary_ms,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and args.workload == "c2":
             out["cpu_baseline"] = cpu_baseline(dsl)
         print(json.dumps(out))
     batch.close()
