@@ -25,14 +25,20 @@ CASES = [                                # (game, n_players, rooms, turns, round
     ("werewolf-(mafia)", 4, [0, 5], 48, 1),
     ("werewolf-(mafia)", 5, [0, 3], 48, 1),
     ("werewolf-(mafia)", 7, [2], 64, 1),
+    ("werewolf-(mafia)", 6, [8], 64, 1),
+    ("werewolf-(mafia)", 9, [11], 96, 1),
+    ("werewolf-(mafia)", 10, [3], 110, 1),
+    ("werewolf-(mafia)", 11, [6], 110, 1),
     ("two-truths-and-a-lie", 4, [0, 1, 2, 1048575], 64, 1),
     ("two-truths-and-a-lie", 3, [0, 9], 48, 1),
     ("two-truths-and-a-lie", 6, [4], 160, 2),
     ("two-truths-and-a-lie", 12, [1], 200, 1),
+    ("two-truths-and-a-lie", 5, [2], 260, 3),
+    ("two-truths-and-a-lie", 8, [7], 150, 1),
 ]
 
 
-def main():
+def main(only=None):
     os.makedirs(os.path.join(GOLD, "dsl"), exist_ok=True)
     for game in sorted({c[0] for c in CASES}):
         with open(os.path.join(REFERENCE_ROOT, "games", f"{game}.yaml"), encoding="utf-8") as f:
@@ -56,6 +62,8 @@ def main():
                 cases.append({"seed": seed, "room": room, "turns": traj})
                 print(game, n, hex(seed), room, "end_turn", traj[-1][3], file=sys.stderr)
         name = f"traj_{game.split('-(')[0].replace('-', '_')}_n{n}.json"
+        if only and name not in only:
+            continue
         with open(os.path.join(GOLD, name), "w") as f:
             json.dump({"game": game, "n_players": n, "rounds": rounds,
                        "source": "reference game_agent_v2 + v3 nodes under oracle/refharness FixedPolicy",
