@@ -57,3 +57,8 @@ export class RoomBatch {
 export function turnToolCalls(table: GameTable, before: RoomState, after: RoomState, event: TurnEvent): ToolCall[];
 export function loadDslByGamename(gamename: string, gamesDir?: string): object;
 export function deviceCount(): number;
+export function compileCriteria(expr: string): (player: Record<string, unknown>) => boolean;
+export function audienceGroups(dsl: object, playerStates: Record<string, Record<string, unknown>>): Record<string, string[]>;
+export interface FrontendToolCall { name: string; args: { audience_type?: boolean; audience_ids?: string[]; [k: string]: unknown }; }
+/** Frontend tool calls of the room's current phase (ActionExecutor / UIUpdateNode without an LLM). */
+export function uiToolCalls(dsl: object, room: RoomState): FrontendToolCall[];

@@ -189,4 +189,7 @@ class RoomBatch {
   }
 }
 
-module.exports = { GameTable, RoomBatch, loadDslByGamename, turnToolCalls, deviceCount: addon.deviceCount, addon };
+const { compileCriteria, audienceGroups, uiToolCalls } = require('./ui_script.js');
+
+module.exports = { GameTable, RoomBatch, loadDslByGamename, turnToolCalls, compileCriteria, audienceGroups, uiToolCalls,
+                   deviceCount: addon.deviceCount, addon };

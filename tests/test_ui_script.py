@@ -87,3 +87,25 @@ def test_ui_script_of_two_truths(dsl_tt):
             ps = st["player_states"]
             box = next(c for c in calls if c["name"] == "createTextInputPanel")
             assert box["args"]["audience_type"] is True or box["args"]["audience_ids"] == [p for p in ps if ps[p]["is_speaker"]]
+
+
+def test_js_ui_script_equals_python(dsl_ww, dsl_tt, tmp_path):
+    """The TypeScript host renders the same UI script (game_engine_amd/node/ui_script.js)."""
+    import json, os, shutil, subprocess
+    from conftest import ROOT
+    if shutil.which("node") is None:
+        pytest.skip("node is not available")
+    cases = []
+    for dsl, n in ((dsl_ww, 8), (dsl_tt, 4)):
+        for st in _room_states(dsl, n, 45):
+            cases.append({"dsl": dsl, "state": st, "want": ui_tool_calls(dsl, st)})
+    inp = tmp_path / "cases.json"
+    inp.write_text(json.dumps(cases))
+    js = ("const {uiToolCalls}=require(process.argv[1]);const c=JSON.parse(require('fs').readFileSync(process.argv[2],'utf8'));"
+          "let bad=0;c.forEach((x,i)=>{if(JSON.stringify(uiToolCalls(x.dsl,x.state))!==JSON.stringify(x.want)){bad++;console.error('case',i);}});"
+          "console.log(JSON.stringify({n:c.length,bad}));")
+    out = subprocess.run(["node", "-e", js, os.path.join(ROOT, "game_engine_amd", "node", "ui_script.js"), str(inp)],
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    r = json.loads(out.stdout.strip())
+    assert r["n"] == len(cases) and r["bad"] == 0, out.stderr[:500]
