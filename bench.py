@@ -163,7 +163,7 @@ def main():
 
     # un-fused reference point: one launch per turn, same workload, short
     unfused = None
-    if rank == 0 and not args.no_unfused:
+    if rank == 0 and world == 1 and not args.no_unfused:      # N=1 only: keeps multi-GPU runs symmetric
         b1 = RoomBatch(segments, seed=SEED, device=device_index, max_fuse=1, restart=True)
         b1.step(64, stream); b1.sync()
         b1.set_timing(True); b1.kernel_time(reset=True)
@@ -220,7 +220,7 @@ def main():
             "summary": {k: summary[k] for k in ("rooms", "finished", "village_wins", "wolf_wins", "games_recycled", "checksum")},
             "summary_allgather_ms": summary_ms,
         }
-        if not args.no_cpu_baseline and args.workload == "c2":
+        if not args.no_cpu_baseline and args.workload == "c2" and world == 1:   # rank 0 at N=1 only (contract)
             out["cpu_baseline"] = cpu_baseline(dsl)
         print(json.dumps(out))
     batch.close()
