@@ -175,6 +175,25 @@ def main():
                    "achieved_GBs": 2 * bytes_per_room * rooms / (k1 * 1e-3 / max(l1, 1)) / 1e9}
         b1.close()
 
+    # BASELINE.md §3 variant: S = 64 turns from the initial state (no recycling), 3 warm-ups, median of 10
+    from_init = None
+    if rank == 0 and world == 1 and args.workload == "c2":
+        bi = RoomBatch(segments, seed=SEED, device=device_index, max_fuse=args.fuse, restart=False)
+        times = []
+        for rep in range(13):
+            bi.reset()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            bi.step(64, stream); bi.sync()
+            if rep >= 3:
+                times.append(time.perf_counter() - t1)
+        times.sort()
+        med = times[len(times) // 2]
+        sm = bi.summary()
+        from_init = {"value": rooms * 64 / med, "unit": "room-phase steps/s (wall, all rooms, finished ones included)",
+                     "ms_per_64_turns": med * 1e3, "finished_after_64": sm["finished"], "rooms": rooms}
+        bi.close()
+
     # other BASELINE shapes on one GPU (device time, informational; `value` above is the contract number)
     other = None
     if rank == 0 and world == 1 and not args.no_other_shapes and args.workload == "c2":
@@ -216,6 +235,7 @@ def main():
                          "note": "algorithmic bytes = 2 x record x rooms x turns in the launch; with fused turns the "
                                  "state stays in registers, so real HBM traffic is ~1/fuse of this (see traffic)"},
             "unfused": unfused,
+            "from_init_64": from_init,
             "other_shapes": other,
             "summary": {k: summary[k] for k in ("rooms", "finished", "village_wins", "wolf_wins", "games_recycled", "checksum")},
             "summary_allgather_ms": summary_ms,
