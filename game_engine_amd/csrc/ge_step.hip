@@ -231,6 +231,12 @@ __device__ __forceinline__ uint64_t wave_sum(uint64_t v) {
     return v;
 }
 
+template <int WORDS> __device__ __forceinline__ uint32_t fold_words(uint32_t h, const uint32_t *w) {
+#pragma unroll
+    for (int j = 0; j < WORDS; j++) h = mix32(h ^ w[j]);
+    return h;
+}
+
 struct RoomStats { uint32_t finished, village, wolves, alive, end_turn, games; };
 
 template <int NB> __device__ __forceinline__ RoomStats stats_ww(const uint32_t *w, const DevRow *rows, uint32_t *hist_score) {
@@ -248,9 +254,10 @@ template <int NB> __device__ __forceinline__ RoomStats stats_tt(const uint32_t *
     RoomStats r;
     r.finished = ((rows[s.phase].r0 >> 11) & 7u) == 0u;
     r.village = 0; r.wolves = 0; r.alive = n; r.end_turn = s.end_turn; r.games = s.games;
-    for (uint32_t i = 0; i < n; i++) {
-        uint32_t sc = (s.score[i / 4] >> (8 * (i % 4))) & 255u;
-        atomicAdd(&hist_score[sc < 15 ? sc : 15], 1u);
+#pragma unroll
+    for (int i = 0; i < NB; i++) {                               // static indices: no scratch
+        const uint32_t sc = (s.score[i / 4] >> (8 * (i % 4))) & 255u;
+        if ((uint32_t)i < n) atomicAdd(&hist_score[sc < 15 ? sc : 15], 1u);
     }
     return r;
 }
@@ -274,17 +281,16 @@ __global__ void __launch_bounds__(256) ge_summary_kernel(const StepArgs a, const
     RoomStats r = {0, 0, 0, 0, END_NONE, 0};
     uint64_t ck = 0;
     if (room < sg.rooms) {
-        uint32_t w[12];
-        switch (sg.kind) {
-        case K_WW8: load_words<8>(sg.base, sg.rooms_padded, room, w); r = stats_ww<8>(w, rows, h_score); break;
-        case K_WW12: load_words<10>(sg.base, sg.rooms_padded, room, w); r = stats_ww<12>(w, rows, h_score); break;
-        case K_TT4: load_words<6>(sg.base, sg.rooms_padded, room, w); r = stats_tt<4>(w, rows, sg.n_players, h_score); break;
-        case K_TT8: load_words<8>(sg.base, sg.rooms_padded, room, w); r = stats_tt<8>(w, rows, sg.n_players, h_score); break;
-        default: load_words<12>(sg.base, sg.rooms_padded, room, w); r = stats_tt<12>(w, rows, sg.n_players, h_score); break;
-        }
         const uint64_t g = sg.first_global + room;
-        uint32_t h = mix32((uint32_t)g ^ mix32((uint32_t)(g >> 32) ^ 0xA5A5A5A5u));
-        for (uint32_t j = 0; j < sg.words; j++) h = mix32(h ^ w[j]);
+        const uint32_t h0 = mix32((uint32_t)g ^ mix32((uint32_t)(g >> 32) ^ 0xA5A5A5A5u));
+        uint32_t h = h0;
+        switch (sg.kind) {
+        case K_WW8: { uint32_t w[8]; load_words<8>(sg.base, sg.rooms_padded, room, w); r = stats_ww<8>(w, rows, h_score); h = fold_words<8>(h0, w); break; }
+        case K_WW12: { uint32_t w[10]; load_words<10>(sg.base, sg.rooms_padded, room, w); r = stats_ww<12>(w, rows, h_score); h = fold_words<10>(h0, w); break; }
+        case K_TT4: { uint32_t w[6]; load_words<6>(sg.base, sg.rooms_padded, room, w); r = stats_tt<4>(w, rows, sg.n_players, h_score); h = fold_words<6>(h0, w); break; }
+        case K_TT8: { uint32_t w[8]; load_words<8>(sg.base, sg.rooms_padded, room, w); r = stats_tt<8>(w, rows, sg.n_players, h_score); h = fold_words<8>(h0, w); break; }
+        default: { uint32_t w[12]; load_words<12>(sg.base, sg.rooms_padded, room, w); r = stats_tt<12>(w, rows, sg.n_players, h_score); h = fold_words<12>(h0, w); break; }
+        }
         ck = (uint64_t)h | ((uint64_t)mix32(h ^ 0x5BD1E995u) << 32);
         if (r.finished) atomicAdd(&h_end[(r.end_turn >> 3) < 15 ? (r.end_turn >> 3) : 15], 1u);
     }

@@ -93,6 +93,20 @@ def test_restart_mode_equals_oracle(game, n):
     assert s["games_recycled"] == int(want["games"].sum()) > R
 
 
+@pytest.mark.parametrize("game,n,n_rooms", [("werewolf-(mafia)", 8, 262144), ("werewolf-(mafia)", 12, 200000),
+                                            ("two-truths-and-a-lie", 4, 262144)])
+def test_high_occupancy_path_equals_oracle(game, n, n_rooms):
+    """Above ~196 608 rooms the launch switches to its many-wavefronts-per-SIMD code path (256-thread
+    blocks, predicated queue writes): compare it with the oracle too, steady state."""
+    dsl = load_dsl(game)
+    seed, turns = 0xC0FFEE, 96
+    with RoomBatch([(GameTable(dsl), n, n_rooms)], seed=seed, restart=True) as b:
+        b.step(turns)
+        got = b.read_rooms()
+    want = oracle_batch(_oracle(dsl, n), n_rooms, seed, 0, turns, restart=True)
+    assert_views_equal(got, want, f"{game} n={n} rooms={n_rooms}")
+
+
 def test_fused_equals_unfused_and_chunked(dsl_ww):
     tb = GameTable(dsl_ww)
     outs = []
