@@ -59,6 +59,12 @@ def load() -> C.CDLL:
     if _lib is not None:
         return _lib
     if not os.path.exists(LIB_PATH):
+        # a fresh checkout (built artefacts are not in git): compile once if hipcc is here
+        import shutil
+        import subprocess
+        if shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc"):
+            subprocess.run(["make", "-C", os.path.join(_HERE, "csrc"), "-s"], check=False)
+    if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `make -C game_engine_amd/csrc` "
             "(or __graft_entry__.build()).  game_engine_amd has no CPU fallback.")
