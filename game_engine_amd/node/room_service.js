@@ -1,0 +1,97 @@
+'use strict';
+/**
+ * RoomService — the single-room drop-in: one LangGraph thread (= one room) served by an N=1
+ * batch through the same C ABI as the big batches.
+ *
+ * In the reference, src/app/api/copilotkit/route.ts:22-47 binds each request's X-Thread-ID to a
+ * LangGraphAgent and every "Continue" / "Start game." message (src/app/page.tsx:2774, 2962) is one
+ * run of the Python graph.  `continueRoom(threadId)` is that run: it advances the room by one turn
+ * and returns what the graph returns to CopilotKit — the AgentState (agent/game_agent_v2.py:97-117)
+ * plus the AIMessage's tool calls: here the backend calls that describe the turn
+ * (turnToolCalls) and the frontend calls of the phase now showing (uiToolCalls).
+ * A handler that wants this instead of the LLM graph calls it in place of constructing the
+ * LangGraphAgent (route.ts:30-39); `serve()` exposes the same over plain HTTP for a quick try.
+ */
+const http = require('http');
+const { GameTable, RoomBatch, loadDslByGamename, turnToolCalls, uiToolCalls } = require('./index.js');
+
+/** stable 48-bit room index from a thread id (the RNG is keyed by it) */
+function roomIndexOf(threadId) {
+  let h = 0xcbf29ce484222325n;
+  for (const ch of Buffer.from(String(threadId), 'utf8')) { h ^= BigInt(ch); h = (h * 0x100000001b3n) & 0xffffffffffffffffn; }
+  return h & 0xffffffffffffn;
+}
+
+class RoomService {
+  constructor({ gamesDir = 'games', seed = 0n, device = 0 } = {}) {
+    this.gamesDir = gamesDir; this.seed = BigInt(seed); this.device = device;
+    this.tables = new Map();       // gameName -> GameTable
+    this.rooms = new Map();        // threadId -> { batch, table, state, phaseHistory, playerActions, gameNotes, names }
+  }
+  table(gameName, dsl) {
+    if (!this.tables.has(gameName)) this.tables.set(gameName, dsl ? new GameTable(dsl) : GameTable.fromGamename(gameName, this.gamesDir));
+    return this.tables.get(gameName);
+  }
+  /** roomSession.players as the lobby builds it (src/app/game-library/[game]/room/page.tsx:261-369). */
+  createRoom({ threadId, gameName, players, dsl }) {
+    const table = this.table(gameName, dsl);
+    const batch = new RoomBatch({ segments: [{ table, nPlayers: players.length, nRooms: 1 }], seed: this.seed,
+                                  firstRoom: roomIndexOf(threadId), device: this.device, maxFuse: 1, trace: true });
+    const room = { batch, table, gameName, names: players.map((p, i) => p.name || `Player ${i + 1}`),
+                   state: batch.readRoom(0), phaseHistory: [], playerActions: {}, gameNotes: [] };
+    this.rooms.set(threadId, room);
+    return this.agentState(room);
+  }
+  agentState(room) {
+    const s = room.state;
+    const ps = {};
+    Object.keys(s.player_states).forEach((pid, i) => { ps[pid] = { name: room.names[i], ...s.player_states[pid] }; });
+    return { gameName: room.gameName, current_phase_id: s.current_phase_id, current_phase_name: s.current_phase_name,
+             player_states: ps, playerActions: room.playerActions, phase_history: room.phaseHistory, game_notes: room.gameNotes };
+  }
+  /** One turn (one graph run).  Returns { state, toolCalls, uiCalls }. */
+  async continueRoom(threadId) {
+    const room = this.rooms.get(threadId);
+    if (!room) throw new Error(`unknown thread ${threadId}`);
+    const before = room.state;
+    await room.batch.step(1);
+    const after = room.batch.readRoom(0);
+    const event = room.batch.readEvents(0, 1)[0][0];
+    const toolCalls = turnToolCalls(room.table, before, after, event);
+    // fold the calls into the log-shaped parts of AgentState the packed state does not carry
+    for (const c of toolCalls) {
+      if (c.name === 'update_player_actions') {                     // backend_tools.py:285-344
+        const pid = c.args.player_id;
+        const rec = room.playerActions[pid] || (room.playerActions[pid] = { name: room.names[Number(pid) - 1], actions: {} });
+        const id = String(Object.keys(rec.actions).length + 1);
+        rec.actions[id] = { action: c.args.actions, timestamp: Date.now(), phase: c.args.phase, id };
+      } else if (c.name === 'add_game_note') {                      // backend_tools.py:163-202
+        room.gameNotes.push(`${c.args.note_type === 'CRITICAL' ? '🔴' : '⏳'} ${c.args.note_type}: ${c.args.content}`);
+      }
+    }
+    room.phaseHistory.push({ phase_id: after.current_phase_id, phase_name: after.current_phase_name });   // v2:1207-1215
+    room.state = after;
+    const state = this.agentState(room);
+    return { state, toolCalls, uiCalls: uiToolCalls(room.table.dsl, after) };
+  }
+  serve(port = 8124) {
+    const server = http.createServer((req, res) => {
+      let body = '';
+      req.on('data', (d) => { body += d; });
+      req.on('end', async () => {
+        try {
+          const msg = body ? JSON.parse(body) : {};
+          let out;
+          if (req.method === 'POST' && req.url === '/rooms') out = this.createRoom(msg);
+          else if (req.method === 'POST' && req.url === '/continue') out = await this.continueRoom(msg.threadId);
+          else { res.writeHead(404); res.end(); return; }
+          res.writeHead(200, { 'content-type': 'application/json' });
+          res.end(JSON.stringify(out));
+        } catch (e) { res.writeHead(400); res.end(JSON.stringify({ error: String(e.message || e) })); }
+      });
+    });
+    return new Promise((resolve) => server.listen(port, '127.0.0.1', () => resolve(server)));
+  }
+}
+
+module.exports = { RoomService, roomIndexOf };

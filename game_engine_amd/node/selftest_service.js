@@ -1,0 +1,36 @@
+'use strict';
+// node selftest_service.js <dsl.json>  — GPU: drives one room through RoomService over HTTP (tests/test_node_host.py)
+const fs = require('fs');
+const http = require('http');
+const { RoomService, roomIndexOf } = require('./room_service.js');
+const dsl = JSON.parse(fs.readFileSync(process.argv[2], 'utf8'));
+
+function post(port, path, obj) {
+  return new Promise((resolve, reject) => {
+    const req = http.request({ host: '127.0.0.1', port, path, method: 'POST', headers: { 'content-type': 'application/json' } }, (res) => {
+      let b = ''; res.on('data', (d) => { b += d; }); res.on('end', () => resolve(JSON.parse(b)));
+    });
+    req.on('error', reject); req.end(JSON.stringify(obj));
+  });
+}
+
+(async () => {
+  const svc = new RoomService({ seed: 7n });
+  const server = await svc.serve(0);
+  const port = server.address().port;
+  const players = Array.from({ length: 8 }, (_, i) => ({ name: `Bot ${i + 1}`, gamePlayerId: i + 1 }));
+  const first = await post(port, '/rooms', { threadId: 'room-abc', gameName: 'werewolf-(mafia)', players, dsl });
+  const phases = [first.current_phase_id];
+  let last = null, notes = 0, acts = 0, ui = 0;
+  for (let t = 0; t < 70; t++) {
+    last = await post(port, '/continue', { threadId: 'room-abc' });
+    phases.push(last.state.current_phase_id);
+    ui += last.uiCalls.length;
+  }
+  notes = last.state.game_notes.length;
+  acts = Object.values(last.state.playerActions).reduce((a, r) => a + Object.keys(r.actions).length, 0);
+  server.close();
+  console.log(JSON.stringify({ room: roomIndexOf('room-abc').toString(), phases, notes, acts, ui,
+                               name1: last.state.player_states['1'].name, finalPhase: last.state.current_phase_name,
+                               alive: Object.values(last.state.player_states).map((p) => p.is_alive ? 1 : 0) }));
+})().catch((e) => { console.error(e); process.exit(1); });

@@ -51,3 +51,26 @@ def test_node_host_matches_golden(dsl, gold):
             want = turn_tool_calls(tb, before, after, b.read_events(0, 1)[0][0])
             assert r["calls"][t] == json.loads(json.dumps(want)), t
             before = after
+
+
+@needs_node
+@pytest.mark.gpu
+def test_single_room_service_over_http():
+    """One LangGraph thread served by an N=1 traced batch (RoomService): the trajectory equals the
+    Python host's for the same seed / room index, and the log-shaped AgentState parts fill up."""
+    from conftest import load_dsl
+    from game_engine_amd import GameTable, RoomBatch
+    out = subprocess.run(["node", os.path.join(NODE_DIR, "selftest_service.js"), os.path.join(GOLD, "dsl", "werewolf-(mafia).json")],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    r = json.loads(out.stdout.strip().splitlines()[-1])
+    tb = GameTable(load_dsl("werewolf-(mafia)"))
+    with RoomBatch([(tb, 8, 1)], seed=7, first_room=int(r["room"]), max_fuse=1) as b:
+        phases = [0]
+        for t in range(70):
+            b.step(1)
+            phases.append(int(b.read_rooms(0, 1)[0]["phase_id"]))
+        alive = [int(x) for x in b.read_rooms(0, 1)[0]["players"][:8, 2]]
+    assert r["phases"] == phases and r["alive"] == alive and phases[-1] == 99
+    assert r["name1"] == "Bot 1" and r["finalPhase"].startswith("Game Over")
+    assert r["notes"] > 10 and r["acts"] > 10 and r["ui"] > 100
