@@ -93,6 +93,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-unfused", action="store_true", help="skip the one-launch-per-turn reference point")
     ap.add_argument("--no-other-shapes", action="store_true", help="skip the informational larger shapes")
+    ap.add_argument("--no-from-init", action="store_true", help="skip the S=64-from-initial-state variant")
     args = ap.parse_args()
 
     import torch
@@ -177,7 +178,7 @@ def main():
 
     # BASELINE.md §3 variant: S = 64 turns from the initial state (no recycling), 3 warm-ups, median of 10
     from_init = None
-    if rank == 0 and world == 1 and args.workload == "c2":
+    if rank == 0 and world == 1 and args.workload == "c2" and not args.no_from_init:
         bi = RoomBatch(segments, seed=SEED, device=device_index, max_fuse=args.fuse, restart=False)
         times = []
         for rep in range(13):
