@@ -191,7 +191,10 @@ def main():
         times.sort()
         med = times[len(times) // 2]
         sm = bi.summary()
+        et = bi.read_rooms()["end_turn"]
+        live_steps = int(((et >= 0) * (et + 1) + (et < 0) * 64).sum())      # turns a room took before it finished
         from_init = {"value": rooms * 64 / med, "unit": "room-phase steps/s (wall, all rooms, finished ones included)",
+                     "live_value": live_steps / med, "live_unit": "room-phase steps/s counting only rooms still in play",
                      "ms_per_64_turns": med * 1e3, "finished_after_64": sm["finished"], "rooms": rooms}
         bi.close()
 
