@@ -96,6 +96,12 @@ def main():
     ap.add_argument("--no-from-init", action="store_true", help="skip the S=64-from-initial-state variant")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line (the JSON): everything else any library prints there — RCCL
+    # writes a version banner to stdout at communicator creation — is diverted to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     from game_engine_amd import GameTable, RoomBatch
@@ -112,8 +118,12 @@ def main():
     device_index = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(device_index)
     coll_device = torch.device("cuda", device_index) if backend == "nccl" else torch.device("cpu")
-    if world > 1:
+    use_dist = world > 1 or bool(os.environ.get("GE_FORCE_DIST"))      # GE_FORCE_DIST: rehearse RCCL with one rank
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
         else:
@@ -121,7 +131,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -152,13 +162,13 @@ def main():
     batch.set_timing(False)
 
     t_el = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
     elapsed = float(t_el.item())
 
     # the one collective of the path: all-gather of the per-GPU summary (RCCL over xGMI)
     ts = time.perf_counter()
-    summary = allgather_summary(batch, world)
+    summary = allgather_summary(batch, world, force=use_dist)
     barrier()
     summary_ms = (time.perf_counter() - ts) * 1e3
 
@@ -246,9 +256,9 @@ def main():
         }
         if not args.no_cpu_baseline and args.workload == "c2" and world == 1:   # rank 0 at N=1 only (contract)
             out["cpu_baseline"] = cpu_baseline(dsl)
-        print(json.dumps(out))
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     batch.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -37,10 +37,11 @@ def reduce_summaries(words: np.ndarray) -> np.ndarray:
     return out
 
 
-def allgather_summary_words(local_words: np.ndarray, world: int, device=None) -> np.ndarray:
-    """All-gather of one rank's summary words; returns [world, SUMMARY_WORDS]."""
+def allgather_summary_words(local_words: np.ndarray, world: int, device=None, force: bool = False) -> np.ndarray:
+    """All-gather of one rank's summary words; returns [world, SUMMARY_WORDS].
+    `force`: run the collective even for a single rank (rehearsal of the RCCL path)."""
     local_words = np.asarray(local_words, dtype=np.uint64)
-    if world == 1:
+    if world == 1 and not force:
         return local_words.reshape(1, -1)
     import torch
     import torch.distributed as dist
@@ -53,14 +54,14 @@ def allgather_summary_words(local_words: np.ndarray, world: int, device=None) ->
     return out.cpu().numpy().view(np.uint64).reshape(world, SUMMARY_WORDS)
 
 
-def allgather_summary(batch, world: int) -> Dict[str, Any]:
+def allgather_summary(batch, world: int, force: bool = False) -> Dict[str, Any]:
     """Whole-job summary on every rank: device-side reduction of this rank's rooms, then the
     single all-gather of the path."""
     device = None
-    if world > 1:
+    if world > 1 or force:
         import torch
         import torch.distributed as dist
         if dist.get_backend() == "nccl":
             device = torch.device("cuda", torch.cuda.current_device())
-    gathered = allgather_summary_words(batch.summary_words(), world, device)
+    gathered = allgather_summary_words(batch.summary_words(), world, device, force)
     return summary_to_dict(reduce_summaries(gathered))
