@@ -26,7 +26,7 @@ class Table(C.Structure):
 
 
 class SegmentDesc(C.Structure):
-    _fields_ = [("table", C.POINTER(Table)), ("n_players", C.c_uint32), ("reserved", C.c_uint32),
+    _fields_ = [("table", C.POINTER(Table)), ("n_players", C.c_uint32), ("human_mask", C.c_uint32),
                 ("n_rooms", C.c_uint64)]
 
 
@@ -47,7 +47,7 @@ SUMMARY_WORDS = C.sizeof(Summary) // 8
 
 # every symbol include/ge_step.h declares (tests/test_abi.py checks the library exports them all)
 SYMBOLS = ["ge_table_compile_json", "ge_batch_create", "ge_batch_step", "ge_batch_reset", "ge_batch_sync", "ge_batch_turn",
-           "ge_batch_n_rooms", "ge_batch_read_rooms", "ge_batch_write_rooms", "ge_batch_read_events", "ge_batch_summary",
+           "ge_batch_n_rooms", "ge_batch_read_rooms", "ge_batch_write_rooms", "ge_batch_read_events", "ge_batch_inject_action", "ge_batch_summary",
            "ge_batch_state", "ge_batch_set_timing", "ge_batch_kernel_time", "ge_batch_destroy",
            "ge_strerror", "ge_last_hip_error", "ge_abi_version", "ge_device_count"]
 
@@ -80,6 +80,7 @@ def load() -> C.CDLL:
     lib.ge_batch_read_rooms.argtypes = [vp, u64, u64, vp, C.c_size_t]
     lib.ge_batch_write_rooms.argtypes = [vp, u64, u64, vp]
     lib.ge_batch_read_events.argtypes = [vp, u64, u64, C.POINTER(u32), vp, C.c_size_t]
+    lib.ge_batch_inject_action.argtypes = [vp, u64, u32, u32]
     lib.ge_batch_summary.argtypes = [vp, C.POINTER(Summary)]
     lib.ge_batch_state.argtypes = [vp, u32, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(u32)]
     lib.ge_batch_set_timing.argtypes = [vp, C.c_int]

@@ -132,7 +132,8 @@ __device__ __forceinline__ uint64_t nib_nonzero(uint64_t x) {
 template <int NB, bool QUEUE>
 __device__ __forceinline__ void ww_turn(WW<NB> &s, DevRow &row, const DevRow *rows, WaveLds *lw, bool valid, uint32_t n,
                                         uint32_t nw, uint32_t phase0_idx, uint32_t rkey, uint32_t turn,
-                                        bool trace, bool lowocc, uint32_t &ev_newly, uint64_t &ev_choice) {
+                                        bool trace, bool lowocc, uint32_t human, uint32_t &ev_newly, uint64_t &ev_choice) {
+    // human: players the host drives (never acted for here)
     // ev_*: this turn's logged actions (who acted, what they chose) for the optional event trace
     // `row` is the table row of s.phase, kept in registers across turns: LDS is read only on a transition
     using nib_t = typename WW<NB>::nib_t;
@@ -181,7 +182,7 @@ __device__ __forceinline__ void ww_turn(WW<NB> &s, DevRow &row, const DevRow *ro
     // ---- BotBehaviorNode: every due bot acts with probability 3/4, one action per visit
     uint32_t newly = 0, new_det_v = 0, new_det_w = 0;
     {
-        uint32_t todo = valid ? (T & ~s.acted) : 0u;
+        uint32_t todo = valid ? (T & ~s.acted & ~human) : 0u;
         const uint32_t known = s.det_v | s.det_w;
         const uint32_t kw_alive = s.det_w & s.alive;
         const uint32_t lo_kw = kw_alive & (0u - kw_alive);       // lowest known living werewolf
@@ -354,7 +355,7 @@ __device__ __forceinline__ void ww_turn(WW<NB> &s, DevRow &row, const DevRow *ro
 template <int NB>
 __device__ __forceinline__ void tt_turn(TT<NB> &s, DevRow &row, const DevRow *rows, bool valid, uint32_t n, uint32_t rounds,
                                         uint32_t phase0_idx, uint32_t rkey, uint32_t turn,
-                                        bool trace, uint32_t &ev_newly, uint64_t &ev_choice) {
+                                        bool trace, uint32_t human, uint32_t &ev_newly, uint64_t &ev_choice) {
     const uint32_t ALL = (1u << n) - 1u;
     const uint32_t comp = row.r0 & 3u, act = (row.r0 >> 2) & 7u, p_eff = (row.r0 >> 5) & 7u;
     const uint32_t nterms = (row.r0 >> 8) & 7u, nbr = (row.r0 >> 11) & 7u;
@@ -379,7 +380,7 @@ __device__ __forceinline__ void tt_turn(TT<NB> &s, DevRow &row, const DevRow *ro
 
     uint32_t newly = 0;
     {
-        uint32_t todo = T & ~s.acted;
+        uint32_t todo = T & ~s.acted & ~human;
         const bool a_stm = act == ACT_TT_STATEMENTS, a_lie = act == ACT_TT_LIE, a_vote = act == ACT_TT_VOTE;
         while (todo) {
             const uint32_t i = ctz(todo);

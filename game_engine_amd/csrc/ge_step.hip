@@ -35,6 +35,7 @@ struct SegDev {
     uint64_t first_global;     // global index of the segment's room 0
     uint32_t kind, n_players, nw, rounds;
     uint32_t phase0_idx, block_begin, table_idx, words;
+    uint32_t human_mask, pad0;
     uint32_t init_words[12];   // the initial record (player_states_template, phase 0)
     uint32_t *trace;           // GE_FLAG_TRACE: [turn in launch][rooms_padded] x 4 words, else null
 };
@@ -124,7 +125,7 @@ __device__ __forceinline__ void run_ww(const SegDev *__restrict__ sgp, const Ste
         uint32_t ev_newly = 0;
         uint64_t ev_choice = 0;
         ww_turn<NB, GE_WAVE_QUEUE>(s, row, rows, lw, valid, sg.n_players, sg.nw, sg.phase0_idx, rk, a.turn0 + t,
-                                   a.trace != 0u, a.lowocc != 0u, ev_newly, ev_choice);
+                                   a.trace != 0u, a.lowocc != 0u, sg.human_mask, ev_newly, ev_choice);
         if (a.trace && valid) store_event(sg.trace, sg.rooms_padded, t, room, a.turn0 + t, p, s.phase, restarted, ev_newly, ev_choice);
     }
     if (!valid) return;
@@ -162,7 +163,7 @@ __device__ __forceinline__ void run_tt(const SegDev *__restrict__ sgp, const Ste
         const uint32_t p = s.phase;
         uint32_t ev_newly = 0;
         uint64_t ev_choice = 0;
-        tt_turn<NB>(s, row, rows, valid, sg.n_players, sg.rounds, sg.phase0_idx, rk, a.turn0 + t, a.trace != 0u, ev_newly, ev_choice);
+        tt_turn<NB>(s, row, rows, valid, sg.n_players, sg.rounds, sg.phase0_idx, rk, a.turn0 + t, a.trace != 0u, sg.human_mask, ev_newly, ev_choice);
         if (a.trace && valid) store_event(sg.trace, sg.rooms_padded, t, room, a.turn0 + t, p, s.phase, restarted, ev_newly, ev_choice);
     }
     if (!valid) return;
@@ -562,6 +563,7 @@ int ge_batch_create(const ge_batch_desc *desc, ge_batch **out) {
         d.rooms_padded = (sd.n_rooms + 255u) & ~uint64_t(255);
         d.first_global = global;
         d.n_players = n; d.nw = n / 4 > 1 ? n / 4 : 1; d.rounds = (uint32_t)s.table.rounds;
+        d.human_mask = sd.human_mask & ((1u << n) - 1u);
         d.phase0_idx = 255;
         for (int r = 0; r < s.table.n_phases; r++)
             if (s.table.rows[r].phase_id == 0) d.phase0_idx = (uint32_t)r;
@@ -781,6 +783,53 @@ int ge_batch_read_rooms(ge_batch *b, uint64_t first, uint64_t count, ge_room_vie
 int ge_batch_write_rooms(ge_batch *b, uint64_t first, uint64_t count, const ge_room_view *src) {
     if (!b || (!src && count)) return GE_ERR_ARG;
     return rooms_io(b, first, count, nullptr, src);
+}
+
+int ge_batch_inject_action(ge_batch *b, uint64_t room, uint32_t player_id, uint32_t choice) {
+    if (!b || room >= b->n_rooms) return GE_ERR_ARG;
+    ge_room_view v;
+    int st = ge_batch_read_rooms(b, room, 1, &v, sizeof v);
+    if (st != GE_OK) return st;
+    const Segment *seg = nullptr;
+    for (const Segment &s : b->segs)
+        if (room >= s.local_first && room < s.local_first + s.dev.rooms) seg = &s;
+    const ge_game_table &tb = seg->table;
+    const int n = v.n_players;
+    if (player_id < 1 || (int)player_id > n) return GE_ERR_ARG;
+    const ge_phase_row *row = nullptr;
+    for (int k = 0; k < tb.n_phases; k++)
+        if (tb.rows[k].phase_id == v.phase_id) row = &tb.rows[k];
+    if (!row || row->completion != GE_COMP_ACTION) return GE_ERR_ARG;
+    uint8_t *f = v.players[player_id - 1];
+    const bool ww = tb.pack == GE_PACK_WEREWOLF;
+    // the player must be a target of the phase (condition AND alive) and not have acted in this visit
+    auto base_true = [&](int base) -> bool {
+        if (ww) {
+            switch (base) {
+            case 0: return f[2]; case 1: return f[4]; case 2: return f[3]; case 3: return f[5]; case 4: return f[6];
+            case 5: return f[7]; case 6: return f[1] == 1; case 7: return f[1] == 2; default: return f[0] == base - 7;
+            }
+        }
+        switch (base) { case 0: return f[0]; case 1: return f[1]; case 2: return f[3]; case 3: return f[4]; default: return f[6]; }
+    };
+    if (ww && !f[2]) return GE_ERR_ARG;
+    for (int t = 0; t < row->n_terms; t++)
+        if (base_true(row->term_base[t]) == (row->term_neg[t] != 0)) return GE_ERR_ARG;
+    if (f[9]) return GE_ERR_ARG;
+    if (ww) {
+        if (choice < 1 || (int)choice > n || !v.players[choice - 1][2]) return GE_ERR_ARG;     // targets must be alive
+    } else if (row->act == GE_ACT_TT_STATEMENTS ? choice != 1 : (choice < 1 || choice > 3)) return GE_ERR_ARG;
+    f[9] = 1; f[10] = (uint8_t)choice;
+    switch (row->act) {                                   // Referee (A), POLICY.md §3 "record"
+    case GE_ACT_DETECTIVE: v.det[choice - 1] = v.players[choice - 1][1] == 2 ? 2 : 1; /* fallthrough */
+    case GE_ACT_WOLF_TARGET:
+    case GE_ACT_DOCTOR_PROTECT: f[7] = 1; f[8] = (uint8_t)choice; break;
+    case GE_ACT_TT_STATEMENTS: f[1] = 1; break;
+    case GE_ACT_TT_LIE: f[2] = (uint8_t)choice; break;
+    case GE_ACT_TT_VOTE: f[5] = (uint8_t)choice; f[6] = 1; break;
+    default: break;
+    }
+    return ge_batch_write_rooms(b, room, 1, &v);
 }
 
 int ge_batch_read_events(ge_batch *b, uint64_t first, uint64_t count, uint32_t *n_turns, ge_turn_event *dst, size_t cap_bytes) {

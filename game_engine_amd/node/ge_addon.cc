@@ -147,14 +147,15 @@ napi_value CreateBatch(napi_env env, napi_callback_info info) {
     d.n_segments = n;
     for (uint32_t k = 0; k < n; k++) {
         napi_value sg, tv;
-        uint64_t np = 0, nr = 0;
+        uint64_t np = 0, nr = 0, hm = 0;
         ge_game_table *t = nullptr;
         if (napi_get_element(env, segs, k, &sg) != napi_ok ||
             napi_get_named_property(env, sg, "table", &tv) != napi_ok ||
             napi_get_value_external(env, tv, reinterpret_cast<void **>(&t)) != napi_ok || !t ||
-            !get_prop_u64(env, sg, "nPlayers", &np, 0) || !get_prop_u64(env, sg, "nRooms", &nr, 0))
+            !get_prop_u64(env, sg, "nPlayers", &np, 0) || !get_prop_u64(env, sg, "nRooms", &nr, 0) ||
+            !get_prop_u64(env, sg, "humanMask", &hm, 0))
             return throw_status(env, GE_ERR_ARG, "createBatch", "segment");
-        d.seg[k].table = t; d.seg[k].n_players = (uint32_t)np; d.seg[k].n_rooms = nr;
+        d.seg[k].table = t; d.seg[k].n_players = (uint32_t)np; d.seg[k].n_rooms = nr; d.seg[k].human_mask = (uint32_t)hm;
     }
     ge_batch *b = nullptr;
     int st = ge_batch_create(&d, &b);
@@ -255,6 +256,20 @@ napi_value ReadRooms(napi_env env, napi_callback_info info) {
     return buf;
 }
 
+// injectAction(batch, room, playerId, choice): throws GE-1 if the action is not allowed
+napi_value InjectAction(napi_env env, napi_callback_info info) {
+    size_t argc = 4;
+    napi_value argv[4];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    ge_batch *b = argc >= 1 ? batch_arg(env, argv[0]) : nullptr;
+    uint64_t room = 0, player = 0, choice = 0;
+    if (!b || argc < 4 || !get_u64(env, argv[1], &room) || !get_u64(env, argv[2], &player) || !get_u64(env, argv[3], &choice))
+        return throw_status(env, GE_ERR_ARG, "injectAction");
+    int st = ge_batch_inject_action(b, room, (uint32_t)player, (uint32_t)choice);
+    if (st != GE_OK) return throw_status(env, st, "injectAction");
+    return nullptr;
+}
+
 // readEvents(batch, first, count): { nTurns, buffer: ArrayBuffer of count*nTurns ge_turn_event }
 napi_value ReadEvents(napi_env env, napi_callback_info info) {
     size_t argc = 3;
@@ -326,6 +341,7 @@ napi_value Init(napi_env env, napi_value exports) {
         {"step", nullptr, Step, nullptr, nullptr, nullptr, napi_default, nullptr},
         {"stepSync", nullptr, StepSync, nullptr, nullptr, nullptr, napi_default, nullptr},
         {"readRooms", nullptr, ReadRooms, nullptr, nullptr, nullptr, napi_default, nullptr},
+        {"injectAction", nullptr, InjectAction, nullptr, nullptr, nullptr, napi_default, nullptr},
         {"readEvents", nullptr, ReadEvents, nullptr, nullptr, nullptr, napi_default, nullptr},
         {"summary", nullptr, Summary, nullptr, nullptr, nullptr, napi_default, nullptr},
         {"reset", nullptr, Reset, nullptr, nullptr, nullptr, napi_default, nullptr},

@@ -38,7 +38,7 @@ export class GameTable {
   readonly info: { pack: number; rounds: number; minPlayers: number; roleNames: string[]; phases: PhaseInfo[] };
   phaseName(id: number): string;
 }
-export interface Segment { table: GameTable; nPlayers: number; nRooms: number; }
+export interface Segment { table: GameTable; nPlayers: number; nRooms: number; /** bit i: player i+1 is driven by the host (a human) */ humanMask?: number; }
 export interface BatchOptions {
   segments: Segment[]; seed?: bigint | number; firstRoom?: bigint | number; device?: number;
   maxFuse?: number; restart?: boolean; trace?: boolean;
@@ -49,6 +49,7 @@ export class RoomBatch {
   step(nTurns?: number): Promise<number>;
   stepSync(nTurns?: number): number;
   reset(): void;
+  injectAction(room: number, playerId: number, choice: number): void;
   readRoom(room: number): RoomState;
   readRooms(first: number, count: number): RoomState[];
   readEvents(first: number, count: number): TurnEvent[][];

@@ -142,7 +142,7 @@ class RoomBatch {
     this.segments = segments;
     this.handle = addon.createBatch({
       seed, firstRoom, device, maxFuse, restart, trace,
-      segments: segments.map((s) => ({ table: s.table.handle, nPlayers: s.nPlayers, nRooms: s.nRooms })),
+      segments: segments.map((s) => ({ table: s.table.handle, nPlayers: s.nPlayers, nRooms: s.nRooms, humanMask: s.humanMask || 0 })),
     });
     this.nRooms = segments.reduce((a, s) => a + s.nRooms, 0);
   }
@@ -150,6 +150,8 @@ class RoomBatch {
   step(nTurns = 1) { return addon.step(this.handle, nTurns); }
   stepSync(nTurns = 1) { return addon.stepSync(this.handle, nTurns); }
   reset() { addon.reset(this.handle); }
+  /** Log an action of a host-driven (human) player in the room's current phase (segment.humanMask). */
+  injectAction(room, playerId, choice) { addon.injectAction(this.handle, room, playerId, choice); }
   tableOf(room) {
     let base = 0;
     for (const s of this.segments) { if (room < base + s.nRooms) return s.table; base += s.nRooms; }

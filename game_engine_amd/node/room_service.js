@@ -33,9 +33,11 @@ class RoomService {
     return this.tables.get(gameName);
   }
   /** roomSession.players as the lobby builds it (src/app/game-library/[game]/room/page.tsx:261-369). */
+  /** players[i].isBot === false marks a human seat: the bot policy never acts for it (humanAction does). */
   createRoom({ threadId, gameName, players, dsl }) {
     const table = this.table(gameName, dsl);
-    const batch = new RoomBatch({ segments: [{ table, nPlayers: players.length, nRooms: 1 }], seed: this.seed,
+    const humanMask = players.reduce((m, p, i) => (p.isBot === false ? m | (1 << i) : m), 0);
+    const batch = new RoomBatch({ segments: [{ table, nPlayers: players.length, nRooms: 1, humanMask }], seed: this.seed,
                                   firstRoom: roomIndexOf(threadId), device: this.device, maxFuse: 1, trace: true });
     const room = { batch, table, gameName, names: players.map((p, i) => p.name || `Player ${i + 1}`),
                    state: batch.readRoom(0), phaseHistory: [], playerActions: {}, gameNotes: [] };
@@ -48,6 +50,14 @@ class RoomService {
     Object.keys(s.player_states).forEach((pid, i) => { ps[pid] = { name: room.names[i], ...s.player_states[pid] }; });
     return { gameName: room.gameName, current_phase_id: s.current_phase_id, current_phase_name: s.current_phase_name,
              player_states: ps, playerActions: room.playerActions, phase_history: room.phaseHistory, game_notes: room.gameNotes };
+  }
+  /** A human's vote / choice (the frontend's "Player X voted ..." message, src/app/page.tsx:302-305). */
+  humanAction(threadId, playerId, choice) {
+    const room = this.rooms.get(threadId);
+    if (!room) throw new Error(`unknown thread ${threadId}`);
+    room.batch.injectAction(0, playerId, choice);
+    room.state = room.batch.readRoom(0);
+    return this.agentState(room);
   }
   /** One turn (one graph run).  Returns { state, toolCalls, uiCalls }. */
   async continueRoom(threadId) {
@@ -84,6 +94,7 @@ class RoomService {
           let out;
           if (req.method === 'POST' && req.url === '/rooms') out = this.createRoom(msg);
           else if (req.method === 'POST' && req.url === '/continue') out = await this.continueRoom(msg.threadId);
+          else if (req.method === 'POST' && req.url === '/action') out = this.humanAction(msg.threadId, msg.playerId, msg.choice);
           else { res.writeHead(404); res.end(); return; }
           res.writeHead(200, { 'content-type': 'application/json' });
           res.end(JSON.stringify(out));

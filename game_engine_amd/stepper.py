@@ -114,7 +114,7 @@ class GameTable:
         return self.c.role_names[cls_idx].value.decode("utf-8", "replace")
 
 
-Segment = Tuple[GameTable, int, int]      # (table, n_players, n_rooms)
+Segment = Tuple                            # (table, n_players, n_rooms[, human_mask])
 
 
 class RoomBatch:
@@ -130,9 +130,11 @@ class RoomBatch:
         d = _lib.BatchDesc()
         d.seed, d.first_room, d.n_segments, d.device, d.max_fuse = seed, first_room, len(segments), device, max_fuse
         d.flags = (1 if restart else 0) | (2 if trace else 0)
-        for k, (tb, n_players, n_rooms) in enumerate(segments):
+        for k, seg in enumerate(segments):
+            tb, n_players, n_rooms = seg[:3]
             d.seg[k].table = C.pointer(tb.c)
             d.seg[k].n_players, d.seg[k].n_rooms = n_players, n_rooms
+            d.seg[k].human_mask = seg[3] if len(seg) > 3 else 0      # bit i: player i+1 is host-driven
         h = C.c_void_p()
         _check(lib.ge_batch_create(C.byref(d), C.byref(h)), "ge_batch_create")
         self._h = h
@@ -187,6 +189,10 @@ class RoomBatch:
         assert views.dtype == ROOM_VIEW_DTYPE and views.flags.c_contiguous
         _check(self._lib.ge_batch_write_rooms(self._h, first, len(views), views.ctypes.data), "ge_batch_write_rooms")
 
+    def inject_action(self, room: int, player_id: int, choice: int):
+        """Log an action of a host-driven (human) player in the room's current phase."""
+        _check(self._lib.ge_batch_inject_action(self._h, room, player_id, choice), "ge_batch_inject_action")
+
     def read_events(self, first: int = 0, count: Optional[int] = None) -> np.ndarray:
         """[count, n_turns] events of the most recent step() call (batch created with trace=True)."""
         count = self.n_rooms - first if count is None else count
@@ -218,7 +224,8 @@ class RoomBatch:
 
     def _segment_of(self, room: int) -> Tuple[GameTable, int]:
         base = 0
-        for tb, n, rooms in self.segments:
+        for seg in self.segments:
+            tb, n, rooms = seg[:3]
             if room < base + rooms:
                 return tb, n
             base += rooms

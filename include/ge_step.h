@@ -134,7 +134,10 @@ typedef struct ge_turn_event {
 typedef struct ge_segment_desc {
     const ge_game_table *table;           /* copied at create; need not outlive the call */
     uint32_t n_players;                   /* werewolf 4..12, two-truths 3..12 */
-    uint32_t reserved;
+    uint32_t human_mask;                  /* bit i: player i+1 is driven by the host (a human), not by the bot
+                                             policy: BotBehaviorNode never acts for it (the reference excludes
+                                             player 1, bot_behavior_system_prompt.txt:3) and a phase waits for its
+                                             action (ge_batch_inject_action).  0 = all bots. */
     uint64_t n_rooms;
 } ge_segment_desc;
 
@@ -201,6 +204,14 @@ int ge_batch_read_rooms(ge_batch *b, uint64_t first, uint64_t count, ge_room_vie
 
 /* Overwrites rooms from canonical views (checkpoint restore, tests of hand-built states). */
 int ge_batch_write_rooms(ge_batch *b, uint64_t first, uint64_t count, const ge_room_view *src);
+
+/* Logs an action of a host-driven player between turns, exactly as if the player had acted in the
+ * room's current phase: the action joins this visit's log (acted / choice) and the Referee's record
+ * effect is applied (POLICY.md §3 "record").  What the reference does with a human's message at the
+ * start of the next graph run (agent/tools/utils.py:310-358 -> bt:285-344).  `choice` is a player id
+ * (werewolf) or a statement number (two-truths); GE_ERR_ARG if the player is not a target of the
+ * current phase, has already acted, or the choice is out of range.  Synchronises. */
+int ge_batch_inject_action(ge_batch *b, uint64_t room, uint32_t player_id, uint32_t choice);
 
 /* GE_FLAG_TRACE: events of the most recent ge_batch_step call, dst[(room - first) * *n_turns + t].
  * cap_bytes >= count * n_turns * sizeof(ge_turn_event).  Synchronises. */

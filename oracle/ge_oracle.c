@@ -142,7 +142,7 @@ void orc_room_init(const orc_table *tb, int n_players, orc_room *r) {
 }
 
 /* One turn = one graph run of the reference. */
-void orc_room_step(const orc_table *tb, orc_room *r, uint64_t seed, uint64_t room, uint32_t turn) {
+void orc_room_step(const orc_table *tb, orc_room *r, uint64_t seed, uint64_t room, uint32_t turn, uint32_t human_mask) {
     const int n = r->n;
     const int p = r->phase;
     const orc_phase *ph = &tb->ph[p];
@@ -166,6 +166,7 @@ void orc_room_step(const orc_table *tb, orc_room *r, uint64_t seed, uint64_t roo
         uint8_t choice[16] = {0};
         for (int i = 0; i < n; i++) {
             if (!is_target(tb, ph, r, i) || r->p[i][F_ACTED]) continue;
+            if ((human_mask >> i) & 1u) continue;      /* host-driven player: never acted for (bot_behavior prompt :3) */
             uint32_t d = draw(tk, (uint32_t)i);
             if ((d & 3u) == 0) continue;
             uint8_t cand[16];
@@ -343,7 +344,7 @@ void orc_room_step(const orc_table *tb, orc_room *r, uint64_t seed, uint64_t roo
 
 /* rooms[i] is room (first_room + i); turns first_turn .. first_turn+n_turns-1 */
 void orc_run(const orc_table *tb, uint64_t seed, uint64_t first_room, uint64_t n_rooms,
-             uint32_t first_turn, uint32_t n_turns, orc_room *rooms, int threads, int restart) {
+             uint32_t first_turn, uint32_t n_turns, orc_room *rooms, int threads, int restart, uint32_t human_mask) {
 #ifdef _OPENMP
     if (threads > 0) omp_set_num_threads(threads);
 #pragma omp parallel for schedule(static)
@@ -360,10 +361,36 @@ void orc_run(const orc_table *tb, uint64_t seed, uint64_t first_room, uint64_t n
                 orc_room_init(tb, r->n, r);
                 r->games = g;
             }
-            orc_room_step(tb, r, seed, first_room + (uint64_t)i, first_turn + t);
+            orc_room_step(tb, r, seed, first_room + (uint64_t)i, first_turn + t, human_mask);
             r->ev_restarted = (uint8_t)restarted;
         }
     (void)threads;
+}
+
+/* A host-driven player's action logged between turns: joins this visit's log and gets the
+ * Referee's record effect (POLICY.md §3), as the reference does with a human's message at the
+ * start of the next graph run (agent/tools/utils.py:310-358).  0 ok, -1 not allowed. */
+int orc_inject_action(const orc_table *tb, orc_room *r, int player_id, int choice) {
+    const orc_phase *ph = &tb->ph[r->phase];
+    const int n = r->n;
+    if (player_id < 1 || player_id > n || ph->completion != COMP_ACTION) return -1;
+    const int i = player_id - 1;
+    if (!is_target(tb, ph, r, i) || r->p[i][F_ACTED]) return -1;
+    if (tb->pack == PACK_WW) {
+        if (choice < 1 || choice > n || !r->p[choice - 1][W_ALIVE]) return -1;
+    } else if (ph->act == ACT_TT_STATEMENTS ? choice != 1 : (choice < 1 || choice > 3)) return -1;
+    uint8_t *f = r->p[i];
+    f[F_ACTED] = 1; f[F_CHOICE] = (uint8_t)choice;
+    switch (ph->act) {
+    case ACT_DETECTIVE: r->det[choice - 1] = r->p[choice - 1][W_TEAM] == TEAM_WEREWOLVES ? 2 : 1; /* fallthrough */
+    case ACT_WOLF_TARGET:
+    case ACT_DOCTOR_PROTECT: f[W_SUB] = 1; f[W_TARGET] = (uint8_t)choice; break;
+    case ACT_TT_STATEMENTS: f[T_SUBMITTED] = 1; break;
+    case ACT_TT_LIE: f[T_LIE] = (uint8_t)choice; break;
+    case ACT_TT_VOTE: f[T_VOTE] = (uint8_t)choice; f[T_HAS_VOTED] = 1; break;
+    default: break;
+    }
+    return 0;
 }
 
 int orc_sizeof_room(void) { return (int)sizeof(orc_room); }

@@ -58,7 +58,8 @@ def lib():
         _lib = C.CDLL(build())
         _lib.orc_room_init.argtypes = [C.POINTER(_Table), C.c_int, C.c_void_p]
         _lib.orc_run.argtypes = [C.POINTER(_Table), C.c_uint64, C.c_uint64, C.c_uint64,
-                                 C.c_uint32, C.c_uint32, C.c_void_p, C.c_int, C.c_int]
+                                 C.c_uint32, C.c_uint32, C.c_void_p, C.c_int, C.c_int, C.c_uint32]
+        _lib.orc_inject_action.argtypes = [C.POINTER(_Table), C.c_void_p, C.c_int, C.c_int]
         assert _lib.orc_sizeof_room() == ROOM_DTYPE.itemsize
         assert _lib.orc_sizeof_table() == C.sizeof(_Table)
     return _lib
@@ -111,10 +112,15 @@ class Oracle:
         return rooms
 
     def run(self, rooms: np.ndarray, seed: int, first_room: int, first_turn: int, n_turns: int,
-            threads: int = 1, restart: bool = False) -> None:
+            threads: int = 1, restart: bool = False, human_mask: int = 0) -> None:
         assert rooms.dtype == ROOM_DTYPE and rooms.flags.c_contiguous
         lib().orc_run(C.byref(self.ct), seed, first_room, len(rooms), first_turn, n_turns,
-                      rooms.ctypes.data, threads, int(restart))
+                      rooms.ctypes.data, threads, int(restart), human_mask)
+
+    def inject(self, rooms: np.ndarray, index: int, player_id: int, choice: int) -> bool:
+        """Log a host-driven player's action in room `index`; False if not allowed."""
+        ptr = rooms.ctypes.data + index * ROOM_DTYPE.itemsize
+        return lib().orc_inject_action(C.byref(self.ct), ptr, player_id, choice) == 0
 
     def project(self, room) -> List[int]:
         out = [self.ids[int(room["phase"])], self.ids[int(room["prev"])], int(room["phase0_done"]),
@@ -126,10 +132,15 @@ class Oracle:
         return out
 
     def trajectory(self, seed: int, room_index: int, n_turns: int, restart: bool = False,
-                   first_turn: int = 0) -> List[List[int]]:
+                   first_turn: int = 0, human_mask: int = 0, human=None) -> List[List[int]]:
+        """`human(turn, projection) -> (player_id, choice) | None` is asked before every turn."""
         rooms = self.init_rooms(1)
         out = []
         for t in range(first_turn, first_turn + n_turns):
-            self.run(rooms, seed, room_index, t, 1, restart=restart)
+            if human is not None:
+                act = human(t, self.project(rooms[0]))
+                if act:
+                    assert self.inject(rooms, 0, act[0], act[1]), (t, act)
+            self.run(rooms, seed, room_index, t, 1, restart=restart, human_mask=human_mask)
             out.append(self.project(rooms[0]))
         return out

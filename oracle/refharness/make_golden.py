@@ -102,6 +102,33 @@ def restart_cases():
                        "cases": cases}, f, separators=(",", ":"))
 
 
+def human_cases():
+    """Player 1 is host-driven (the reference's human): the bot policy skips it and a scripted
+    person (oracle/human_script.py) acts for it."""
+    from ..human_script import HUMAN_MASK, scripted_human
+    for game, n, turns in (("werewolf-(mafia)", 8, 110), ("two-truths-and-a-lie", 4, 100), ("werewolf-(mafia)", 12, 140)):
+        cases = []
+        for seed in SEEDS:
+            room = 31
+            sess = {v: RoomSession(game, n, seed, room, v, human_mask=HUMAN_MASK, human_script=scripted_human) for v in ("v2", "v3")}
+            traj = []
+            for t in range(turns):
+                for s_ in sess.values():
+                    s_.step()
+                pa = sess["v2"].project()
+                assert pa == sess["v3"].project()
+                traj.append(pa)
+            assert traj[-1][3] >= 0, (game, n, seed, "did not finish")
+            cases.append({"seed": seed, "room": room, "turns": traj})
+            print("human", game, n, hex(seed), "end", traj[-1][3], file=sys.stderr)
+        name = f"human_{game.split('-(')[0].replace('-', '_')}_n{n}.json"
+        with open(os.path.join(GOLD, name), "w") as f:
+            json.dump({"game": game, "n_players": n, "rounds": 1, "human_mask": HUMAN_MASK,
+                       "source": "reference v2 + v3 nodes under FixedPolicy with player 1 host-driven (oracle/human_script.py)",
+                       "cases": cases}, f, separators=(",", ":"))
+
+
 if __name__ == "__main__":
     main()
     restart_cases()
+    human_cases()

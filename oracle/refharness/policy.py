@@ -126,9 +126,11 @@ def plurality(votes: List[int], n: int) -> int:
 
 
 class FixedPolicy:
-    def __init__(self, table: T.Table, seed: int, room: int):
+    def __init__(self, table: T.Table, seed: int, room: int, human_mask: int = 0, human=None):
         self.table = table
         self.rkey = rng.room_key(seed, room)
+        self.human_mask = human_mask      # players the bot policy never acts for (player 1 = the human)
+        self.human = human                # callable(turn, view) -> (player_id, choice) | None: the scripted person
         # clock, set by the walker before each graph run
         self.turn = 0
         self.t_enter = -1
@@ -152,8 +154,17 @@ class FixedPolicy:
         wolfteam = v.mask(v.is_wolf_team)
         kv, kw = v.known() if tb.pack == T.PACK_WEREWOLF else (0, 0)
         calls = []
+        if self.human is not None:
+            # the person's action, logged at the start of this graph run (utils.py:310-358 does it in
+            # InitialRouterNode from the chat message; same tool, same effect)
+            act = self.human(t, v)
+            if act:
+                hp, hc = act
+                calls.append({"name": "update_player_actions",
+                              "args": {"player_id": str(hp), "actions": f"[t={t}|c={hc}] (human) chose {hc}",
+                                       "phase": ph.name}})
         for i in range(v.n):
-            if not (tgt >> i) & 1 or i in acted:
+            if not (tgt >> i) & 1 or i in acted or (self.human_mask >> i) & 1:
                 continue
             d = rng.draw(tkey, i)
             if (d & 3) == 0:          # acts this turn with probability 3/4

@@ -29,6 +29,10 @@ def restart_files():
     return sorted(f for f in os.listdir(GOLD) if f.startswith("restart_") and f.endswith(".json"))
 
 
+def human_files():
+    return sorted(f for f in os.listdir(GOLD) if f.startswith("human_") and f.endswith(".json"))
+
+
 def load_golden(name: str) -> dict:
     with open(os.path.join(GOLD, name)) as f:
         return json.load(f)

@@ -6,7 +6,7 @@ Integer path: every comparison is bit-exact."""
 import numpy as np
 import pytest
 
-from conftest import golden_files, load_dsl, load_golden, restart_files
+from conftest import golden_files, human_files, load_dsl, load_golden, restart_files
 from game_engine_amd import GameTable, GeError, RoomBatch
 from game_engine_amd.stepper import project_view
 from parity_util import assert_views_equal, oracle_batch
@@ -105,6 +105,57 @@ def test_high_occupancy_path_equals_oracle(game, n, n_rooms):
         got = b.read_rooms()
     want = oracle_batch(_oracle(dsl, n), n_rooms, seed, 0, turns, restart=True)
     assert_views_equal(got, want, f"{game} n={n} rooms={n_rooms}")
+
+
+@pytest.mark.parametrize("name", human_files())
+def test_host_driven_player_golden(name):
+    """Player 1 host-driven (human_mask) + ge_batch_inject_action, against reference-run vectors."""
+    from oracle.human_script import scripted_human
+    from oracle import dsl_table
+    g = load_golden(name)
+    dsl = load_dsl(g["game"])
+    tb, otb, n = GameTable(dsl), dsl_table.compile_dsl(dsl), g["n_players"]
+    for case in g["cases"]:
+        with RoomBatch([(tb, n, 1, g["human_mask"])], seed=case["seed"], first_room=case["room"], max_fuse=1) as b:
+            for t, want in enumerate(case["turns"]):
+                act = scripted_human(otb, t, project_view(b.read_rooms(0, 1)[0]), n)
+                if act:
+                    b.inject_action(0, act[0], act[1])
+                b.step(1)
+                assert project_view(b.read_rooms(0, 1)[0]) == want, f"{name} seed={case['seed']:#x} turn={t}"
+
+
+@pytest.mark.parametrize("game,n,mask", [("werewolf-(mafia)", 8, 0b1), ("werewolf-(mafia)", 12, 0b100000000101),
+                                         ("two-truths-and-a-lie", 4, 0b11)])
+def test_host_driven_players_random_injection_equals_oracle(game, n, mask):
+    """Many rooms, several host-driven players, actions injected at random moments with random
+    (valid) choices; refused injections (not a target, already acted, dead target) agree too."""
+    dsl = load_dsl(game)
+    orc = _oracle(dsl, n)
+    R, seed, first = 300, 21, 5000
+    rng = np.random.default_rng(n + mask)
+    rooms = orc.init_rooms(R)
+    accepted = refused = 0
+    with RoomBatch([(GameTable(dsl), n, R, mask)], seed=seed, first_room=first, max_fuse=1) as b:
+        for t in range(70):
+            for r in rng.choice(R, size=40, replace=False):
+                pl = int(rng.choice([i + 1 for i in range(n) if (mask >> i) & 1]))
+                ch = int(rng.integers(0, n + 2))
+                ok = orc.inject(rooms, int(r), pl, ch)
+                try:
+                    b.inject_action(int(r), pl, ch)
+                    got_ok = True
+                except GeError as e:
+                    assert e.status == -1
+                    got_ok = False
+                assert ok == got_ok, (t, int(r), pl, ch)
+                accepted += ok
+                refused += not ok
+            b.step(1)
+            orc.run(rooms, seed, first, t, 1, threads=0, human_mask=mask)
+            from parity_util import oracle_rooms_as_views
+            assert_views_equal(b.read_rooms(), oracle_rooms_as_views(orc, rooms), f"{game} turn {t}")
+    assert accepted > 50 and refused > 50
 
 
 def test_fused_equals_unfused_and_chunked(dsl_ww):

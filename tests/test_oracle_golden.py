@@ -3,7 +3,7 @@ produced by running the REFERENCE's own node coroutines (game_agent_v2.py / v3) 
 fixed policy — turn by turn, bit-exact.  CPU only."""
 import pytest
 
-from conftest import golden_files, load_dsl, load_golden, restart_files
+from conftest import golden_files, human_files, load_dsl, load_golden, restart_files
 from oracle.oracle import Oracle
 
 
@@ -40,3 +40,24 @@ def test_oracle_restart_mode_matches_chained_reference_sessions(name):
         got = orc.trajectory(case["seed"], case["room"], len(case["turns"]), restart=True)
         for t, (a, b) in enumerate(zip(got, case["turns"])):
             assert a == b, f"{name} seed={case['seed']:#x} turn={t}"
+
+
+@pytest.mark.parametrize("name", human_files())
+def test_oracle_with_host_driven_player_matches_reference(name):
+    """Player 1 is the reference's human: the bot policy skips it, a scripted person acts for it
+    (oracle/human_script.py) and its action is logged at the start of the next graph run."""
+    from oracle.human_script import scripted_human
+    g = load_golden(name)
+    orc = Oracle(load_dsl(g["game"]), g["n_players"])
+    n = g["n_players"]
+    acted_as_human = 0
+    for case in g["cases"]:
+        def human(t, proj):
+            nonlocal acted_as_human
+            a = scripted_human(orc.table, t, proj, n)
+            acted_as_human += a is not None
+            return a
+        got = orc.trajectory(case["seed"], case["room"], len(case["turns"]), human_mask=g["human_mask"], human=human)
+        for t, (a, b) in enumerate(zip(got, case["turns"])):
+            assert a == b, f"{name} seed={case['seed']:#x} turn={t}"
+    assert acted_as_human >= 3          # the script really drove player 1
