@@ -53,6 +53,28 @@ template <int NB> __device__ __forceinline__ uint32_t nth_set_bit(uint32_t m, ui
     return pos;
 }
 
+// the same through a 2 KB LDS table nth8[mask][n] (mask: 8 bits): one LDS read instead of ~15 VALU
+// instructions.  Pays at many wavefronts per SIMD (VALU-bound); a lone wavefront would only add
+// LDS latency to a dependent chain, so it keeps the computed form (`lowocc`).
+template <int NB> __device__ __forceinline__ uint32_t nth_set_bit_lds(const uint8_t *nth8, uint32_t m, uint32_t n) {
+    if (NB <= 8) return nth8[(m & 0xFFu) * 8u + (n & 7u)];
+    const uint32_t lo = m & 0xFFu, c = popc(lo);
+    const bool in_lo = n < c;
+    const uint32_t idx = in_lo ? lo * 8u + n : ((m >> 8) & 0xFFu) * 8u + ((n - c) & 7u);
+    return (in_lo ? 0u : 8u) + nth8[idx];
+}
+
+__device__ __forceinline__ void fill_nth8(uint8_t *nth8) {
+    for (uint32_t m = threadIdx.x; m < 256u; m += blockDim.x) {
+        uint32_t x = m;
+#pragma unroll
+        for (uint32_t n = 0; n < 8u; n++) {
+            nth8[m * 8u + n] = x ? (uint8_t)(__ffs((int)x) - 1) : (uint8_t)0;
+            x &= x - 1u;
+        }
+    }
+}
+
 // 1-based id with the most votes among `voters`, ties -> lowest id, 0 if nobody voted.
 // votes: one nibble per player (1-based target id, 0 = none).  Counters are nibbles too
 // (<= 12 voters), so the whole tally is one or two registers.
@@ -105,9 +127,9 @@ __device__ __forceinline__ void wave_sync() {
 }
 
 // candidate choice of one bot action (POLICY.md §3); shared by the per-lane loop and the queue
-template <int NB>
+template <int NB, bool TABLE>
 __device__ __forceinline__ uint32_t ww_choose(uint32_t act, uint32_t i, uint32_t d, uint32_t alive, uint32_t team_w,
-                                              uint32_t known, uint32_t lo_kw, uint32_t r_det) {
+                                              uint32_t known, uint32_t lo_kw, uint32_t r_det, const uint8_t *nth8) {
     const uint32_t me = 1u << i;
     const uint32_t others = alive & ~me, non_wolf = alive & ~team_w;
     uint32_t cand = alive;                                    // ACT_DOCTOR_PROTECT
@@ -117,7 +139,8 @@ __device__ __forceinline__ uint32_t ww_choose(uint32_t act, uint32_t i, uint32_t
     const uint32_t vote = (team_w & me) ? non_wolf : (((r_det & me) && lo_kw) ? lo_kw : others);
     cand = act == ACT_DAY_VOTE ? vote : cand;
     cand = cand ? cand : alive;
-    return nth_set_bit<NB>(cand, pick(d, popc(cand))) + 1u;
+    const uint32_t idx = pick(d, popc(cand));
+    return (TABLE ? nth_set_bit_lds<NB>(nth8, cand, idx) : nth_set_bit<NB>(cand, idx)) + 1u;
 }
 
 // nibble mask (0xF per player) of the non-zero nibbles of x
@@ -129,10 +152,13 @@ __device__ __forceinline__ uint64_t nib_nonzero(uint64_t x) {
 }
 
 // ------------------------------------------------------------------ werewolf
-template <int NB, bool QUEUE>
-__device__ __forceinline__ void ww_turn(WW<NB> &s, DevRow &row, const DevRow *rows, WaveLds *lw, bool valid, uint32_t n,
+// LOWOCC: the launch has fewer than ~3 wavefronts per SIMD (e.g. 65 536 rooms): a lone wavefront
+// stalls on every branch instruction and every dependent LDS access, so that build is branch-lean
+// and computes; the other build (many wavefronts, VALU-bound) prefers LDS tables and skip-branches.
+template <int NB, bool QUEUE, bool LOWOCC>
+__device__ __forceinline__ void ww_turn(WW<NB> &s, DevRow &row, const DevRow *rows, WaveLds *lw, const uint8_t *nth8, bool valid, uint32_t n,
                                         uint32_t nw, uint32_t phase0_idx, uint32_t rkey, uint32_t turn,
-                                        bool trace, bool lowocc, uint32_t human, uint32_t &ev_newly, uint64_t &ev_choice) {
+                                        bool trace, uint32_t human, uint32_t &ev_newly, uint64_t &ev_choice) {
     // human: players the host drives (never acted for here)
     // ev_*: this turn's logged actions (who acted, what they chose) for the optional event trace
     // `row` is the table row of s.phase, kept in registers across turns: LDS is read only on a transition
@@ -193,7 +219,7 @@ __device__ __forceinline__ void ww_turn(WW<NB> &s, DevRow &row, const DevRow *ro
                 todo &= todo - 1u;
                 const uint32_t d = draw(tk, i);
                 const bool go = (d & 3u) != 0u;
-                const uint32_t c = ww_choose<NB>(act, i, d, s.alive, s.team_w, known, lo_kw, r_det);
+                const uint32_t c = ww_choose<NB, false>(act, i, d, s.alive, s.team_w, known, lo_kw, r_det, nullptr);
                 const uint32_t sh = 4u * i;
                 const nib_t clr = ~(nib_t(15) << sh), put = nib_t(c) << sh;
                 s.choice = go ? ((s.choice & clr) | put) : s.choice;
@@ -221,7 +247,7 @@ __device__ __forceinline__ void ww_turn(WW<NB> &s, DevRow &row, const DevRow *ro
                 lw->res[lane] = make_uint4(0u, 0u, 0u, 0u);
                 // straight-line, predicated: a loop's taken back-edges are what a lone wavefront
                 // per SIMD (the 65 536-room shape) cannot hide
-                if (lowocc) {
+                if (LOWOCC) {
                     // one wavefront per SIMD: every branch instruction stalls it (~50 cycles, nothing
                     // else to issue), so write unconditionally; an exhausted lane hits its dummy slot
 #pragma unroll
@@ -251,8 +277,8 @@ __device__ __forceinline__ void ww_turn(WW<NB> &s, DevRow &row, const DevRow *ro
                     const uint4 c4 = lw->ctx[L];
                     const uint32_t d = draw(c4.w, i);
                     if (k < total && (d & 3u) != 0u) {
-                        const uint32_t c = ww_choose<NB>(c4.z >> 16, i, d, c4.x & 0xFFFFu, c4.x >> 16,
-                                                         c4.y & 0xFFFFu, c4.z & 0xFFFFu, c4.y >> 16);
+                        const uint32_t c = ww_choose<NB, !LOWOCC>(c4.z >> 16, i, d, c4.x & 0xFFFFu, c4.x >> 16,
+                                                                  c4.y & 0xFFFFu, c4.z & 0xFFFFu, c4.y >> 16, nth8);
                         uint32_t *r = reinterpret_cast<uint32_t *>(&lw->res[L]);
                         atomicOr(r, 1u << i);
                         atomicOr(r + 1 + (i >> 3), c << (4u * (i & 7u)));
@@ -322,7 +348,9 @@ __device__ __forceinline__ void ww_turn(WW<NB> &s, DevRow &row, const DevRow *ro
         for (uint32_t j = 0; j < (NB > 8 ? 5u : 4u); j++) {           // nw + 2 picks, nw <= NB / 4
             const uint32_t k = popc(rem);
             const bool on = j < nw + 2u && k != 0u;            // selects, not branches (see `lowocc`)
-            const uint32_t bit = on ? (1u << nth_set_bit<NB>(rem | (1u << 31), pick(draw(tk, 16u + j), k | (k == 0u)))) : 0u;
+            const uint32_t idx = pick(draw(tk, 16u + j), k | (k == 0u));
+            const uint32_t pos = LOWOCC ? nth_set_bit<NB>(rem | (1u << 31), idx) : nth_set_bit_lds<NB>(nth8, rem, idx);
+            const uint32_t bit = on ? (1u << (pos & 15u)) : 0u;
             rem &= ~bit;
             wolves |= j < nw ? bit : 0u;
             doc = j == nw ? bit : doc;

@@ -90,9 +90,9 @@ __device__ __forceinline__ void store_event(uint32_t *trace, uint64_t rooms_padd
     ((__attribute__((address_space(1))) u32x4 *)(uintptr_t)trace)[(uint64_t)t * rooms_padded + room] = v;
 }
 
-template <int NB>
+template <int NB, bool LOWOCC>
 __device__ __forceinline__ void run_ww(const SegDev *__restrict__ sgp, const StepArgs &a, const DevRow *rows, WaveLds *lw,
-                                       uint64_t room_in) {
+                                       const uint8_t *nth8, uint64_t room_in) {
     const SegDev &sg = *sgp;
     using L = WWLayout<NB>;
     // lanes past the end of the segment stay in the wavefront (the action queue is a wave-wide
@@ -124,8 +124,8 @@ __device__ __forceinline__ void run_ww(const SegDev *__restrict__ sgp, const Ste
         const uint32_t p = s.phase;
         uint32_t ev_newly = 0;
         uint64_t ev_choice = 0;
-        ww_turn<NB, GE_WAVE_QUEUE>(s, row, rows, lw, valid, sg.n_players, sg.nw, sg.phase0_idx, rk, a.turn0 + t,
-                                   a.trace != 0u, a.lowocc != 0u, sg.human_mask, ev_newly, ev_choice);
+        ww_turn<NB, GE_WAVE_QUEUE, LOWOCC>(s, row, rows, lw, nth8, valid, sg.n_players, sg.nw, sg.phase0_idx, rk, a.turn0 + t,
+                                   a.trace != 0u, sg.human_mask, ev_newly, ev_choice);
         if (a.trace && valid) store_event(sg.trace, sg.rooms_padded, t, room, a.turn0 + t, p, s.phase, restarted, ev_newly, ev_choice);
     }
     if (!valid) return;
@@ -176,52 +176,57 @@ __device__ __forceinline__ void run_tt(const SegDev *__restrict__ sgp, const Ste
 // Two-Truths batch diverges per block, never inside a wavefront.  Segment descriptors live in
 // device memory and are read with a block-uniform index (scalar loads): indexing the kernel
 // arguments dynamically would push them through scratch.
-template <int KIND>
+template <int KIND, bool LOWOCC>
 __device__ __forceinline__ void run_kind(const SegDev *__restrict__ sg, const StepArgs &a, const DevRow *rows, WaveLds *lw,
-                                         uint64_t room) {
-    if (KIND == K_WW8) run_ww<8>(sg, a, rows, lw, room);
-    else if (KIND == K_WW12) run_ww<12>(sg, a, rows, lw, room);
+                                         const uint8_t *nth8, uint64_t room) {
+    if (KIND == K_WW8) run_ww<8, LOWOCC>(sg, a, rows, lw, nth8, room);
+    else if (KIND == K_WW12) run_ww<12, LOWOCC>(sg, a, rows, lw, nth8, room);
     else if (KIND == K_TT4) run_tt<4>(sg, a, rows, room);
     else if (KIND == K_TT8) run_tt<8>(sg, a, rows, room);
     else run_tt<12>(sg, a, rows, room);
 }
 
-__device__ __forceinline__ void load_rows(DevRow *rows, const DevTable *tables, uint32_t table_idx) {
+__device__ __forceinline__ void load_rows(DevRow *rows, const DevTable *tables, uint32_t table_idx, uint8_t *nth8) {
     if (threadIdx.x < GE_MAX_PHASES) rows[threadIdx.x] = tables[table_idx].rows[threadIdx.x];
+    if (nth8) fill_nth8(nth8);
     __syncthreads();
 }
 
 // single-kind batch (the benchmark configurations): one instantiation per record layout, so each
 // gets its own register allocation
-template <int KIND>
+template <int KIND, bool LOWOCC>
 __global__ void __launch_bounds__(256) ge_step_kernel(const StepArgs a, const SegDev *__restrict__ segs,
                                                       const DevTable *__restrict__ tables) {
     __shared__ DevRow rows[GE_MAX_PHASES];
-    __shared__ WaveLds wl[(KIND == K_WW8 || KIND == K_WW12) ? 4 : 1];
-    load_rows(rows, tables, segs[0].table_idx);
+    constexpr bool WWK = KIND == K_WW8 || KIND == K_WW12;
+    __shared__ WaveLds wl[WWK ? 4 : 1];
+    __shared__ uint8_t nth8[WWK ? 2048 : 8];
+    load_rows(rows, tables, segs[0].table_idx, (WWK && !LOWOCC) ? nth8 : nullptr);
     const uint64_t room = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    run_kind<KIND>(segs, a, rows, &wl[(KIND == K_WW8 || KIND == K_WW12) ? (threadIdx.x >> 6) : 0], room);
+    run_kind<KIND, LOWOCC>(segs, a, rows, &wl[WWK ? (threadIdx.x >> 6) : 0], nth8, room);
 }
 
 // mixed batch: several segments (games / player counts) in one launch
+template <bool LOWOCC>
 __global__ void __launch_bounds__(256) ge_step_kernel_mixed(const StepArgs a, const SegDev *__restrict__ segs,
                                                             const DevTable *__restrict__ tables) {
     __shared__ DevRow rows[GE_MAX_PHASES];
     __shared__ WaveLds wl[4];
+    __shared__ uint8_t nth8[2048];
     uint32_t si = 0;
     for (uint32_t k = 1; k < a.n_seg; k++)
         if (blockIdx.x >= a.block_begin[k]) si = k;
     si = __builtin_amdgcn_readfirstlane(si);
     const SegDev *sg = segs + si;
-    load_rows(rows, tables, sg->table_idx);
+    load_rows(rows, tables, sg->table_idx, LOWOCC ? nullptr : nth8);
     const uint64_t room = (uint64_t)(blockIdx.x - a.block_begin[si]) * blockDim.x + threadIdx.x;
     WaveLds *lw = &wl[threadIdx.x >> 6];
     switch (sg->kind) {
-    case K_WW8: run_kind<K_WW8>(sg, a, rows, lw, room); break;
-    case K_WW12: run_kind<K_WW12>(sg, a, rows, lw, room); break;
-    case K_TT4: run_kind<K_TT4>(sg, a, rows, lw, room); break;
-    case K_TT8: run_kind<K_TT8>(sg, a, rows, lw, room); break;
-    default: run_kind<K_TT12>(sg, a, rows, lw, room); break;
+    case K_WW8: run_kind<K_WW8, LOWOCC>(sg, a, rows, lw, nth8, room); break;
+    case K_WW12: run_kind<K_WW12, LOWOCC>(sg, a, rows, lw, nth8, room); break;
+    case K_TT4: run_kind<K_TT4, LOWOCC>(sg, a, rows, lw, nth8, room); break;
+    case K_TT8: run_kind<K_TT8, LOWOCC>(sg, a, rows, lw, nth8, room); break;
+    default: run_kind<K_TT12, LOWOCC>(sg, a, rows, lw, nth8, room); break;
     }
 }
 
@@ -679,17 +684,20 @@ int ge_batch_step(ge_batch *b, uint32_t n_turns, void *hip_stream) {
             HIP_TRY(hipEventRecord(e0, st));
         }
         const dim3 grid(b->n_blocks), block(b->block_threads);
+#define GE_LAUNCH(KERNEL) hipLaunchKernelGGL(KERNEL, grid, block, 0, st, a, b->segs_dev, b->tables)
+        const bool low = a.lowocc != 0u;
         if (b->segs.size() > 1) {
-            hipLaunchKernelGGL(ge_step_kernel_mixed, grid, block, 0, st, a, b->segs_dev, b->tables);
+            if (low) GE_LAUNCH(ge_step_kernel_mixed<true>); else GE_LAUNCH(ge_step_kernel_mixed<false>);
         } else {
             switch (b->segs[0].dev.kind) {
-            case K_WW8: hipLaunchKernelGGL(ge_step_kernel<K_WW8>, grid, block, 0, st, a, b->segs_dev, b->tables); break;
-            case K_WW12: hipLaunchKernelGGL(ge_step_kernel<K_WW12>, grid, block, 0, st, a, b->segs_dev, b->tables); break;
-            case K_TT4: hipLaunchKernelGGL(ge_step_kernel<K_TT4>, grid, block, 0, st, a, b->segs_dev, b->tables); break;
-            case K_TT8: hipLaunchKernelGGL(ge_step_kernel<K_TT8>, grid, block, 0, st, a, b->segs_dev, b->tables); break;
-            default: hipLaunchKernelGGL(ge_step_kernel<K_TT12>, grid, block, 0, st, a, b->segs_dev, b->tables); break;
+            case K_WW8: if (low) GE_LAUNCH((ge_step_kernel<K_WW8, true>)); else GE_LAUNCH((ge_step_kernel<K_WW8, false>)); break;
+            case K_WW12: if (low) GE_LAUNCH((ge_step_kernel<K_WW12, true>)); else GE_LAUNCH((ge_step_kernel<K_WW12, false>)); break;
+            case K_TT4: GE_LAUNCH((ge_step_kernel<K_TT4, false>)); break;
+            case K_TT8: GE_LAUNCH((ge_step_kernel<K_TT8, false>)); break;
+            default: GE_LAUNCH((ge_step_kernel<K_TT12, false>)); break;
             }
         }
+#undef GE_LAUNCH
         HIP_TRY(hipGetLastError());
         if (b->timing) HIP_TRY(hipEventRecord(e1, st));
         b->launches++;
