@@ -179,7 +179,7 @@ __device__ __forceinline__ void ww_turn(WW<NB> &s, DevRow &row, const DevRow *ro
     // shifts, not as a select chain over the struct fields: the compiler turns such a chain
     // into an indexed load and spills the whole room to scratch.
     uint32_t T = 0;
-    if (comp == COMP_ACTION) {
+    if (LOWOCC || comp == COMP_ACTION) {                       // LOWOCC: always evaluated, masked below (no branch)
         uint32_t W[6];
         if (NB == 8) {
             W[0] = s.alive | (s.can_vote << 8) | (s.revealed << 16) | (s.secret << 24);
@@ -201,8 +201,9 @@ __device__ __forceinline__ void ww_turn(WW<NB> &s, DevRow &row, const DevRow *ro
             return ((row.r0 >> (16u + j)) & 1u) ? ~m : m;
         };
         T = s.alive & term(0) & term(1);
-        if (nterms > 2u) T &= term(2) & term(3);               // no shipped phase has more than two terms
-        T &= ALL;
+        if (LOWOCC) T &= term(2) & term(3);                    // unused terms read as all-ones
+        else if (nterms > 2u) T &= term(2) & term(3);          // no shipped phase has more than two terms
+        T &= comp == COMP_ACTION ? ALL : 0u;
     }
 
     // ---- BotBehaviorNode: every due bot acts with probability 3/4, one action per visit
@@ -242,7 +243,7 @@ __device__ __forceinline__ void ww_turn(WW<NB> &s, DevRow &row, const DevRow *ro
                 off += __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)) << b;
                 total += (uint32_t)__popcll(m) << b;
             }
-            if (total != 0u) {                                  // wave-uniform
+            if (LOWOCC || total != 0u) {                        // wave-uniform; LOWOCC: some room almost always has a due bot
                 lw->ctx[lane] = make_uint4(s.alive | (s.team_w << 16), known | (r_det << 16), lo_kw | (act << 16), tk);
                 lw->res[lane] = make_uint4(0u, 0u, 0u, 0u);
                 // straight-line, predicated: a loop's taken back-edges are what a lone wavefront
