@@ -243,7 +243,8 @@ def main():
                        "rooms_per_gpu": rooms, "n_players": [n for _, n, _ in spec], "turns_fused_per_launch": args.fuse,
                        "bytes_per_room_record": bytes_per_room, "sharding": f"rooms x{world}, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(bytes_per_room),
+                         "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_copy_peak": achieved / 6290.0,
+                         "traffic": pmc_traffic(bytes_per_room),
                          "kernel": "ge_step_kernel", "avg_launch_us": avg_launch_s * 1e6, "launches": launches,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "algorithmic bytes = 2 x record x rooms x turns in the launch; with fused turns the "

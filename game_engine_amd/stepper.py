@@ -68,6 +68,27 @@ def load_dsl_by_gamename(gamename: str, games_dir: Optional[str] = None) -> dict
     return {}
 
 
+def initialize_player_states_from_dsl(dsl_content: dict, room_players: list) -> dict:
+    """Same contract as the reference's helper (agent/tools/utils.py:584-653; TS twin
+    src/app/api/games/initialize-players/route.ts:83-166): every room player gets a copy of
+    declaration.player_states_template.player_states[<first id>] with its own `name`; ids "1".."N".
+    Falls back to defaults derived from declaration.player_states when there is no template."""
+    decl = (dsl_content or {}).get("declaration") or {}
+    tmpl_all = (decl.get("player_states_template") or {}).get("player_states") or {}
+    template = tmpl_all.get("1") or tmpl_all.get(1) or (tmpl_all[next(iter(tmpl_all))] if tmpl_all else {})
+    if not template:
+        defaults = {"string": "", "num": 0, "number": 0, "array": [], "list": [], "object": {}, "dict": {}}
+        for name, spec in (decl.get("player_states") or {}).items():
+            ftype, example = spec.get("type", "string"), spec.get("example")
+            if ftype == "boolean":
+                template[name] = example if example is not None else True
+            else:
+                template[name] = example or defaults.get(ftype)
+    if not template:
+        return {}
+    return {str(i + 1): {**template, "name": p.get("name", f"Player {i + 1}")} for i, p in enumerate(room_players)}
+
+
 class GameTable:
     """A game DSL compiled by ge_table_compile_json."""
 
