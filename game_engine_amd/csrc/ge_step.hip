@@ -243,6 +243,8 @@ template <int WORDS> __device__ __forceinline__ uint32_t fold_words(uint32_t h, 
     return h;
 }
 
+constexpr uint32_t SUM_CHUNKS = 16;
+
 struct RoomStats { uint32_t finished, village, wolves, alive, end_turn, games; };
 
 template <int NB> __device__ __forceinline__ RoomStats stats_ww(const uint32_t *w, const DevRow *rows, uint32_t *hist_score) {
@@ -283,25 +285,31 @@ __global__ void __launch_bounds__(256) ge_summary_kernel(const StepArgs a, const
     if (threadIdx.x < 16) { h_end[threadIdx.x] = 0; h_score[threadIdx.x] = 0; }
     if (threadIdx.x < 7) acc[threadIdx.x] = 0;
     __syncthreads();
-    const uint64_t room = (uint64_t)(blockIdx.x - a.block_begin[si]) * blockDim.x + threadIdx.x;
-    RoomStats r = {0, 0, 0, 0, END_NONE, 0};
+    // each block walks SUM_CHUNKS consecutive 256-room chunks of its segment, so that the per-block
+    // global atomics (a few dozen, all blocks on the same words) stay rare
+    RoomStats r = {0, 0, 0, 0, 0, 0};
     uint64_t ck = 0;
-    if (room < sg.rooms) {
+    for (uint32_t c = 0; c < SUM_CHUNKS; c++) {
+        const uint64_t room = ((uint64_t)(blockIdx.x - a.block_begin[si]) * SUM_CHUNKS + c) * blockDim.x + threadIdx.x;
+        if (room >= sg.rooms) break;
         const uint64_t g = sg.first_global + room;
         const uint32_t h0 = mix32((uint32_t)g ^ mix32((uint32_t)(g >> 32) ^ 0xA5A5A5A5u));
         uint32_t h = h0;
+        RoomStats q;
         switch (sg.kind) {
-        case K_WW8: { uint32_t w[8]; load_words<8>(sg.base, sg.rooms_padded, room, w); r = stats_ww<8>(w, rows, h_score); h = fold_words<8>(h0, w); break; }
-        case K_WW12: { uint32_t w[10]; load_words<10>(sg.base, sg.rooms_padded, room, w); r = stats_ww<12>(w, rows, h_score); h = fold_words<10>(h0, w); break; }
-        case K_TT4: { uint32_t w[6]; load_words<6>(sg.base, sg.rooms_padded, room, w); r = stats_tt<4>(w, rows, sg.n_players, h_score); h = fold_words<6>(h0, w); break; }
-        case K_TT8: { uint32_t w[8]; load_words<8>(sg.base, sg.rooms_padded, room, w); r = stats_tt<8>(w, rows, sg.n_players, h_score); h = fold_words<8>(h0, w); break; }
-        default: { uint32_t w[12]; load_words<12>(sg.base, sg.rooms_padded, room, w); r = stats_tt<12>(w, rows, sg.n_players, h_score); h = fold_words<12>(h0, w); break; }
+        case K_WW8: { uint32_t w[8]; load_words<8>(sg.base, sg.rooms_padded, room, w); q = stats_ww<8>(w, rows, h_score); h = fold_words<8>(h0, w); break; }
+        case K_WW12: { uint32_t w[10]; load_words<10>(sg.base, sg.rooms_padded, room, w); q = stats_ww<12>(w, rows, h_score); h = fold_words<10>(h0, w); break; }
+        case K_TT4: { uint32_t w[6]; load_words<6>(sg.base, sg.rooms_padded, room, w); q = stats_tt<4>(w, rows, sg.n_players, h_score); h = fold_words<6>(h0, w); break; }
+        case K_TT8: { uint32_t w[8]; load_words<8>(sg.base, sg.rooms_padded, room, w); q = stats_tt<8>(w, rows, sg.n_players, h_score); h = fold_words<8>(h0, w); break; }
+        default: { uint32_t w[12]; load_words<12>(sg.base, sg.rooms_padded, room, w); q = stats_tt<12>(w, rows, sg.n_players, h_score); h = fold_words<12>(h0, w); break; }
         }
-        ck = (uint64_t)h | ((uint64_t)mix32(h ^ 0x5BD1E995u) << 32);
-        if (r.finished) atomicAdd(&h_end[(r.end_turn >> 3) < 15 ? (r.end_turn >> 3) : 15], 1u);
+        ck += (uint64_t)h | ((uint64_t)mix32(h ^ 0x5BD1E995u) << 32);
+        if (q.finished) atomicAdd(&h_end[(q.end_turn >> 3) < 15 ? (q.end_turn >> 3) : 15], 1u);
+        r.finished += q.finished; r.village += q.village; r.wolves += q.wolves; r.alive += q.alive;
+        r.end_turn += q.finished ? q.end_turn : 0u; r.games += q.games;
     }
     const uint64_t v0 = wave_sum(r.finished), v1 = wave_sum(r.village), v2 = wave_sum(r.wolves);
-    const uint64_t v3 = wave_sum(r.alive), v4 = wave_sum(r.finished ? r.end_turn : 0), v5 = wave_sum(ck);
+    const uint64_t v3 = wave_sum(r.alive), v4 = wave_sum(r.end_turn), v5 = wave_sum(ck);
     const uint64_t v6 = wave_sum(r.games);
     if ((threadIdx.x & 63) == 0) {
         atomicAdd(&acc[0], v0); atomicAdd(&acc[1], v1); atomicAdd(&acc[2], v2);
@@ -889,7 +897,7 @@ int ge_batch_summary(ge_batch *b, ge_summary *out) {
     uint32_t blocks = 0;
     for (uint32_t k = 0; k < a.n_seg; k++) {
         a.block_begin[k] = blocks;
-        blocks += (uint32_t)((b->segs[k].dev.rooms + 255u) / 256u);
+        blocks += (uint32_t)((b->segs[k].dev.rooms + 256u * SUM_CHUNKS - 1u) / (256u * SUM_CHUNKS));
     }
     hipLaunchKernelGGL(ge_summary_kernel, dim3(blocks), dim3(256), 0, st, a, b->segs_dev, b->tables, b->sum_dev);
     HIP_TRY(hipGetLastError());
