@@ -43,11 +43,33 @@ def load_dsl(game=GAME):
         return json.load(f)
 
 
+def usable_cores():
+    """Threads this process may really run at once: the affinity mask, capped by the cgroup CPU quota
+    (a GPU box grants a share of its host: oversubscribing 256 hardware threads only adds noise)."""
+    n = len(os.sched_getaffinity(0))
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    n = min(n, max(1, -(-int(parts[0]) // int(parts[1]))))
+            else:
+                q = int(parts[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                        n = min(n, max(1, -(-q // int(g.read().split()[0]))))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 def cpu_baseline(dsl, budget_s=12.0):
     """The oracle (a scalar C port of the reference loop + policy) on this host's cores, on a
     bounded sample of the same steady-state workload."""
     from oracle.oracle import Oracle
-    cores = len(os.sched_getaffinity(0))
+    cores = usable_cores()
     orc = Oracle(dsl, N_PLAYERS)
     rooms = orc.init_rooms(ROOMS_PER_GPU)
     t0 = time.perf_counter()
