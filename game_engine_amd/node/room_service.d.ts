@@ -1,0 +1,22 @@
+// Types for room_service.js — the single-room (one LangGraph thread) drop-in.
+import { RoomState, ToolCall, FrontendToolCall } from './index';
+
+export interface RoomPlayer { name?: string; gamePlayerId?: number; /** false marks a human seat (host-driven) */ isBot?: boolean; }
+/** AgentState as the frontend syncs it (src/lib/canvas/types.ts:338-360), log-shaped parts included. */
+export interface AgentStateView {
+  gameName: string; current_phase_id: number; current_phase_name: string;
+  player_states: Record<string, Record<string, unknown>>;
+  playerActions: Record<string, { name: string; actions: Record<string, { action: string; timestamp: number; phase: string; id: string }> }>;
+  phase_history: { phase_id: number; phase_name: string }[];
+  game_notes: string[];
+}
+export interface TurnResult { state: AgentStateView; toolCalls: ToolCall[]; uiCalls: FrontendToolCall[]; }
+export class RoomService {
+  constructor(opts?: { gamesDir?: string; seed?: bigint | number; device?: number });
+  createRoom(opts: { threadId: string; gameName: string; players: RoomPlayer[]; dsl?: object }): AgentStateView;
+  humanAction(threadId: string, playerId: number, choice: number): AgentStateView;
+  continueRoom(threadId: string): Promise<TurnResult>;
+  serve(port?: number): Promise<import('http').Server>;
+}
+export function roomIndexOf(threadId: string): bigint;
+export type { RoomState };
