@@ -90,9 +90,15 @@ __device__ __forceinline__ void store_event(uint32_t *trace, uint64_t rooms_padd
     ((__attribute__((address_space(1))) u32x4 *)(uintptr_t)trace)[(uint64_t)t * rooms_padded + room] = v;
 }
 
+__device__ __forceinline__ void load_rows(DevRow *rows, const DevTable *tables, uint32_t table_idx, uint8_t *nth8) {
+    if (threadIdx.x < GE_MAX_PHASES) rows[threadIdx.x] = tables[table_idx].rows[threadIdx.x];
+    if (nth8) fill_nth8(nth8);
+    __syncthreads();
+}
+
 template <int NB, bool LOWOCC>
-__device__ __forceinline__ void run_ww(const SegDev *__restrict__ sgp, const StepArgs &a, const DevRow *rows, WaveLds *lw,
-                                       const uint8_t *nth8, uint64_t room_in) {
+__device__ __forceinline__ void run_ww(const SegDev *__restrict__ sgp, const StepArgs &a, DevRow *rows, WaveLds *lw,
+                                       uint8_t *nth8, const DevTable *__restrict__ tables, uint64_t room_in) {
     const SegDev &sg = *sgp;
     using L = WWLayout<NB>;
     // lanes past the end of the segment stay in the wavefront (the action queue is a wave-wide
@@ -100,7 +106,8 @@ __device__ __forceinline__ void run_ww(const SegDev *__restrict__ sgp, const Ste
     const bool valid = room_in < sg.rooms;
     const uint64_t room = valid ? room_in : 0;
     uint32_t w[L::WORDS];
-    load_words<L::WORDS>(sg.base, sg.rooms_padded, room, w);
+    load_words<L::WORDS>(sg.base, sg.rooms_padded, room, w);      // in flight while the block fills its LDS tables
+    load_rows(rows, tables, sg.table_idx, LOWOCC ? nullptr : nth8);
     WW<NB> s;
     L::unpack(w, s);
     const uint32_t rk = room_key(a.seed_lo, a.seed_hi, sg.first_global + room);
@@ -134,13 +141,15 @@ __device__ __forceinline__ void run_ww(const SegDev *__restrict__ sgp, const Ste
 }
 
 template <int NB>
-__device__ __forceinline__ void run_tt(const SegDev *__restrict__ sgp, const StepArgs &a, const DevRow *rows, uint64_t room_in) {
+__device__ __forceinline__ void run_tt(const SegDev *__restrict__ sgp, const StepArgs &a, DevRow *rows,
+                                       const DevTable *__restrict__ tables, uint64_t room_in) {
     const SegDev &sg = *sgp;
     using L = TTLayout<NB>;
     const bool valid = room_in < sg.rooms;
     const uint64_t room = valid ? room_in : 0;
     uint32_t w[L::WORDS];
     load_words<L::WORDS>(sg.base, sg.rooms_padded, room, w);
+    load_rows(rows, tables, sg.table_idx, nullptr);
     TT<NB> s;
     L::unpack(w, s);
     const uint32_t rk = room_key(a.seed_lo, a.seed_hi, sg.first_global + room);
@@ -177,19 +186,13 @@ __device__ __forceinline__ void run_tt(const SegDev *__restrict__ sgp, const Ste
 // device memory and are read with a block-uniform index (scalar loads): indexing the kernel
 // arguments dynamically would push them through scratch.
 template <int KIND, bool LOWOCC>
-__device__ __forceinline__ void run_kind(const SegDev *__restrict__ sg, const StepArgs &a, const DevRow *rows, WaveLds *lw,
-                                         const uint8_t *nth8, uint64_t room) {
-    if (KIND == K_WW8) run_ww<8, LOWOCC>(sg, a, rows, lw, nth8, room);
-    else if (KIND == K_WW12) run_ww<12, LOWOCC>(sg, a, rows, lw, nth8, room);
-    else if (KIND == K_TT4) run_tt<4>(sg, a, rows, room);
-    else if (KIND == K_TT8) run_tt<8>(sg, a, rows, room);
-    else run_tt<12>(sg, a, rows, room);
-}
-
-__device__ __forceinline__ void load_rows(DevRow *rows, const DevTable *tables, uint32_t table_idx, uint8_t *nth8) {
-    if (threadIdx.x < GE_MAX_PHASES) rows[threadIdx.x] = tables[table_idx].rows[threadIdx.x];
-    if (nth8) fill_nth8(nth8);
-    __syncthreads();
+__device__ __forceinline__ void run_kind(const SegDev *__restrict__ sg, const StepArgs &a, DevRow *rows, WaveLds *lw,
+                                         uint8_t *nth8, const DevTable *__restrict__ tables, uint64_t room) {
+    if (KIND == K_WW8) run_ww<8, LOWOCC>(sg, a, rows, lw, nth8, tables, room);
+    else if (KIND == K_WW12) run_ww<12, LOWOCC>(sg, a, rows, lw, nth8, tables, room);
+    else if (KIND == K_TT4) run_tt<4>(sg, a, rows, tables, room);
+    else if (KIND == K_TT8) run_tt<8>(sg, a, rows, tables, room);
+    else run_tt<12>(sg, a, rows, tables, room);
 }
 
 // single-kind batch (the benchmark configurations): one instantiation per record layout, so each
@@ -201,9 +204,8 @@ __global__ void __launch_bounds__(256) ge_step_kernel(const StepArgs a, const Se
     constexpr bool WWK = KIND == K_WW8 || KIND == K_WW12;
     __shared__ WaveLds wl[WWK ? 4 : 1];
     __shared__ uint8_t nth8[WWK ? 2048 : 8];
-    load_rows(rows, tables, segs[0].table_idx, (WWK && !LOWOCC) ? nth8 : nullptr);
     const uint64_t room = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    run_kind<KIND, LOWOCC>(segs, a, rows, &wl[WWK ? (threadIdx.x >> 6) : 0], nth8, room);
+    run_kind<KIND, LOWOCC>(segs, a, rows, &wl[WWK ? (threadIdx.x >> 6) : 0], nth8, tables, room);
 }
 
 // mixed batch: several segments (games / player counts) in one launch
@@ -218,15 +220,14 @@ __global__ void __launch_bounds__(256) ge_step_kernel_mixed(const StepArgs a, co
         if (blockIdx.x >= a.block_begin[k]) si = k;
     si = __builtin_amdgcn_readfirstlane(si);
     const SegDev *sg = segs + si;
-    load_rows(rows, tables, sg->table_idx, LOWOCC ? nullptr : nth8);
     const uint64_t room = (uint64_t)(blockIdx.x - a.block_begin[si]) * blockDim.x + threadIdx.x;
     WaveLds *lw = &wl[threadIdx.x >> 6];
     switch (sg->kind) {
-    case K_WW8: run_kind<K_WW8, LOWOCC>(sg, a, rows, lw, nth8, room); break;
-    case K_WW12: run_kind<K_WW12, LOWOCC>(sg, a, rows, lw, nth8, room); break;
-    case K_TT4: run_kind<K_TT4, LOWOCC>(sg, a, rows, lw, nth8, room); break;
-    case K_TT8: run_kind<K_TT8, LOWOCC>(sg, a, rows, lw, nth8, room); break;
-    default: run_kind<K_TT12, LOWOCC>(sg, a, rows, lw, nth8, room); break;
+    case K_WW8: run_kind<K_WW8, LOWOCC>(sg, a, rows, lw, nth8, tables, room); break;
+    case K_WW12: run_kind<K_WW12, LOWOCC>(sg, a, rows, lw, nth8, tables, room); break;
+    case K_TT4: run_kind<K_TT4, LOWOCC>(sg, a, rows, lw, nth8, tables, room); break;
+    case K_TT8: run_kind<K_TT8, LOWOCC>(sg, a, rows, lw, nth8, tables, room); break;
+    default: run_kind<K_TT12, LOWOCC>(sg, a, rows, lw, nth8, tables, room); break;
     }
 }
 
