@@ -37,6 +37,8 @@ GE_HD uint32_t room_key(uint32_t seed_lo, uint32_t seed_hi, uint64_t room) {
 }
 GE_HD uint32_t turn_key(uint32_t rk, uint32_t turn) { return mix32(rk ^ (turn * GOLDEN)); }
 GE_HD uint32_t draw(uint32_t tk, uint32_t idx) { return mix32(tk + (idx + 1u) * GOLDEN); }
+// role picks are keyed by the room's game index, not by the turn in which they are applied
+GE_HD uint32_t deal_key(uint32_t rk, uint32_t game) { return mix32(rk ^ 0x44454C31u ^ (game * GOLDEN)); }
 
 #if defined(__HIPCC__)
 __device__ __forceinline__ uint32_t pick(uint32_t d, uint32_t k) { return __umulhi(d, k); }
@@ -151,6 +153,28 @@ __device__ __forceinline__ uint64_t nib_nonzero(uint64_t x) {
     uint64_t m = x | (x >> 1); m |= m >> 2; m &= 0x1111111111111111ull; return (m << 4) - m;
 }
 
+// A room's role deal (POLICY.md §3 ASSIGN_ROLES): nw werewolves, then a Doctor, then a Detective, by
+// repeated n-th-set-bit sampling of the players not yet dealt; `rem` = the Villagers.
+struct Deal { uint32_t wolves, doc, det, rem, game, valid; };
+
+template <int NB, bool LOWOCC>
+__device__ __forceinline__ void deal_roles(Deal &d, uint32_t dk, uint32_t game, uint32_t n, uint32_t nw, const uint8_t *nth8) {
+    uint32_t rem = (1u << n) - 1u, wolves = 0, doc = 0, det = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < (NB > 8 ? 5u : 4u); j++) {           // nw + 2 picks, nw <= NB / 4
+        const uint32_t k = popc(rem);
+        const bool on = j < nw + 2u && k != 0u;            // selects, not branches (see LOWOCC)
+        const uint32_t idx = pick(draw(dk, 16u + j), k | (k == 0u));
+        const uint32_t pos = LOWOCC ? nth_set_bit<NB>(rem | (1u << 31), idx) : nth_set_bit_lds<NB>(nth8, rem, idx);
+        const uint32_t bit = on ? (1u << (pos & 15u)) : 0u;
+        rem &= ~bit;
+        wolves |= j < nw ? bit : 0u;
+        doc = j == nw ? bit : doc;
+        det = j == nw + 1u ? bit : det;
+    }
+    d.wolves = wolves; d.doc = doc; d.det = det; d.rem = rem; d.game = game; d.valid = 1u;
+}
+
 // ------------------------------------------------------------------ werewolf
 // LOWOCC: the launch has fewer than ~3 wavefronts per SIMD (e.g. 65 536 rooms): a lone wavefront
 // stalls on every branch instruction and every dependent LDS access, so that build is branch-lean
@@ -158,7 +182,7 @@ __device__ __forceinline__ uint64_t nib_nonzero(uint64_t x) {
 template <int NB, bool QUEUE, bool LOWOCC>
 __device__ __forceinline__ void ww_turn(WW<NB> &s, DevRow &row, const DevRow *rows, WaveLds *lw, const uint8_t *nth8, bool valid, uint32_t n,
                                         uint32_t nw, uint32_t phase0_idx, uint32_t rkey, uint32_t turn,
-                                        bool trace, uint32_t human, uint32_t &ev_newly, uint64_t &ev_choice) {
+                                        bool trace, uint32_t human, Deal &deal, uint32_t &ev_newly, uint64_t &ev_choice) {
     // human: players the host drives (never acted for here)
     // ev_*: this turn's logged actions (who acted, what they chose) for the optional event trace
     // `row` is the table row of s.phase, kept in registers across turns: LDS is read only on a transition
@@ -344,19 +368,11 @@ __device__ __forceinline__ void ww_turn(WW<NB> &s, DevRow &row, const DevRow *ro
     const uint32_t q0 = qrow.r0;
     const uint32_t eff = (q0 >> 5) & 7u;
     if (eff == EFF_ASSIGN_ROLES) {
-        uint32_t rem = ALL, wolves = 0, doc = 0, det = 0;
-#pragma unroll
-        for (uint32_t j = 0; j < (NB > 8 ? 5u : 4u); j++) {           // nw + 2 picks, nw <= NB / 4
-            const uint32_t k = popc(rem);
-            const bool on = j < nw + 2u && k != 0u;            // selects, not branches (see `lowocc`)
-            const uint32_t idx = pick(draw(tk, 16u + j), k | (k == 0u));
-            const uint32_t pos = LOWOCC ? nth_set_bit<NB>(rem | (1u << 31), idx) : nth_set_bit_lds<NB>(nth8, rem, idx);
-            const uint32_t bit = on ? (1u << (pos & 15u)) : 0u;
-            rem &= ~bit;
-            wolves |= j < nw ? bit : 0u;
-            doc = j == nw ? bit : doc;
-            det = j == nw + 1u ? bit : det;
-        }
+        // the deal of this game was normally prepared ahead (run loop, every 8th turn, for all lanes
+        // of the wavefront at once); fall back to dealing here if it was not
+        if (!(deal.valid && deal.game == s.games)) deal_roles<NB, LOWOCC>(deal, deal_key(rkey, s.games), s.games, n, nw, nth8);
+        const uint32_t rem = deal.rem, wolves = deal.wolves, doc = deal.doc, det = deal.det;
+        deal.valid = 0u;
         s.rb0 = rem | doc; s.rb1 = wolves | doc; s.rb2 = det;
         s.team_w = wolves; s.team_v = ALL & ~wolves;
         s.secret = ALL & ~rem; s.elig = ALL & ~rem;

@@ -119,7 +119,18 @@ __device__ __forceinline__ void run_ww(const SegDev *__restrict__ sgp, const Ste
     WW<NB> s0;
     L::unpack(iw, s0);
     const DevRow row0 = rows[sg.phase0_idx];
+    // Role deals are keyed by (room, game index), so they can be prepared before the turn that applies
+    // them.  Entering the role-assignment phase is rare per room (once a game) but in a wavefront of 64
+    // rooms some room does it on ~80 % of the turns; instead of running the deal for that one lane, every
+    // 8th turn all lanes without a prepared deal get their next one together (a game is longer than 8 turns).
+    Deal deal = {0u, 0u, 0u, 0u, 0u, 0u};
+    const bool ahead = a.n_turns >= 16u;                      // not worth it for short launches
     for (uint32_t t = 0; t < a.n_turns; t++) {
+        if (ahead && (t & 7u) == 0u && !deal.valid) {
+            const bool dealt = (s.rb0 | s.rb1 | s.rb2) != 0u;  // this game already has roles: prepare the next game's
+            const uint32_t g = dealt ? (s.games < 0xFFFFu ? s.games + 1u : s.games) : s.games;
+            deal_roles<NB, LOWOCC>(deal, deal_key(rk, g), g, sg.n_players, sg.nw, nth8);
+        }
         uint32_t restarted = 0;
         if (a.restart && ((row.r0 >> 11) & 7u) == 0u) {      // recycle a finished room
             const uint32_t g = s.games;
@@ -132,7 +143,7 @@ __device__ __forceinline__ void run_ww(const SegDev *__restrict__ sgp, const Ste
         uint32_t ev_newly = 0;
         uint64_t ev_choice = 0;
         ww_turn<NB, GE_WAVE_QUEUE, LOWOCC>(s, row, rows, lw, nth8, valid, sg.n_players, sg.nw, sg.phase0_idx, rk, a.turn0 + t,
-                                   a.trace != 0u, sg.human_mask, ev_newly, ev_choice);
+                                   a.trace != 0u, sg.human_mask, deal, ev_newly, ev_choice);
         if (a.trace && valid) store_event(sg.trace, sg.rooms_padded, t, room, a.turn0 + t, p, s.phase, restarted, ev_newly, ev_choice);
     }
     if (!valid) return;

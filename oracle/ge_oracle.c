@@ -83,6 +83,7 @@ static uint32_t room_key(uint64_t seed, uint64_t room) {
     return k;
 }
 static uint32_t turn_key(uint32_t rk, uint32_t turn) { return mix32(rk ^ (turn * 0x9E3779B9u)); }
+static uint32_t deal_key(uint32_t rk, uint32_t game) { return mix32(rk ^ 0x44454C31u ^ (game * 0x9E3779B9u)); }
 static uint32_t draw(uint32_t tk, uint32_t idx) { return mix32(tk + (idx + 1u) * 0x9E3779B9u); }
 static uint32_t pick(uint32_t d, uint32_t k) { return (uint32_t)(((uint64_t)d * k) >> 32); }
 
@@ -270,9 +271,10 @@ void orc_room_step(const orc_table *tb, orc_room *r, uint64_t seed, uint64_t roo
     case EFF_ASSIGN_ROLES: {
         uint8_t rem[16];
         int left = n, nw = n / 4 > 1 ? n / 4 : 1;
+        const uint32_t dk = deal_key(room_key(seed, room), (uint32_t)r->games);   /* roles are dealt per game */
         for (int i = 0; i < n; i++) { rem[i] = 1; r->p[i][W_ROLE] = ROLE_VILLAGER; }
         for (int j = 0; j < nw + 2 && left > 0; j++) {
-            int i = nth_candidate(rem, n, (int)pick(draw(tk, 16u + (uint32_t)j), (uint32_t)left));
+            int i = nth_candidate(rem, n, (int)pick(draw(dk, 16u + (uint32_t)j), (uint32_t)left));
             r->p[i][W_ROLE] = j < nw ? ROLE_WEREWOLF : (j == nw ? ROLE_DOCTOR : ROLE_DETECTIVE);
             rem[i] = 0; left--;
         }

@@ -85,8 +85,8 @@ def restart_cases():
             traj, games = [], 0
             for t in range(turns):
                 if sess["v2"].end_turn >= 0:
-                    sess = {v: RoomSession(game, n, seed, room, v, turn0=t) for v in ("v2", "v3")}
                     games += 1
+                    sess = {v: RoomSession(game, n, seed, room, v, turn0=t, game_index=games) for v in ("v2", "v3")}
                 for s_ in sess.values():
                     s_.step()
                 pa = sess["v2"].project()

@@ -131,6 +131,7 @@ class FixedPolicy:
         self.rkey = rng.room_key(seed, room)
         self.human_mask = human_mask      # players the bot policy never acts for (player 1 = the human)
         self.human = human                # callable(turn, view) -> (player_id, choice) | None: the scripted person
+        self.game = 0            # index of this room's game on its slot (steady-state chains; else 0)
         # clock, set by the walker before each graph run
         self.turn = 0
         self.t_enter = -1
@@ -304,7 +305,7 @@ class FixedPolicy:
             note("CRITICAL", f"Player {k} ({ps[v.ids[i]].get('role', '')}) eliminated {how} - marked is_alive=false")
 
         if q.effect == T.EFF_ASSIGN_ROLES:
-            tkey = rng.turn_key(self.rkey, t)
+            tkey = rng.deal_key(self.rkey, self.game)       # roles are dealt per game, not per turn
             rem = (1 << n) - 1
             cls = [T.ROLE_VILLAGER] * n
             order = [T.ROLE_WEREWOLF] * T.wolves_for(n) + [T.ROLE_DOCTOR, T.ROLE_DETECTIVE]

@@ -88,7 +88,7 @@ class RoomSession:
     """One room (= one LangGraph thread, src/app/api/copilotkit/route.ts:24-37)."""
 
     def __init__(self, game: str, n_players: int, seed: int, room: int = 0,
-                 version: str = "v2", rounds: int = 1, turn0: int = 0, human_mask: int = 0, human_script=None):
+                 version: str = "v2", rounds: int = 1, turn0: int = 0, human_mask: int = 0, human_script=None, game_index: int = 0):
         from .. import dsl_table
         from .policy import FixedPolicy
         import yaml
@@ -101,6 +101,7 @@ class RoomSession:
             def human(turn, view, _s=self):          # the script sees the canonical projection, like the tests do
                 return human_script(_s.table, turn, _s.project(), n_players)
         self.policy = FixedPolicy(self.table, seed, room, human_mask, human)
+        self.policy.game = min(game_index, 0xFFFF)
         self.turn = turn0              # the clock may start late: a new room on a recycled slot
         self.t_enter, self.prev_phase, self.end_turn = turn0 - 1, 0, -1
         self.llm_calls = 0

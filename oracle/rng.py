@@ -31,6 +31,11 @@ def turn_key(rkey: int, turn: int) -> int:
     return mix32(rkey ^ ((turn * GOLDEN) & M32))
 
 
+def deal_key(rkey: int, game: int) -> int:
+    """Key of the role deal of a room's `game`-th game (0-based; > 0 only in steady-state mode)."""
+    return mix32(rkey ^ 0x44454C31 ^ ((game * GOLDEN) & M32))
+
+
 def draw(tkey: int, idx: int) -> int:
     """idx = stream*16 + j ; stream 0 = per-player action draw, 1 = role picks."""
     return mix32((tkey + (idx + 1) * GOLDEN) & M32)
