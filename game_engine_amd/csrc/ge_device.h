@@ -96,18 +96,32 @@ __device__ __forceinline__ uint32_t plurality(nib_t votes, uint32_t voters) {
     }
     const nib_t v = votes & vm;
     // tally: counter k (a nibble) counts votes for player id k; nibble 0 collects "no vote"
-    uint64_t tally = 0;
+    uint32_t key = 0;                                          // max over k of (count << 4 | 15 - k): ties -> lowest id
+    if (NB <= 8) {
+        // 32-bit counters: a vote for player 8 would be nibble 8; its shift (32) wraps to nibble 0,
+        // which nobody reads, and player 8 is counted from bit 3 of the vote nibbles instead
+        const uint32_t v32 = (uint32_t)v;
+        uint32_t tally = 0;
 #pragma unroll
-    for (int i = 0; i < NB; i++) tally += uint64_t(1) << (4u * ((uint32_t)(v >> (4 * i)) & 15u));
-    uint32_t best = 0, arg = 0;
+        for (int i = 0; i < NB; i++) tally += 1u << ((4u * ((v32 >> (4 * i)) & 15u)) & 31u);
 #pragma unroll
-    for (int k = 1; k <= NB; k++) {
-        const uint32_t cnt = (uint32_t)(tally >> (4 * k)) & 15u;
-        const bool gt = cnt > best;
-        best = gt ? cnt : best;
-        arg = gt ? (uint32_t)k : arg;
+        for (int k = 1; k <= NB; k++) {
+            const uint32_t cnt = k < 8 ? (tally >> (4 * k)) & 15u : popc(v32 & 0x88888888u);
+            const uint32_t kk = (cnt << 4) | (uint32_t)(15 - k);
+            key = kk > key ? kk : key;
+        }
+    } else {
+        uint64_t tally = 0;
+#pragma unroll
+        for (int i = 0; i < NB; i++) tally += uint64_t(1) << (4u * ((uint32_t)(v >> (4 * i)) & 15u));
+#pragma unroll
+        for (int k = 1; k <= NB; k++) {
+            const uint32_t cnt = (uint32_t)(tally >> (4 * k)) & 15u;
+            const uint32_t kk = (cnt << 4) | (uint32_t)(15 - k);
+            key = kk > key ? kk : key;
+        }
     }
-    return arg;
+    return (key >> 4) ? 15u - (key & 15u) : 0u;
 }
 
 // Per-wavefront LDS scratch of the bot-action work queue.  Lane = room leaves the action step
@@ -189,7 +203,7 @@ __device__ __forceinline__ void ww_turn(WW<NB> &s, DevRow &row, const DevRow *ro
     using nib_t = typename WW<NB>::nib_t;
     const uint32_t ALL = (1u << n) - 1u;
     const uint32_t comp = row.r0 & 3u, act = (row.r0 >> 2) & 7u, p_eff = (row.r0 >> 5) & 7u;
-    const uint32_t nterms = (row.r0 >> 8) & 7u, nbr = (row.r0 >> 11) & 7u;
+    const uint32_t nterms = (row.r0 >> 8) & 7u;
     const uint32_t tk = turn_key(rkey, turn);
 
     const uint32_t nrb2 = ~s.rb2;
@@ -222,7 +236,7 @@ __device__ __forceinline__ void ww_turn(WW<NB> &s, DevRow &row, const DevRow *ro
             word = wi == 0u ? W[0] : word; word = wi == 1u ? W[1] : word; word = wi == 2u ? W[2] : word;
             if (NB > 8) { word = wi == 3u ? W[3] : word; word = wi == 4u ? W[4] : word; word = wi == 5u ? W[5] : word; }
             const uint32_t m = word >> (e & 31u);
-            return ((row.r0 >> (16u + j)) & 1u) ? ~m : m;
+            return m ^ (uint32_t)((int32_t)(row.r0 << (15u - j)) >> 31);   // term_neg bit j -> 0 / ~0
         };
         T = s.alive & term(0) & term(1);
         if (LOWOCC) T &= term(2) & term(3);                    // unused terms read as all-ones
@@ -342,18 +356,17 @@ __device__ __forceinline__ void ww_turn(WW<NB> &s, DevRow &row, const DevRow *ro
     s.flags |= FLAG_PHASE0_DONE;                               // set by the guard turn; already set afterwards
     uint32_t q = s.phase;
     {   // evaluated for every lane, selected at the end (one branch less than a guarded block)
-        const bool open = !guard && nbr != 0u && (comp != COMP_ACTION || (T & ~s.acted) == 0u);
+        const bool open = !guard && (comp != COMP_ACTION || (T & ~s.acted) == 0u);
         const uint32_t w = popc(s.alive & s.team_w), g = popc(s.alive & s.team_v);
         const uint32_t prev_eff = (s.flags >> 1) & 7u;
         const uint32_t C = 1u | ((w == 0u) << RES_WOLVES_ZERO) | ((w >= g) << RES_WOLVES_GE_VILLAGERS) |
                            ((prev_eff == EFF_DAY_RESOLVE) << RES_FOLLOWS_DAY) |
                            ((prev_eff == EFF_NIGHT_RESOLVE) << RES_FOLLOWS_NIGHT) | (1u << RES_OTHERWISE);
-#pragma unroll
-        for (int b = 3; b >= 0; b--) {
-            const uint32_t res = (row.r2 >> (4 * b)) & 15u;
-            const bool ok = open && (uint32_t)b < nbr && ((C >> res) & 1u);
-            q = ok ? ((row.r3 >> (8 * b)) & 255u) : q;
-        }
+        // first branch (DSL order) whose resolver holds: row.r2 has one byte per branch with the bit of
+        // its resolver set (0 for absent branches), so the lowest non-zero byte of r2 & (C in every byte) wins
+        const uint32_t hit = row.r2 & (C * 0x01010101u);
+        const uint32_t sh = ctz(hit) & 24u;
+        q = (open && hit != 0u) ? ((row.r3 >> sh) & 255u) : q;
     }
     {   // investigated_alignments[c] = team(c): an assignment, so a stale entry is replaced
         // (the guard turn has no actions: both masks are 0)
@@ -416,7 +429,7 @@ __device__ __forceinline__ void tt_turn(TT<NB> &s, DevRow &row, const DevRow *ro
             uint32_t word = 0xFFFFFFFFu;
             word = wi == 0u ? W0 : word; word = wi == 1u ? W1 : word; word = wi == 2u ? W2 : word;
             const uint32_t m = word >> (e & 31u);
-            return ((row.r0 >> (16u + j)) & 1u) ? ~m : m;
+            return m ^ (uint32_t)((int32_t)(row.r0 << (15u - j)) >> 31);   // term_neg bit j -> 0 / ~0
         };
         T = term(0) & term(1);
         if (nterms > 2u) T &= term(2) & term(3);
@@ -466,12 +479,9 @@ __device__ __forceinline__ void tt_turn(TT<NB> &s, DevRow &row, const DevRow *ro
                 if ((uint32_t)i < n && ((uint32_t)(s.rounds >> (4 * i)) & 15u) < rounds) all_done = 0u;
         }
         const uint32_t C = 1u | (all_done << RES_ALL_ROUNDS_DONE) | (1u << RES_OTHERWISE);
-#pragma unroll
-        for (int b = 3; b >= 0; b--) {
-            const uint32_t res = (row.r2 >> (4 * b)) & 15u;
-            const bool ok = (uint32_t)b < nbr && ((C >> res) & 1u);
-            q = ok ? ((row.r3 >> (8 * b)) & 255u) : q;
-        }
+        const uint32_t hit = row.r2 & (C * 0x01010101u);       // see ww_turn
+        const uint32_t sh = ctz(hit) & 24u;
+        q = hit != 0u ? ((row.r3 >> sh) & 255u) : q;
     }
     if (q == s.phase) return;
 

@@ -185,7 +185,7 @@ template <> struct TTLayout<12> {
 //   r0: completion[1:0] act[4:2] effect[7:5] n_terms[10:8] n_br[13:11] term_neg[19:16]
 //   r1: per term a byte {word index [7:5] (7 = no term), shift [4:0]} into the packed predicate words (ge_device.h)
 //   r0 bit 20: some branch asks "all rounds done?" (two-truths)
-//   r2: br_res 4 x 4 bits        r3: br_target 4 x 8 bits
+//   r2: 4 x 8 bits, byte b = 1 << resolver of branch b (0: no such branch)   r3: br_target 4 x 8 bits
 struct DevRow { uint32_t r0, r1, r2, r3; };
 
 struct DevTable {

@@ -364,7 +364,7 @@ DevRow to_dev_row(const ge_phase_row &r, bool bytes4) {
         d.r1 |= enc << (8 * j);
     }
     for (int b = 0; b < GE_MAX_BRANCHES; b++) {
-        d.r2 |= (uint32_t)(r.br_res[b] & 15u) << (4 * b);
+        if (b < r.n_branches) d.r2 |= (1u << (r.br_res[b] & 7u)) << (8 * b);
         d.r3 |= (uint32_t)r.br_target[b] << (8 * b);
         if (b < r.n_branches && r.br_res[b] == GE_RES_ALL_ROUNDS_DONE) d.r0 |= 1u << 20;
     }
