@@ -194,71 +194,67 @@ __device__ __forceinline__ void deal_roles(Deal &d, uint32_t dk, uint32_t game, 
 // stalls on every branch instruction and every dependent LDS access, so that build is branch-lean
 // and computes; the other build (many wavefronts, VALU-bound) prefers LDS tables and skip-branches.
 template <int NB, bool QUEUE, bool LOWOCC>
-__device__ __forceinline__ void ww_turn(WW<NB> &s, DevRow &row, const DevRow *rows, WaveLds *lw, const uint8_t *nth8, bool valid, uint32_t n,
+__device__ __forceinline__ void ww_turn(WWR<NB> &s, DevRow &row, const DevRow *rows, WaveLds *lw, const uint8_t *nth8, bool valid, uint32_t n,
                                         uint32_t nw, uint32_t phase0_idx, uint32_t rkey, uint32_t turn,
                                         bool trace, uint32_t human, Deal &deal, uint32_t &ev_newly, uint64_t &ev_choice) {
     // human: players the host drives (never acted for here)
     // ev_*: this turn's logged actions (who acted, what they chose) for the optional event trace
     // `row` is the table row of s.phase, kept in registers across turns: LDS is read only on a transition
-    using nib_t = typename WW<NB>::nib_t;
+    using nib_t = typename WWR<NB>::nib_t;
+    using R = WWR<NB>;
     const uint32_t ALL = (1u << n) - 1u;
     const uint32_t comp = row.r0 & 3u, act = (row.r0 >> 2) & 7u, p_eff = (row.r0 >> 5) & 7u;
     const uint32_t nterms = (row.r0 >> 8) & 7u;
     const uint32_t tk = turn_key(rkey, turn);
-
-    const uint32_t nrb2 = ~s.rb2;
-    const uint32_t r_vil = s.rb0 & ~s.rb1 & nrb2, r_wolf = ~s.rb0 & s.rb1 & nrb2;
-    const uint32_t r_doc = s.rb0 & s.rb1 & nrb2, r_det = s.rb2 & ~s.rb1 & ~s.rb0;
+    const uint32_t alive = s.template get<F_ALIVE>(), team_w = s.template get<F_TEAM_W>(), r_det = s.template get<F_DET>();
 
     // ---- who must act: target_players.condition AND alive, all players at once.
-    // The 12 base predicates are packed 4 (NB 8) or 2 (NB 12) per 32-bit word; a term selects
-    // its mask with a word select and one shift (row.r1: per term {word [7:5], shift [4:0]},
-    // filled per layout by the host; word 7 = constant all-ones for unused terms).  Written as
-    // shifts, not as a select chain over the struct fields: the compiler turns such a chain
-    // into an indexed load and spills the whole room to scratch.
+    // The 12 base predicates live packed in s.W; the row carries byte-permute selectors that pull each
+    // term's mask out of the word pairs (0xFF where the term is elsewhere / absent), so the condition
+    // is 2-3 v_perm + AND, XOR with the negation mask, and a fold of the term bytes (ge_layout.h DevRow).
     uint32_t T = 0;
     if (LOWOCC || comp == COMP_ACTION) {                       // LOWOCC: always evaluated, masked below (no branch)
-        uint32_t W[6];
-        if (NB == 8) {
-            W[0] = s.alive | (s.can_vote << 8) | (s.revealed << 16) | (s.secret << 24);
-            W[1] = s.elig | (s.sub << 8) | (s.team_v << 16) | (s.team_w << 24);
-            W[2] = (r_vil & 0xFFu) | ((r_wolf & 0xFFu) << 8) | ((r_doc & 0xFFu) << 16) | ((r_det & 0xFFu) << 24);
-            W[3] = W[4] = W[5] = 0xFFFFFFFFu;
+        uint32_t X;
+        if (NB <= 8) {
+            X = __builtin_amdgcn_perm(s.W[1], s.W[0], row.r4) & __builtin_amdgcn_perm(s.W[2], s.W[2], row.r5);
+            X ^= row.r7;
+            X &= X >> 16; X &= X >> 8;                         // 4 terms, one byte each
         } else {
-            W[0] = s.alive | (s.can_vote << 16); W[1] = s.revealed | (s.secret << 16);
-            W[2] = s.elig | (s.sub << 16);       W[3] = s.team_v | (s.team_w << 16);
-            W[4] = (r_vil & 0xFFFu) | ((r_wolf & 0xFFFu) << 16); W[5] = (r_doc & 0xFFFu) | ((r_det & 0xFFFu) << 16);
+            X = __builtin_amdgcn_perm(s.W[1], s.W[0], row.r4) & __builtin_amdgcn_perm(s.W[3], s.W[2], row.r5) &
+                __builtin_amdgcn_perm(s.W[R::NW - 1], s.W[R::NW - 2], row.r6);
+            X ^= row.r7;
+            X &= X >> 16;                                      // terms 0..1, one half-word each
+            if (nterms > 2u) {                                 // no shipped phase has more than two terms
+                auto term = [&](uint32_t j) -> uint32_t {
+                    const uint32_t e = (row.r1 >> (8u * j)) & 255u;
+                    const uint32_t wi = e >> 5;
+                    uint32_t word = 0xFFFFFFFFu;               // wi == 7: no term
+#pragma unroll
+                    for (int k = 0; k < R::NW; k++) word = wi == (uint32_t)k ? s.W[k] : word;
+                    const uint32_t m = word >> (e & 31u);
+                    return m ^ (uint32_t)((int32_t)(row.r0 << (15u - j)) >> 31);   // term_neg bit j -> 0 / ~0
+                };
+                X &= term(2) & term(3);
+            }
         }
-        auto term = [&](uint32_t j) -> uint32_t {
-            const uint32_t e = (row.r1 >> (8u * j)) & 255u;
-            const uint32_t wi = e >> 5;
-            uint32_t word = 0xFFFFFFFFu;                       // wi == 7: no term
-            word = wi == 0u ? W[0] : word; word = wi == 1u ? W[1] : word; word = wi == 2u ? W[2] : word;
-            if (NB > 8) { word = wi == 3u ? W[3] : word; word = wi == 4u ? W[4] : word; word = wi == 5u ? W[5] : word; }
-            const uint32_t m = word >> (e & 31u);
-            return m ^ (uint32_t)((int32_t)(row.r0 << (15u - j)) >> 31);   // term_neg bit j -> 0 / ~0
-        };
-        T = s.alive & term(0) & term(1);
-        if (LOWOCC) T &= term(2) & term(3);                    // unused terms read as all-ones
-        else if (nterms > 2u) T &= term(2) & term(3);          // no shipped phase has more than two terms
-        T &= comp == COMP_ACTION ? ALL : 0u;
+        T = X & alive & (comp == COMP_ACTION ? ALL : 0u);
     }
 
     // ---- BotBehaviorNode: every due bot acts with probability 3/4, one action per visit
     uint32_t newly = 0, new_det_v = 0, new_det_w = 0;
+    const bool night = act >= ACT_WOLF_TARGET && act <= ACT_DETECTIVE;
     {
         uint32_t todo = valid ? (T & ~s.acted & ~human) : 0u;
         const uint32_t known = s.det_v | s.det_w;
-        const uint32_t kw_alive = s.det_w & s.alive;
+        const uint32_t kw_alive = s.det_w & alive;
         const uint32_t lo_kw = kw_alive & (0u - kw_alive);       // lowest known living werewolf
-        const bool night = act >= ACT_WOLF_TARGET && act <= ACT_DETECTIVE;
         if (!QUEUE) {
             while (todo) {
                 const uint32_t i = ctz(todo);
                 todo &= todo - 1u;
                 const uint32_t d = draw(tk, i);
                 const bool go = (d & 3u) != 0u;
-                const uint32_t c = ww_choose<NB, false>(act, i, d, s.alive, s.team_w, known, lo_kw, r_det, nullptr);
+                const uint32_t c = ww_choose<NB, false>(act, i, d, alive, team_w, known, lo_kw, r_det, nullptr);
                 const uint32_t sh = 4u * i;
                 const nib_t clr = ~(nib_t(15) << sh), put = nib_t(c) << sh;
                 s.choice = go ? ((s.choice & clr) | put) : s.choice;
@@ -266,8 +262,8 @@ __device__ __forceinline__ void ww_turn(WW<NB> &s, DevRow &row, const DevRow *ro
                 // RefereeNode (A): record the action (bt:204-225 update_player_state)
                 s.sel = (go && night) ? ((s.sel & clr) | put) : s.sel;
                 const uint32_t tb = (go && act == ACT_DETECTIVE) ? (1u << (c - 1u)) : 0u;
-                new_det_w |= tb & s.team_w;
-                new_det_v |= tb & ~s.team_w;
+                new_det_w |= tb & team_w;
+                new_det_v |= tb & ~team_w;
             }
         } else {
             // exclusive prefix sum of the per-room item counts (<= 12) over the wavefront:
@@ -282,7 +278,7 @@ __device__ __forceinline__ void ww_turn(WW<NB> &s, DevRow &row, const DevRow *ro
                 total += (uint32_t)__popcll(m) << b;
             }
             if (LOWOCC || total != 0u) {                        // wave-uniform; LOWOCC: some room almost always has a due bot
-                lw->ctx[lane] = make_uint4(s.alive | (s.team_w << 16), known | (r_det << 16), lo_kw | (act << 16), tk);
+                lw->ctx[lane] = make_uint4(alive | (team_w << 16), known | (r_det << 16), lo_kw | (act << 16), tk);
                 lw->res[lane] = make_uint4(0u, 0u, 0u, 0u);
                 // straight-line, predicated: a loop's taken back-edges are what a lone wavefront
                 // per SIMD (the 65 536-room shape) cannot hide
@@ -334,14 +330,14 @@ __device__ __forceinline__ void ww_turn(WW<NB> &s, DevRow &row, const DevRow *ro
                 {
                     const uint32_t c = (uint32_t)(got >> (4u * ctz(newly | 0x80000000u))) & 15u;
                     const uint32_t tb = (act == ACT_DETECTIVE && newly) ? (1u << ((c - 1u) & 15u)) : 0u;
-                    new_det_w = tb & s.team_w;
-                    new_det_v = tb & ~s.team_w;
+                    new_det_w = tb & team_w;
+                    new_det_v = tb & ~team_w;
                 }
             }
         }
     }
     s.acted |= newly;
-    if (act >= ACT_WOLF_TARGET && act <= ACT_DETECTIVE) s.sub |= newly;   // act is ACT_NONE outside action phases
+    s.template set<F_SUB>(night ? newly : 0u);                 // night_action_submitted
     ev_newly = newly;
     if (trace) {                                              // wave-uniform
         uint32_t x = newly;                                   // nibble mask of the new actors
@@ -357,7 +353,7 @@ __device__ __forceinline__ void ww_turn(WW<NB> &s, DevRow &row, const DevRow *ro
     uint32_t q = s.phase;
     {   // evaluated for every lane, selected at the end (one branch less than a guarded block)
         const bool open = !guard && (comp != COMP_ACTION || (T & ~s.acted) == 0u);
-        const uint32_t w = popc(s.alive & s.team_w), g = popc(s.alive & s.team_v);
+        const uint32_t w = popc(alive & team_w), g = popc(alive & s.template get<F_TEAM_V>());
         const uint32_t prev_eff = (s.flags >> 1) & 7u;
         const uint32_t C = 1u | ((w == 0u) << RES_WOLVES_ZERO) | ((w >= g) << RES_WOLVES_GE_VILLAGERS) |
                            ((prev_eff == EFF_DAY_RESOLVE) << RES_FOLLOWS_DAY) |
@@ -386,21 +382,24 @@ __device__ __forceinline__ void ww_turn(WW<NB> &s, DevRow &row, const DevRow *ro
         if (!(deal.valid && deal.game == s.games)) deal_roles<NB, LOWOCC>(deal, deal_key(rkey, s.games), s.games, n, nw, nth8);
         const uint32_t rem = deal.rem, wolves = deal.wolves, doc = deal.doc, det = deal.det;
         deal.valid = 0u;
-        s.rb0 = rem | doc; s.rb1 = wolves | doc; s.rb2 = det;
-        s.team_w = wolves; s.team_v = ALL & ~wolves;
-        s.secret = ALL & ~rem; s.elig = ALL & ~rem;
+        const uint32_t special = ALL & ~rem;
+        s.template put<F_VIL>(rem); s.template put<F_WOLF>(wolves); s.template put<F_DOC>(doc); s.template put<F_DET>(det);
+        s.template put<F_TEAM_W>(wolves); s.template put<F_TEAM_V>(ALL & ~wolves);
+        s.template put<F_SECRET>(special); s.template put<F_ELIG>(special);
     } else if (eff == EFF_NIGHT_RESOLVE || eff == EFF_DAY_RESOLVE) {
         const bool day = eff == EFF_DAY_RESOLVE;
-        const uint32_t voters = day ? (s.alive & s.acted) : (s.alive & r_wolf);
+        const uint32_t voters = day ? (alive & s.acted) : (alive & s.template get<F_WOLF>());
         const uint32_t victim = plurality<NB, nib_t>(day ? s.choice : s.sel, voters);
-        const uint32_t docs = s.alive & r_doc;                 // the highest-id living Doctor protects
+        const uint32_t docs = alive & s.template get<F_DOC>();  // the highest-id living Doctor protects
         const uint32_t guarded = (uint32_t)(s.sel >> (4u * (31u - (uint32_t)__clz((int)(docs | 1u))))) & 15u;
         const uint32_t protect = (!day && docs) ? guarded : 0u;
         const uint32_t bit = (victim != 0u && victim != protect) ? (1u << ((victim - 1u) & 15u)) : 0u;
-        s.alive &= ~bit; s.can_vote &= ~bit; s.elig &= ~bit; s.revealed |= bit;
+        s.template clear<F_ALIVE>(bit); s.template clear<F_CAN_VOTE>(bit); s.template clear<F_ELIG>(bit);
+        s.template set<F_REVEALED>(bit);
     }
     const bool nbeg = eff == EFF_NIGHT_BEGIN;
-    s.sub = nbeg ? 0u : s.sub; s.sel = nbeg ? nib_t(0) : s.sel;
+    s.template clear<F_SUB>(nbeg ? R::FM : 0u);
+    s.sel = nbeg ? nib_t(0) : s.sel;
     s.acted = 0; s.choice = 0;
     s.flags = (s.flags & FLAG_PHASE0_DONE) | (p_eff << 1);
     s.prev = s.phase;

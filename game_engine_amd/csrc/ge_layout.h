@@ -98,6 +98,51 @@ template <> struct WWLayout<12> {
     }
 };
 
+// ---------------------------------------------------------------- werewolf room in registers (device)
+// The kernels do not keep the 12 base predicates as 12 separate masks: they stay packed, 4 byte
+// fields (N<=8) or 2 half-word fields (N<=12) per 32-bit word, in predicate order
+//   0 alive 1 can_vote 2 revealed 3 secret | 4 elig 5 sub 6 team_v 7 team_w | 8 r_vil 9 r_wolf 10 r_doc 11 r_det
+// (roles one-hot per class instead of the record's three bit-planes).  A phase's target condition is
+// then a byte permute of these words by a selector precomputed in the table row (ge_device.h), and
+// single fields are byte / half-word operand selects.
+enum { F_ALIVE = 0, F_CAN_VOTE, F_REVEALED, F_SECRET, F_ELIG, F_SUB, F_TEAM_V, F_TEAM_W, F_VIL, F_WOLF, F_DOC, F_DET };
+
+template <int NB> struct WWR {
+    using nib_t = typename Nib<NB>::type;
+    static constexpr int FPW = NB <= 8 ? 4 : 2;     // fields per word
+    static constexpr int FB = 32 / FPW;             // bits per field
+    static constexpr int NW = 12 / FPW;
+    static constexpr uint32_t FM = (1u << FB) - 1u;
+    uint32_t W[NW];
+    uint32_t acted, det_v, det_w;
+    nib_t sel, choice;
+    uint32_t phase, prev, flags, end_turn, games;
+
+    template <int F> GE_HD uint32_t get() const { return (W[F / FPW] >> (FB * (F % FPW))) & FM; }
+    template <int F> GE_HD void set(uint32_t bits) { W[F / FPW] |= bits << (FB * (F % FPW)); }
+    template <int F> GE_HD void clear(uint32_t bits) { W[F / FPW] &= ~(bits << (FB * (F % FPW))); }
+    template <int F> GE_HD void put(uint32_t v) { W[F / FPW] = (W[F / FPW] & ~(FM << (FB * (F % FPW)))) | (v << (FB * (F % FPW))); }
+
+    GE_HD void from(const WW<NB> &u) {
+        for (int k = 0; k < NW; k++) W[k] = 0;
+        set<F_ALIVE>(u.alive); set<F_CAN_VOTE>(u.can_vote); set<F_REVEALED>(u.revealed); set<F_SECRET>(u.secret);
+        set<F_ELIG>(u.elig); set<F_SUB>(u.sub); set<F_TEAM_V>(u.team_v); set<F_TEAM_W>(u.team_w);
+        const uint32_t n2 = ~u.rb2 & FM;
+        set<F_VIL>(u.rb0 & ~u.rb1 & n2); set<F_WOLF>(~u.rb0 & u.rb1 & n2);
+        set<F_DOC>(u.rb0 & u.rb1 & n2); set<F_DET>(u.rb2 & ~u.rb1 & ~u.rb0 & FM);
+        acted = u.acted; det_v = u.det_v; det_w = u.det_w; sel = u.sel; choice = u.choice;
+        phase = u.phase; prev = u.prev; flags = u.flags; end_turn = u.end_turn; games = u.games;
+    }
+    GE_HD void to(WW<NB> &u) const {
+        u.alive = get<F_ALIVE>(); u.can_vote = get<F_CAN_VOTE>(); u.revealed = get<F_REVEALED>(); u.secret = get<F_SECRET>();
+        u.elig = get<F_ELIG>(); u.sub = get<F_SUB>(); u.team_v = get<F_TEAM_V>(); u.team_w = get<F_TEAM_W>();
+        const uint32_t doc = get<F_DOC>();
+        u.rb0 = get<F_VIL>() | doc; u.rb1 = get<F_WOLF>() | doc; u.rb2 = get<F_DET>();
+        u.acted = acted; u.det_v = det_v; u.det_w = det_w; u.sel = sel; u.choice = choice;
+        u.phase = phase; u.prev = prev; u.flags = flags; u.end_turn = end_turn; u.games = games;
+    }
+};
+
 // ---------------------------------------------------------------- two-truths pack
 // masks 0..4 are the base predicates 0..4 (is_speaker, statements_submitted, lie_revealed,
 // can_vote, has_voted).  lie / vote / choice: 2 bits per player.  score: a byte per player,
@@ -181,12 +226,18 @@ template <> struct TTLayout<12> {
 };
 
 // ---------------------------------------------------------------- phase table on the device
-// One row = 4 words (ds_read_b128):
+// One row = 8 words (two ds_read_b128):
 //   r0: completion[1:0] act[4:2] effect[7:5] n_terms[10:8] n_br[13:11] term_neg[19:16]
-//   r1: per term a byte {word index [7:5] (7 = no term), shift [4:0]} into the packed predicate words (ge_device.h)
 //   r0 bit 20: some branch asks "all rounds done?" (two-truths)
+//   r1: per term a byte {word index [7:5] (7 = no term), shift [4:0]} into the packed predicate words
+//       (two-truths, and werewolf N<=12 terms 2..3)
 //   r2: 4 x 8 bits, byte b = 1 << resolver of branch b (0: no such branch)   r3: br_target 4 x 8 bits
-struct DevRow { uint32_t r0, r1, r2, r3; };
+//   r4..r6: werewolf: v_perm_b32 selectors that gather each term's mask out of the packed predicate
+//       word pairs (W1:W0), (W3:W2), (W5:W4) - a term's bytes in the pair that holds its predicate,
+//       0xFF bytes (selector 0x0D) in the others, so the AND of the three permutes is the term.
+//       N<=8: 4 terms x 1 byte, pair (W2:W2) in r5;  N<=12: terms 0..1 x 2 bytes.
+//   r7: XOR mask of the negated terms (same byte positions)
+struct DevRow { uint32_t r0, r1, r2, r3, r4, r5, r6, r7; };
 
 struct DevTable {
     DevRow rows[32];

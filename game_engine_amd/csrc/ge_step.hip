@@ -108,16 +108,24 @@ __device__ __forceinline__ void run_ww(const SegDev *__restrict__ sgp, const Ste
     uint32_t w[L::WORDS];
     load_words<L::WORDS>(sg.base, sg.rooms_padded, room, w);      // in flight while the block fills its LDS tables
     load_rows(rows, tables, sg.table_idx, LOWOCC ? nullptr : nth8);
-    WW<NB> s;
-    L::unpack(w, s);
+    WWR<NB> s;
+    {
+        WW<NB> u;
+        L::unpack(w, u);
+        s.from(u);                                            // packed predicates, one-hot roles (ge_layout.h)
+    }
     const uint32_t rk = room_key(a.seed_lo, a.seed_hi, sg.first_global + room);
     DevRow row = rows[s.phase];
     // the fresh room a finished one is recycled into: wave-uniform, kept in scalar registers
     uint32_t iw[L::WORDS];
 #pragma unroll
     for (int j = 0; j < L::WORDS; j++) iw[j] = __builtin_amdgcn_readfirstlane(sg.init_words[j]);
-    WW<NB> s0;
-    L::unpack(iw, s0);
+    WWR<NB> s0;
+    {
+        WW<NB> u;
+        L::unpack(iw, u);
+        s0.from(u);
+    }
     const DevRow row0 = rows[sg.phase0_idx];
     // Role deals are keyed by (room, game index), so they can be prepared before the turn that applies
     // them.  Entering the role-assignment phase is rare per room (once a game) but in a wavefront of 64
@@ -127,7 +135,8 @@ __device__ __forceinline__ void run_ww(const SegDev *__restrict__ sgp, const Ste
     const bool ahead = a.n_turns >= 16u;                      // not worth it for short launches
     for (uint32_t t = 0; t < a.n_turns; t++) {
         if (ahead && (t & 7u) == 0u && !deal.valid) {
-            const bool dealt = (s.rb0 | s.rb1 | s.rb2) != 0u;  // this game already has roles: prepare the next game's
+            // this game already has roles: prepare the next game's
+            const bool dealt = (NB <= 8 ? s.W[2] : (s.W[WWR<NB>::NW - 2] | s.W[WWR<NB>::NW - 1])) != 0u;
             const uint32_t g = dealt ? (s.games < 0xFFFFu ? s.games + 1u : s.games) : s.games;
             deal_roles<NB, LOWOCC>(deal, deal_key(rk, g), g, sg.n_players, sg.nw, nth8);
         }
@@ -147,7 +156,9 @@ __device__ __forceinline__ void run_ww(const SegDev *__restrict__ sgp, const Ste
         if (a.trace && valid) store_event(sg.trace, sg.rooms_padded, t, room, a.turn0 + t, p, s.phase, restarted, ev_newly, ev_choice);
     }
     if (!valid) return;
-    L::pack(s, w);
+    WW<NB> u;
+    s.to(u);
+    L::pack(u, w);
     store_words<L::WORDS>(sg.base, sg.rooms_padded, room, w);
 }
 
@@ -350,11 +361,12 @@ struct Segment {
     uint64_t local_first;      // index of the segment's room 0 inside the batch
 };
 
-DevRow to_dev_row(const ge_phase_row &r, bool bytes4) {
+DevRow to_dev_row(const ge_phase_row &r, uint32_t kind) {
     // predicate masks per 32-bit word (ge_device.h): 4 bytes (werewolf N<=8) or 2 half-words (all others)
+    const bool bytes4 = kind == K_WW8;
     const int fpw = bytes4 ? 4 : 2;
     const int stride = bytes4 ? 8 : 16;
-    DevRow d = {0, 0, 0, 0};
+    DevRow d = {0, 0, 0, 0, 0, 0, 0, 0};
     d.r0 = (r.completion & 3u) | ((r.act & 7u) << 2) | ((r.effect & 7u) << 5) | ((r.n_terms & 7u) << 8) |
            ((r.n_branches & 7u) << 11);
     for (int j = 0; j < GE_MAX_TERMS; j++) {
@@ -367,6 +379,24 @@ DevRow to_dev_row(const ge_phase_row &r, bool bytes4) {
         if (b < r.n_branches) d.r2 |= (1u << (r.br_res[b] & 7u)) << (8 * b);
         d.r3 |= (uint32_t)r.br_target[b] << (8 * b);
         if (b < r.n_branches && r.br_res[b] == GE_RES_ALL_ROUNDS_DONE) d.r0 |= 1u << 20;
+    }
+    if (kind == K_WW8 || kind == K_WW12) {
+        // v_perm_b32 selector bytes: 0..3 = bytes of the pair's low word, 4..7 = of its high word, 0x0D = 0xFF
+        uint32_t sel[3] = {0x0D0D0D0Du, 0x0D0D0D0Du, 0x0D0D0D0Du};
+        const int fbytes = bytes4 ? 1 : 2;                       // bytes per field
+        const int nfast = bytes4 ? 4 : 2;                        // terms the permute path covers
+        for (int j = 0; j < nfast && j < r.n_terms; j++) {
+            const uint32_t base = r.term_base[j];
+            const uint32_t word = base / fpw, pair = bytes4 ? (word < 2 ? 0u : 1u) : word / 2;
+            const uint32_t in_pair = bytes4 ? (word < 2 ? word : 0u) : word % 2;     // N<=8: W2 is the low word of pair 1
+            const uint32_t byte0 = in_pair * 4u + (base % fpw) * fbytes;
+            for (int k = 0; k < fbytes; k++) {
+                const int ob = j * fbytes + k;                    // output byte
+                sel[pair] = (sel[pair] & ~(0xFFu << (8 * ob))) | ((byte0 + k) << (8 * ob));
+                if (r.term_neg[j]) d.r7 |= 0xFFu << (8 * ob);
+            }
+        }
+        d.r4 = sel[0]; d.r5 = sel[1]; d.r6 = sel[2];
     }
     return d;
 }
@@ -626,7 +656,7 @@ int ge_batch_create(const ge_batch_desc *desc, ge_batch **out) {
             s.dev.base = reinterpret_cast<uint32_t *>(static_cast<char *>(b->state) + reinterpret_cast<size_t>(s.dev.base));
             DevTable &dt = host_tables[k];
             memset(&dt, 0, sizeof dt);
-            for (int r = 0; r < s.table.n_phases; r++) dt.rows[r] = to_dev_row(s.table.rows[r], s.dev.kind == K_WW8);
+            for (int r = 0; r < s.table.n_phases; r++) dt.rows[r] = to_dev_row(s.table.rows[r], s.dev.kind);
             dt.n_phases = s.table.n_phases; dt.rounds = s.table.rounds; dt.n_players = (int32_t)s.dev.n_players;
         }
         if (hipMemcpy(b->tables, host_tables.data(), sizeof(DevTable) * host_tables.size(), hipMemcpyHostToDevice) != hipSuccess) { st = GE_ERR_HIP; break; }
@@ -810,6 +840,10 @@ int ge_batch_read_rooms(ge_batch *b, uint64_t first, uint64_t count, ge_room_vie
 
 int ge_batch_write_rooms(ge_batch *b, uint64_t first, uint64_t count, const ge_room_view *src) {
     if (!b || (!src && count)) return GE_ERR_ARG;
+    for (uint64_t k = 0; k < count; k++)                       // werewolf role classes are 0 (unassigned) .. 4
+        if (src[k].pack == GE_PACK_WEREWOLF)
+            for (int i = 0; i < src[k].n_players && i < 16; i++)
+                if (src[k].players[i][0] > 4) return GE_ERR_ARG;
     return rooms_io(b, first, count, nullptr, src);
 }
 
