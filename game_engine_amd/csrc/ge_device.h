@@ -131,9 +131,9 @@ __device__ __forceinline__ uint32_t plurality(nib_t votes, uint32_t voters) {
 // takes one item per round (reading the owning room's context from LDS), and results go back
 // with LDS atomic ORs.  Wavefront-private: no block barrier, only wave-level ordering.
 struct WaveLds {
-    uint4 ctx[64];            // {alive | team_w<<16, known | r_det<<16, lo_kw | act<<16, turn key}
+    uint4 ctx[64];            // {alive | team_w<<16 | act<<28, known-or-r_det | lo_kw<<16, due mask | first slot<<16, turn key}
     uint4 res[64];            // {go mask, choice nibbles lo, choice nibbles hi, -}
-    uint16_t queue[64 * 13];  // lane | player << 6 ; the last 64 entries are per-lane dummies
+    uint8_t queue[64 * 13];   // slot -> lane of the owning room; 64 * 12 slots at most, read in rounds of 64
 };
 
 __device__ __forceinline__ void wave_sync() {
@@ -278,42 +278,38 @@ __device__ __forceinline__ void ww_turn(WWR<NB> &s, DevRow &row, const DevRow *r
                 total += (uint32_t)__popcll(m) << b;
             }
             if (LOWOCC || total != 0u) {                        // wave-uniform; LOWOCC: some room almost always has a due bot
-                lw->ctx[lane] = make_uint4(alive | (team_w << 16), known | (r_det << 16), lo_kw | (act << 16), tk);
+                // per-room context of an action; `ky`: what the acting role knows (the Detective's memory
+                // at night, who the Detective is by day - ww_choose reads only one of the two per kind)
+                const uint32_t ky = night ? known : r_det;
+                lw->ctx[lane] = make_uint4(alive | (team_w << 16) | (act << 28), ky | (lo_kw << 16), todo | (off << 16), tk);
                 lw->res[lane] = make_uint4(0u, 0u, 0u, 0u);
-                // straight-line, predicated: a loop's taken back-edges are what a lone wavefront
-                // per SIMD (the 65 536-room shape) cannot hide
-                if (LOWOCC) {
-                    // one wavefront per SIMD: every branch instruction stalls it (~50 cycles, nothing
-                    // else to issue), so write unconditionally; an exhausted lane hits its dummy slot
+                // Queue slot -> owning room.  A room with cnt due bots owns slots [off, off + cnt); it writes
+                // its lane id to NB slots from `off` on, highest first (immediate offsets, no per-slot
+                // address or predicate).  The surplus writes land in the ranges of the rooms after it and
+                // are overwritten by their owners: an owner's write to its r-th slot is issued at step r,
+                // any intruder's at a step > r, i.e. earlier.  Rooms without a due bot do not write
+                // (they would tie with the next owner inside one instruction).
+                if (cnt != 0u) {
+                    uint8_t *qp = lw->queue + off;
 #pragma unroll
-                    for (int j = 0; j < NB; j++) {
-                        const uint32_t i = ctz(todo | 0x80000000u);
-                        lw->queue[todo ? off + j : 64u * 12u + lane] = (uint16_t)(lane | (i << 6));
-                        todo &= todo - 1u;
-                    }
-                } else {
-                    // many wavefronts per SIMD: branches are hidden, LDS write slots are not
-#pragma unroll
-                    for (int j = 0; j < NB; j++) {
-                        if (todo) {
-                            const uint32_t i = ctz(todo);
-                            todo &= todo - 1u;
-                            lw->queue[off + j] = (uint16_t)(lane | (i << 6));
-                        }
+                    for (int j = NB - 1; j >= 0; j--) {
+                        qp[j] = (uint8_t)lane;
+                        asm volatile("" ::: "memory");             // the stores must issue in this order
                     }
                 }
                 wave_sync();
                 for (uint32_t base = 0; base < total; base += 64u) {
                     const uint32_t k = base + lane;
-                    // slots past `total` hold stale but in-range entries: read them anyway and drop
-                    // the result, so that the whole item is one predicated block
-                    const uint32_t item = lw->queue[k < total ? k : 64u * 12u + lane];
-                    const uint32_t L = item & 63u, i = (item >> 6) & 15u;
+                    // slots past `total` hold stale lane ids: computed like the others, result dropped
+                    const uint32_t L = lw->queue[k] & 63u;
                     const uint4 c4 = lw->ctx[L];
+                    const uint32_t due = c4.z & 0xFFFFu, rank = (k - (c4.z >> 16)) & 15u;   // this slot = the rank-th due bot of room L
+                    const uint32_t i = (LOWOCC ? nth_set_bit<NB>(due | (1u << 31), rank) : nth_set_bit_lds<NB>(nth8, due, rank)) & 15u;
                     const uint32_t d = draw(c4.w, i);
                     if (k < total && (d & 3u) != 0u) {
-                        const uint32_t c = ww_choose<NB, !LOWOCC>(c4.z >> 16, i, d, c4.x & 0xFFFFu, c4.x >> 16,
-                                                                  c4.y & 0xFFFFu, c4.z & 0xFFFFu, c4.y >> 16, nth8);
+                        const uint32_t know = c4.y & 0xFFFFu;
+                        const uint32_t c = ww_choose<NB, !LOWOCC>(c4.x >> 28, i, d, c4.x & 0xFFFFu, (c4.x >> 16) & 0xFFFu,
+                                                                  know, c4.y >> 16, know, nth8);
                         uint32_t *r = reinterpret_cast<uint32_t *>(&lw->res[L]);
                         atomicOr(r, 1u << i);
                         atomicOr(r + 1 + (i >> 3), c << (4u * (i & 7u)));

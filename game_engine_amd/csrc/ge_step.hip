@@ -550,7 +550,13 @@ static int fill_args(const ge_batch *b, StepArgs &a, uint32_t turn0, uint32_t n_
     a.block_threads = b->block_threads;
     a.restart = (b->flags & GE_FLAG_RESTART) ? 1u : 0u;
     a.trace = (b->flags & GE_FLAG_TRACE) ? 1u : 0u;
-    a.lowocc = b->n_rooms < 3u * 1024u * 64u ? 1u : 0u;      // fewer than ~3 wavefronts per SIMD on 256 CUs
+    // fewer than ~3 wavefronts per SIMD on 256 CUs -> the branch-lean build (ge_device.h LOWOCC);
+    // GE_LOWOCC_ROOMS overrides the threshold (tuning / A-B runs)
+    static const uint64_t low_rooms = [] {
+        const char *e = getenv("GE_LOWOCC_ROOMS");
+        return e ? strtoull(e, nullptr, 10) : (uint64_t)(3u * 1024u * 64u);
+    }();
+    a.lowocc = b->n_rooms < low_rooms ? 1u : 0u;
     return GE_OK;
 }
 
