@@ -217,26 +217,39 @@ __device__ __forceinline__ void run_kind(const SegDev *__restrict__ sg, const St
     else run_tt<12>(sg, a, rows, tables, room);
 }
 
+// LDS of a step block, sized at launch (a 64-room block must not pay for four wavefronts' queues, or
+// LDS, not registers, caps the wavefronts per CU): [phase rows][nth8 table, table builds only][one WaveLds per wavefront]
+constexpr uint32_t LDS_ROWS = sizeof(DevRow) * GE_MAX_PHASES;
+constexpr uint32_t LDS_NTH8 = 2048;
+static_assert(sizeof(WaveLds) % 16 == 0 && LDS_ROWS % 16 == 0, "LDS sections stay 16-byte aligned");
+
+inline uint32_t step_lds_bytes(bool werewolf, bool lowocc, uint32_t block_threads) {
+    if (!werewolf) return LDS_ROWS;
+    return LDS_ROWS + (lowocc ? 0u : LDS_NTH8) + (uint32_t)sizeof(WaveLds) * (block_threads / 64u);
+}
+
+extern __shared__ __align__(16) unsigned char ge_lds[];
+
 // single-kind batch (the benchmark configurations): one instantiation per record layout, so each
 // gets its own register allocation
 template <int KIND, bool LOWOCC>
 __global__ void __launch_bounds__(256) ge_step_kernel(const StepArgs a, const SegDev *__restrict__ segs,
                                                       const DevTable *__restrict__ tables) {
-    __shared__ DevRow rows[GE_MAX_PHASES];
     constexpr bool WWK = KIND == K_WW8 || KIND == K_WW12;
-    __shared__ WaveLds wl[WWK ? 4 : 1];
-    __shared__ uint8_t nth8[WWK ? 2048 : 8];
+    DevRow *rows = reinterpret_cast<DevRow *>(ge_lds);
+    uint8_t *nth8 = ge_lds + LDS_ROWS;
+    WaveLds *wl = reinterpret_cast<WaveLds *>(ge_lds + LDS_ROWS + (LOWOCC ? 0u : LDS_NTH8));
     const uint64_t room = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    run_kind<KIND, LOWOCC>(segs, a, rows, &wl[WWK ? (threadIdx.x >> 6) : 0], nth8, tables, room);
+    run_kind<KIND, LOWOCC>(segs, a, rows, WWK ? &wl[threadIdx.x >> 6] : nullptr, nth8, tables, room);
 }
 
 // mixed batch: several segments (games / player counts) in one launch
 template <bool LOWOCC>
 __global__ void __launch_bounds__(256) ge_step_kernel_mixed(const StepArgs a, const SegDev *__restrict__ segs,
                                                             const DevTable *__restrict__ tables) {
-    __shared__ DevRow rows[GE_MAX_PHASES];
-    __shared__ WaveLds wl[4];
-    __shared__ uint8_t nth8[2048];
+    DevRow *rows = reinterpret_cast<DevRow *>(ge_lds);
+    uint8_t *nth8 = ge_lds + LDS_ROWS;
+    WaveLds *wl = reinterpret_cast<WaveLds *>(ge_lds + LDS_ROWS + (LOWOCC ? 0u : LDS_NTH8));
     uint32_t si = 0;
     for (uint32_t k = 1; k < a.n_seg; k++)
         if (blockIdx.x >= a.block_begin[k]) si = k;
@@ -550,11 +563,12 @@ static int fill_args(const ge_batch *b, StepArgs &a, uint32_t turn0, uint32_t n_
     a.block_threads = b->block_threads;
     a.restart = (b->flags & GE_FLAG_RESTART) ? 1u : 0u;
     a.trace = (b->flags & GE_FLAG_TRACE) ? 1u : 0u;
-    // fewer than ~3 wavefronts per SIMD on 256 CUs -> the branch-lean build (ge_device.h LOWOCC);
+    // at most ~1 wavefront per SIMD on 256 CUs -> the branch-lean build (ge_device.h LOWOCC); from two
+    // wavefronts per SIMD on the other build is faster (measured: 131 072 rooms 1.87 vs 1.99 us/turn).
     // GE_LOWOCC_ROOMS overrides the threshold (tuning / A-B runs)
     static const uint64_t low_rooms = [] {
         const char *e = getenv("GE_LOWOCC_ROOMS");
-        return e ? strtoull(e, nullptr, 10) : (uint64_t)(3u * 1024u * 64u);
+        return e ? strtoull(e, nullptr, 10) : (uint64_t)(1024u * 64u * 3u / 2u);
     }();
     a.lowocc = b->n_rooms < low_rooms ? 1u : 0u;
     return GE_OK;
@@ -740,17 +754,17 @@ int ge_batch_step(ge_batch *b, uint32_t n_turns, void *hip_stream) {
             HIP_TRY(hipEventRecord(e0, st));
         }
         const dim3 grid(b->n_blocks), block(b->block_threads);
-#define GE_LAUNCH(KERNEL) hipLaunchKernelGGL(KERNEL, grid, block, 0, st, a, b->segs_dev, b->tables)
+#define GE_LAUNCH(KERNEL, WWK) hipLaunchKernelGGL(KERNEL, grid, block, step_lds_bytes(WWK, low, b->block_threads), st, a, b->segs_dev, b->tables)
         const bool low = a.lowocc != 0u;
         if (b->segs.size() > 1) {
-            if (low) GE_LAUNCH(ge_step_kernel_mixed<true>); else GE_LAUNCH(ge_step_kernel_mixed<false>);
+            if (low) GE_LAUNCH(ge_step_kernel_mixed<true>, true); else GE_LAUNCH(ge_step_kernel_mixed<false>, true);
         } else {
             switch (b->segs[0].dev.kind) {
-            case K_WW8: if (low) GE_LAUNCH((ge_step_kernel<K_WW8, true>)); else GE_LAUNCH((ge_step_kernel<K_WW8, false>)); break;
-            case K_WW12: if (low) GE_LAUNCH((ge_step_kernel<K_WW12, true>)); else GE_LAUNCH((ge_step_kernel<K_WW12, false>)); break;
-            case K_TT4: GE_LAUNCH((ge_step_kernel<K_TT4, false>)); break;
-            case K_TT8: GE_LAUNCH((ge_step_kernel<K_TT8, false>)); break;
-            default: GE_LAUNCH((ge_step_kernel<K_TT12, false>)); break;
+            case K_WW8: if (low) GE_LAUNCH((ge_step_kernel<K_WW8, true>), true); else GE_LAUNCH((ge_step_kernel<K_WW8, false>), true); break;
+            case K_WW12: if (low) GE_LAUNCH((ge_step_kernel<K_WW12, true>), true); else GE_LAUNCH((ge_step_kernel<K_WW12, false>), true); break;
+            case K_TT4: GE_LAUNCH((ge_step_kernel<K_TT4, false>), false); break;
+            case K_TT8: GE_LAUNCH((ge_step_kernel<K_TT8, false>), false); break;
+            default: GE_LAUNCH((ge_step_kernel<K_TT12, false>), false); break;
             }
         }
 #undef GE_LAUNCH

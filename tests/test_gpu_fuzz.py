@@ -68,9 +68,11 @@ def _random_tt_views(orc, n, R, rng, rounds):
     return v
 
 
-@pytest.mark.parametrize("n,consistent", [(8, True), (8, False), (12, True), (12, False), (4, True), (6, False)])
-def test_werewolf_from_random_states(dsl_ww, n, consistent):
-    R, seed, first = 20000, 99, 777
+# R below / above the room count at which the launcher switches kernel builds (branch-lean vs LDS tables)
+@pytest.mark.parametrize("n,consistent,R", [(8, True, 20000), (8, False, 20000), (12, True, 20000), (12, False, 20000),
+                                            (4, True, 20000), (6, False, 20000), (8, False, 120000), (12, False, 110000)])
+def test_werewolf_from_random_states(dsl_ww, n, consistent, R):
+    seed, first = 99, 777
     rng = np.random.default_rng(n * 2 + consistent)
     orc = _oracle(dsl_ww, n)
     views = _random_ww_views(orc, n, R, rng, consistent)
