@@ -131,10 +131,18 @@ __device__ __forceinline__ uint32_t plurality(nib_t votes, uint32_t voters) {
 // takes one item per round (reading the owning room's context from LDS), and results go back
 // with LDS atomic ORs.  Wavefront-private: no block barrier, only wave-level ordering.
 struct WaveLds {
-    uint4 ctx[64];            // {alive | team_w<<16 | act<<28, known-or-r_det | lo_kw<<16, due mask | first slot<<16, turn key}
+    uint4 ctx[64];            // {alive | team_w<<16 | act<<28, known-or-r_det | lo_kw<<16, due mask | first slot<<16 | lane<<26, turn key}
     uint4 res[64];            // {go mask, choice nibbles lo, choice nibbles hi, -}
     uint8_t queue[64 * 13];   // slot -> lane of the owning room; 64 * 12 slots at most, read in rounds of 64
 };
+// The lone-wavefront build pays ~150 cycles for every dependent LDS round trip and has LDS to spare, so
+// there a slot holds the owning room's whole context (one read per item instead of lane id -> context).
+struct WaveLdsLow {
+    uint4 slot[64 * 13];
+    uint4 res[64];
+};
+template <bool LOWOCC> struct WaveLdsOf { using type = WaveLds; };
+template <> struct WaveLdsOf<true> { using type = WaveLdsLow; };
 
 __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -194,7 +202,7 @@ __device__ __forceinline__ void deal_roles(Deal &d, uint32_t dk, uint32_t game, 
 // stalls on every branch instruction and every dependent LDS access, so that build is branch-lean
 // and computes; the other build (many wavefronts, VALU-bound) prefers LDS tables and skip-branches.
 template <int NB, bool QUEUE, bool LOWOCC>
-__device__ __forceinline__ void ww_turn(WWR<NB> &s, DevRow &row, const DevRow *rows, WaveLds *lw, const uint8_t *nth8, bool valid, uint32_t n,
+__device__ __forceinline__ void ww_turn(WWR<NB> &s, DevRow &row, const DevRow *rows, void *wave_lds, const uint8_t *nth8, bool valid, uint32_t n,
                                         uint32_t nw, uint32_t phase0_idx, uint32_t rkey, uint32_t turn,
                                         bool trace, uint32_t human, Deal &deal, uint32_t &ev_newly, uint64_t &ev_choice) {
     // human: players the host drives (never acted for here)
@@ -202,6 +210,7 @@ __device__ __forceinline__ void ww_turn(WWR<NB> &s, DevRow &row, const DevRow *r
     // `row` is the table row of s.phase, kept in registers across turns: LDS is read only on a transition
     using nib_t = typename WWR<NB>::nib_t;
     using R = WWR<NB>;
+    auto *lw = static_cast<typename WaveLdsOf<LOWOCC>::type *>(wave_lds);
     const uint32_t ALL = (1u << n) - 1u;
     const uint32_t comp = row.r0 & 3u, act = (row.r0 >> 2) & 7u, p_eff = (row.r0 >> 5) & 7u;
     const uint32_t nterms = (row.r0 >> 8) & 7u;
@@ -281,35 +290,63 @@ __device__ __forceinline__ void ww_turn(WWR<NB> &s, DevRow &row, const DevRow *r
                 // per-room context of an action; `ky`: what the acting role knows (the Detective's memory
                 // at night, who the Detective is by day - ww_choose reads only one of the two per kind)
                 const uint32_t ky = night ? known : r_det;
-                lw->ctx[lane] = make_uint4(alive | (team_w << 16) | (act << 28), ky | (lo_kw << 16), todo | (off << 16), tk);
+                const uint4 ctx = make_uint4(alive | (team_w << 16) | (act << 28), ky | (lo_kw << 16), todo | (off << 16) | (lane << 26), tk);
                 lw->res[lane] = make_uint4(0u, 0u, 0u, 0u);
                 // Queue slot -> owning room.  A room with cnt due bots owns slots [off, off + cnt); it writes
-                // its lane id to NB slots from `off` on, highest first (immediate offsets, no per-slot
-                // address or predicate).  The surplus writes land in the ranges of the rooms after it and
-                // are overwritten by their owners: an owner's write to its r-th slot is issued at step r,
+                // NB slots from `off` on, highest first (immediate offsets, no per-slot address or
+                // predicate).  The surplus writes land in the ranges of the rooms after it and are
+                // overwritten by their owners: an owner's write to its r-th slot is issued at step r,
                 // any intruder's at a step > r, i.e. earlier.  Rooms without a due bot do not write
                 // (they would tie with the next owner inside one instruction).
-                if (cnt != 0u) {
-                    uint8_t *qp = lw->queue + off;
+                if (LOWOCC) {
+                    auto *lo = reinterpret_cast<WaveLdsLow *>(lw);
+                    if (cnt != 0u) {
+                        uint4 *qp = lo->slot + off;
 #pragma unroll
-                    for (int j = NB - 1; j >= 0; j--) {
-                        qp[j] = (uint8_t)lane;
-                        asm volatile("" ::: "memory");             // the stores must issue in this order
+                        for (int j = NB - 1; j >= 0; j--) {
+                            qp[j] = ctx;
+                            asm volatile("" ::: "memory");         // the stores must issue in this order
+                        }
+                    }
+                } else {
+                    auto *hi = reinterpret_cast<WaveLds *>(lw);
+                    hi->ctx[lane] = ctx;
+                    if (cnt != 0u) {
+                        uint8_t *qp = hi->queue + off;
+#pragma unroll
+                        for (int j = NB - 1; j >= 0; j--) {
+                            qp[j] = (uint8_t)lane;
+                            asm volatile("" ::: "memory");
+                        }
                     }
                 }
                 wave_sync();
                 for (uint32_t base = 0; base < total; base += 64u) {
                     const uint32_t k = base + lane;
-                    // slots past `total` hold stale lane ids: computed like the others, result dropped
-                    const uint32_t L = lw->queue[k] & 63u;
-                    const uint4 c4 = lw->ctx[L];
-                    const uint32_t due = c4.z & 0xFFFFu, rank = (k - (c4.z >> 16)) & 15u;   // this slot = the rank-th due bot of room L
+                    // slots past `total` hold stale entries: computed like the others, result dropped
+                    uint4 c4;
+                    if (LOWOCC) c4 = reinterpret_cast<WaveLdsLow *>(lw)->slot[k];
+                    else { auto *hi = reinterpret_cast<WaveLds *>(lw); c4 = hi->ctx[hi->queue[k] & 63u]; }
+                    const uint32_t L = c4.z >> 26;
+                    const uint32_t due = c4.z & 0xFFFFu, rank = (k - ((c4.z >> 16) & 0x3FFu)) & 15u;   // this slot = the rank-th due bot of room L
                     const uint32_t i = (LOWOCC ? nth_set_bit<NB>(due | (1u << 31), rank) : nth_set_bit_lds<NB>(nth8, due, rank)) & 15u;
                     const uint32_t d = draw(c4.w, i);
-                    if (k < total && (d & 3u) != 0u) {
+                    const bool go = k < total && (d & 3u) != 0u;
+                    if (LOWOCC) {
+                        // the choice is computed for every slot and only the result is predicated: a
+                        // conditional block would split the slot read in two dependent LDS round trips
                         const uint32_t know = c4.y & 0xFFFFu;
-                        const uint32_t c = ww_choose<NB, !LOWOCC>(c4.x >> 28, i, d, c4.x & 0xFFFFu, (c4.x >> 16) & 0xFFFu,
-                                                                  know, c4.y >> 16, know, nth8);
+                        const uint32_t c = ww_choose<NB, false>(c4.x >> 28, i, d, c4.x & 0xFFFFu, (c4.x >> 16) & 0xFFFu,
+                                                                know, c4.y >> 16, know, nth8);
+                        if (go) {
+                            uint32_t *r = reinterpret_cast<uint32_t *>(&lw->res[L]);
+                            atomicOr(r, 1u << i);
+                            atomicOr(r + 1 + (i >> 3), c << (4u * (i & 7u)));
+                        }
+                    } else if (go) {
+                        const uint32_t know = c4.y & 0xFFFFu;
+                        const uint32_t c = ww_choose<NB, true>(c4.x >> 28, i, d, c4.x & 0xFFFFu, (c4.x >> 16) & 0xFFFu,
+                                                               know, c4.y >> 16, know, nth8);
                         uint32_t *r = reinterpret_cast<uint32_t *>(&lw->res[L]);
                         atomicOr(r, 1u << i);
                         atomicOr(r + 1 + (i >> 3), c << (4u * (i & 7u)));
@@ -346,7 +383,7 @@ __device__ __forceinline__ void ww_turn(WWR<NB> &s, DevRow &row, const DevRow *r
     // ---- PhaseNode: phase-0 guard (v2:1025-1052): first turn only records phase 0, Referee skipped
     const bool guard = s.phase == phase0_idx && !(s.flags & FLAG_PHASE0_DONE);
     s.flags |= FLAG_PHASE0_DONE;                               // set by the guard turn; already set afterwards
-    uint32_t q = s.phase;
+    uint32_t qe = s.phase;                                     // next row index | its entry effect << 5
     {   // evaluated for every lane, selected at the end (one branch less than a guarded block)
         const bool open = !guard && (comp != COMP_ACTION || (T & ~s.acted) == 0u);
         const uint32_t w = popc(alive & team_w), g = popc(alive & s.template get<F_TEAM_V>());
@@ -358,8 +395,9 @@ __device__ __forceinline__ void ww_turn(WWR<NB> &s, DevRow &row, const DevRow *r
         // its resolver set (0 for absent branches), so the lowest non-zero byte of r2 & (C in every byte) wins
         const uint32_t hit = row.r2 & (C * 0x01010101u);
         const uint32_t sh = ctz(hit) & 24u;
-        q = (open && hit != 0u) ? ((row.r3 >> sh) & 255u) : q;
+        qe = (open && hit != 0u) ? ((row.r3 >> sh) & 255u) : qe;
     }
+    const uint32_t q = qe & 31u;
     {   // investigated_alignments[c] = team(c): an assignment, so a stale entry is replaced
         // (the guard turn has no actions: both masks are 0)
         const uint32_t seen = new_det_v | new_det_w;
@@ -369,9 +407,8 @@ __device__ __forceinline__ void ww_turn(WWR<NB> &s, DevRow &row, const DevRow *r
     if (q == s.phase) return;
 
     // ---- RefereeNode (B): effect of entering q
-    const DevRow qrow = rows[q];
-    const uint32_t q0 = qrow.r0;
-    const uint32_t eff = (q0 >> 5) & 7u;
+    const DevRow qrow = rows[q];                               // LDS read in flight during the effect: first used at the end
+    const uint32_t eff = qe >> 5;
     if (eff == EFF_ASSIGN_ROLES) {
         // the deal of this game was normally prepared ahead (run loop, every 8th turn, for all lanes
         // of the wavefront at once); fall back to dealing here if it was not
@@ -401,7 +438,7 @@ __device__ __forceinline__ void ww_turn(WWR<NB> &s, DevRow &row, const DevRow *r
     s.prev = s.phase;
     s.phase = q;
     row = qrow;
-    s.end_turn = (((q0 >> 11) & 7u) == 0u && s.end_turn == END_NONE) ? (turn < 0xFFFEu ? turn : 0xFFFEu) : s.end_turn;
+    s.end_turn = (((qrow.r0 >> 11) & 7u) == 0u && s.end_turn == END_NONE) ? (turn < 0xFFFEu ? turn : 0xFFFEu) : s.end_turn;
 }
 
 // ------------------------------------------------------------------ two truths and a lie
@@ -476,7 +513,7 @@ __device__ __forceinline__ void tt_turn(TT<NB> &s, DevRow &row, const DevRow *ro
         const uint32_t C = 1u | (all_done << RES_ALL_ROUNDS_DONE) | (1u << RES_OTHERWISE);
         const uint32_t hit = row.r2 & (C * 0x01010101u);       // see ww_turn
         const uint32_t sh = ctz(hit) & 24u;
-        q = hit != 0u ? ((row.r3 >> sh) & 255u) : q;
+        q = hit != 0u ? ((row.r3 >> sh) & 31u) : q;
     }
     if (q == s.phase) return;
 

@@ -231,7 +231,8 @@ template <> struct TTLayout<12> {
 //   r0 bit 20: some branch asks "all rounds done?" (two-truths)
 //   r1: per term a byte {word index [7:5] (7 = no term), shift [4:0]} into the packed predicate words
 //       (two-truths, and werewolf N<=12 terms 2..3)
-//   r2: 4 x 8 bits, byte b = 1 << resolver of branch b (0: no such branch)   r3: br_target 4 x 8 bits
+//   r2: 4 x 8 bits, byte b = 1 << resolver of branch b (0: no such branch)
+//   r3: 4 x 8 bits, byte b = target row index [4:0] | the target's entry effect [7:5]
 //   r4..r6: werewolf: v_perm_b32 selectors that gather each term's mask out of the packed predicate
 //       word pairs (W1:W0), (W3:W2), (W5:W4) - a term's bytes in the pair that holds its predicate,
 //       0xFF bytes (selector 0x0D) in the others, so the AND of the three permutes is the term.

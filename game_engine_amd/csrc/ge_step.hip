@@ -97,7 +97,7 @@ __device__ __forceinline__ void load_rows(DevRow *rows, const DevTable *tables, 
 }
 
 template <int NB, bool LOWOCC>
-__device__ __forceinline__ void run_ww(const SegDev *__restrict__ sgp, const StepArgs &a, DevRow *rows, WaveLds *lw,
+__device__ __forceinline__ void run_ww(const SegDev *__restrict__ sgp, const StepArgs &a, DevRow *rows, void *lw,
                                        uint8_t *nth8, const DevTable *__restrict__ tables, uint64_t room_in) {
     const SegDev &sg = *sgp;
     using L = WWLayout<NB>;
@@ -208,7 +208,7 @@ __device__ __forceinline__ void run_tt(const SegDev *__restrict__ sgp, const Ste
 // device memory and are read with a block-uniform index (scalar loads): indexing the kernel
 // arguments dynamically would push them through scratch.
 template <int KIND, bool LOWOCC>
-__device__ __forceinline__ void run_kind(const SegDev *__restrict__ sg, const StepArgs &a, DevRow *rows, WaveLds *lw,
+__device__ __forceinline__ void run_kind(const SegDev *__restrict__ sg, const StepArgs &a, DevRow *rows, void *lw,
                                          uint8_t *nth8, const DevTable *__restrict__ tables, uint64_t room) {
     if (KIND == K_WW8) run_ww<8, LOWOCC>(sg, a, rows, lw, nth8, tables, room);
     else if (KIND == K_WW12) run_ww<12, LOWOCC>(sg, a, rows, lw, nth8, tables, room);
@@ -221,11 +221,11 @@ __device__ __forceinline__ void run_kind(const SegDev *__restrict__ sg, const St
 // LDS, not registers, caps the wavefronts per CU): [phase rows][nth8 table, table builds only][one WaveLds per wavefront]
 constexpr uint32_t LDS_ROWS = sizeof(DevRow) * GE_MAX_PHASES;
 constexpr uint32_t LDS_NTH8 = 2048;
-static_assert(sizeof(WaveLds) % 16 == 0 && LDS_ROWS % 16 == 0, "LDS sections stay 16-byte aligned");
+static_assert(sizeof(WaveLds) % 16 == 0 && sizeof(WaveLdsLow) % 16 == 0 && LDS_ROWS % 16 == 0, "LDS sections stay 16-byte aligned");
 
 inline uint32_t step_lds_bytes(bool werewolf, bool lowocc, uint32_t block_threads) {
     if (!werewolf) return LDS_ROWS;
-    return LDS_ROWS + (lowocc ? 0u : LDS_NTH8) + (uint32_t)sizeof(WaveLds) * (block_threads / 64u);
+    return LDS_ROWS + (lowocc ? 0u : LDS_NTH8) + (uint32_t)(lowocc ? sizeof(WaveLdsLow) : sizeof(WaveLds)) * (block_threads / 64u);
 }
 
 extern __shared__ __align__(16) unsigned char ge_lds[];
@@ -238,7 +238,7 @@ __global__ void __launch_bounds__(256) ge_step_kernel(const StepArgs a, const Se
     constexpr bool WWK = KIND == K_WW8 || KIND == K_WW12;
     DevRow *rows = reinterpret_cast<DevRow *>(ge_lds);
     uint8_t *nth8 = ge_lds + LDS_ROWS;
-    WaveLds *wl = reinterpret_cast<WaveLds *>(ge_lds + LDS_ROWS + (LOWOCC ? 0u : LDS_NTH8));
+    auto *wl = reinterpret_cast<typename WaveLdsOf<LOWOCC>::type *>(ge_lds + LDS_ROWS + (LOWOCC ? 0u : LDS_NTH8));
     const uint64_t room = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     run_kind<KIND, LOWOCC>(segs, a, rows, WWK ? &wl[threadIdx.x >> 6] : nullptr, nth8, tables, room);
 }
@@ -249,14 +249,14 @@ __global__ void __launch_bounds__(256) ge_step_kernel_mixed(const StepArgs a, co
                                                             const DevTable *__restrict__ tables) {
     DevRow *rows = reinterpret_cast<DevRow *>(ge_lds);
     uint8_t *nth8 = ge_lds + LDS_ROWS;
-    WaveLds *wl = reinterpret_cast<WaveLds *>(ge_lds + LDS_ROWS + (LOWOCC ? 0u : LDS_NTH8));
+    auto *wl = reinterpret_cast<typename WaveLdsOf<LOWOCC>::type *>(ge_lds + LDS_ROWS + (LOWOCC ? 0u : LDS_NTH8));
     uint32_t si = 0;
     for (uint32_t k = 1; k < a.n_seg; k++)
         if (blockIdx.x >= a.block_begin[k]) si = k;
     si = __builtin_amdgcn_readfirstlane(si);
     const SegDev *sg = segs + si;
     const uint64_t room = (uint64_t)(blockIdx.x - a.block_begin[si]) * blockDim.x + threadIdx.x;
-    WaveLds *lw = &wl[threadIdx.x >> 6];
+    void *lw = &wl[threadIdx.x >> 6];
     switch (sg->kind) {
     case K_WW8: run_kind<K_WW8, LOWOCC>(sg, a, rows, lw, nth8, tables, room); break;
     case K_WW12: run_kind<K_WW12, LOWOCC>(sg, a, rows, lw, nth8, tables, room); break;
@@ -374,7 +374,7 @@ struct Segment {
     uint64_t local_first;      // index of the segment's room 0 inside the batch
 };
 
-DevRow to_dev_row(const ge_phase_row &r, uint32_t kind) {
+DevRow to_dev_row(const ge_game_table &tb, const ge_phase_row &r, uint32_t kind) {
     // predicate masks per 32-bit word (ge_device.h): 4 bytes (werewolf N<=8) or 2 half-words (all others)
     const bool bytes4 = kind == K_WW8;
     const int fpw = bytes4 ? 4 : 2;
@@ -390,7 +390,9 @@ DevRow to_dev_row(const ge_phase_row &r, uint32_t kind) {
     }
     for (int b = 0; b < GE_MAX_BRANCHES; b++) {
         if (b < r.n_branches) d.r2 |= (1u << (r.br_res[b] & 7u)) << (8 * b);
-        d.r3 |= (uint32_t)r.br_target[b] << (8 * b);
+        // target row index, and the target's entry effect (so the effect can start before the row load returns)
+        const uint32_t tgt = r.br_target[b] & 31u;
+        d.r3 |= (tgt | ((uint32_t)(tb.rows[tgt].effect & 7u) << 5)) << (8 * b);
         if (b < r.n_branches && r.br_res[b] == GE_RES_ALL_ROUNDS_DONE) d.r0 |= 1u << 20;
     }
     if (kind == K_WW8 || kind == K_WW12) {
@@ -676,7 +678,7 @@ int ge_batch_create(const ge_batch_desc *desc, ge_batch **out) {
             s.dev.base = reinterpret_cast<uint32_t *>(static_cast<char *>(b->state) + reinterpret_cast<size_t>(s.dev.base));
             DevTable &dt = host_tables[k];
             memset(&dt, 0, sizeof dt);
-            for (int r = 0; r < s.table.n_phases; r++) dt.rows[r] = to_dev_row(s.table.rows[r], s.dev.kind);
+            for (int r = 0; r < s.table.n_phases; r++) dt.rows[r] = to_dev_row(s.table, s.table.rows[r], s.dev.kind);
             dt.n_phases = s.table.n_phases; dt.rounds = s.table.rounds; dt.n_players = (int32_t)s.dev.n_players;
         }
         if (hipMemcpy(b->tables, host_tables.data(), sizeof(DevTable) * host_tables.size(), hipMemcpyHostToDevice) != hipSuccess) { st = GE_ERR_HIP; break; }
