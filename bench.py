@@ -91,15 +91,22 @@ def cpu_baseline(dsl, budget_s=12.0):
             "single_thread_value": 4096 * t1 / dt_one}
 
 
-def pmc_traffic(bytes_per_room):
+def pmc_traffic(alg_bytes_per_launch):
     """HBM bytes per launch from a committed rocprofv3 --pmc pass of this same command
-    (profiles/*pmc_traffic.json, written by tools/pmc_summary.py), or None."""
+    (profiles/pmc_traffic.json, written by tools/pmc_summary.py), or None.  The state is read once and
+    written once per launch whatever the number of fused turns, so the counters only describe a run
+    with the same rooms x record bytes: the file records the launch's read+write floor and is ignored
+    when this run's differs."""
     p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if not os.path.exists(p):
         return None
     try:
         with open(p) as f:
-            return json.load(f).get("bytes_per_launch")
+            d = json.load(f)
+        floor = d.get("state_bytes_read_plus_written")
+        if floor is not None and abs(floor - alg_bytes_per_launch) > 1e-6 * alg_bytes_per_launch:
+            return None
+        return d.get("bytes_per_launch")
     except Exception:
         return None
 
@@ -109,7 +116,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4096)
     ap.add_argument("--warmup", type=int, default=256)
-    ap.add_argument("--fuse", type=int, default=64, help="turns fused per launch (1 = one launch per turn)")
+    ap.add_argument("--fuse", type=int, default=256, help="turns fused per launch (1 = one launch per turn)")
     ap.add_argument("--rooms", type=int, default=None, help="rooms per GPU (overrides the workload's count; c2 only)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2", help="BASELINE.json config (default c2 = configs[1])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -266,7 +273,7 @@ def main():
                        "bytes_per_room_record": bytes_per_room, "sharding": f"rooms x{world}, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_copy_peak": achieved / 6290.0,
-                         "traffic": pmc_traffic(bytes_per_room),
+                         "traffic": pmc_traffic(2.0 * bytes_per_room * rooms),
                          "kernel": "ge_step_kernel", "avg_launch_us": avg_launch_s * 1e6, "launches": launches,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "algorithmic bytes = 2 x record x rooms x turns in the launch; with fused turns the "

@@ -46,7 +46,10 @@ if "FETCH_SIZE" in res and "WRITE_SIZE" in res:
     write_b = res["WRITE_SIZE"]["median"] * 1024
     res["hbm_bytes_per_launch"] = {"read": fetch_b, "write": write_b, "total": fetch_b + write_b}
     with open(os.path.join(prof, "pmc_traffic.json"), "w") as f:
+        # the launch's floor: every room record read once and written once (65 536 x 32 B for the default bench)
+        floor = float(os.environ.get("GE_STATE_BYTES", 2 * 65536 * 32))
         json.dump({"tag": tag, "bytes_per_launch": fetch_b + write_b, "read": fetch_b, "write": write_b,
+                   "state_bytes_read_plus_written": floor,
                    "correction": "FETCH_SIZE KiB x1024 x2 (gfx950 half-count for 16 B/lane streams), WRITE_SIZE KiB x1024"}, f)
 for b in ("bench_kt.json",):
     p = os.path.join(src, b)
