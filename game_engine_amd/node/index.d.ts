@@ -58,6 +58,11 @@ export class RoomBatch {
 export function turnToolCalls(table: GameTable, before: RoomState, after: RoomState, event: TurnEvent): ToolCall[];
 export function loadDslByGamename(gamename: string, gamesDir?: string): object;
 export function deviceCount(): number;
+/** route.ts:62-70 file matching (case-insensitive, non-alphanumerics equal '-') */
+export function findGameFile(gameName: string, gamesDir?: string): string | null;
+export interface RoomPlayer { id?: string; name: string; isHost?: boolean; gamePlayerId?: string; }
+/** POST /api/games/initialize-players (route.ts:83-166) without the HTTP layer */
+export function initializePlayers(dsl: object, roomPlayers: RoomPlayer[]): { player_states: Record<string, Record<string, unknown>>; fallback_mode?: boolean; message?: string };
 export function compileCriteria(expr: string): (player: Record<string, unknown>) => boolean;
 export function audienceGroups(dsl: object, playerStates: Record<string, Record<string, unknown>>): Record<string, string[]>;
 export interface FrontendToolCall { name: string; args: { audience_type?: boolean; audience_ids?: string[]; [k: string]: unknown }; }

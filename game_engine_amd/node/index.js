@@ -32,6 +32,61 @@ function loadDslByGamename(gamename, gamesDir) {
   return {};
 }
 
+/** Game name -> file in the games directory, as the reference's TS routes match it
+ * (src/app/api/games/initialize-players/route.ts:62-70): case-insensitive, every character outside
+ * [a-z0-9] equals '-'.  Returns the file name or null. */
+function findGameFile(gameName, gamesDir) {
+  const dir = gamesDir || process.env.GE_GAMES_DIR || 'games';
+  const norm = (x) => String(x).toLowerCase().replace(/[^a-z0-9]/g, '-');
+  const want = norm(gameName);
+  for (const f of fs.readdirSync(dir)) {
+    if (norm(f.toLowerCase().replace('.yaml', '')) === want) return f;
+  }
+  return null;
+}
+
+/** player_states for the real players of a room, as POST /api/games/initialize-players builds them
+ * (route.ts:83-166): template = declaration.player_states_template.player_states['1'], else its first
+ * entry, else defaults generated from the declaration.player_states schema (string '' / num 0 /
+ * boolean true / list [] / dict {}, or the field's `example`), else {player_states: {}, fallback_mode: true}.
+ * Every player gets a copy of the template plus name, id, isHost; keys are gamePlayerId or the
+ * 1-based position.  (The Python host's initialize_player_states_from_dsl is the agent-side twin,
+ * agent/tools/utils.py:584-653.) */
+function initializePlayers(dsl, roomPlayers) {
+  const decl = (dsl && dsl.declaration) || {};
+  let template;
+  const tpl = decl.player_states_template && decl.player_states_template.player_states;
+  if (tpl) {
+    template = tpl['1'];
+    if (!template) {
+      const ids = Object.keys(tpl);
+      if (ids.length) template = tpl[ids[0]];
+    }
+  }
+  if (!template && decl.player_states) {
+    template = {};
+    for (const [field, def] of Object.entries(decl.player_states)) {
+      const type = (def && def.type) || 'string';
+      const ex = def ? def.example : undefined;
+      if (type === 'string') template[field] = ex || '';
+      else if (type === 'num' || type === 'number') template[field] = ex || 0;
+      else if (type === 'boolean') template[field] = ex !== undefined ? ex : true;
+      else if (type === 'array' || type === 'list') template[field] = ex || [];
+      else if (type === 'object' || type === 'dict') template[field] = ex || {};
+      else template[field] = ex || null;
+    }
+  }
+  if (!template || !Object.keys(template).length) {
+    return { player_states: {}, fallback_mode: true, message: 'No template found, agent will generate player_states' };
+  }
+  const out = {};
+  roomPlayers.forEach((pl, k) => {
+    const pid = pl.gamePlayerId || String(k + 1);
+    out[pid] = Object.assign(JSON.parse(JSON.stringify(template)), { name: pl.name, id: pl.id || pid, isHost: pl.isHost || false });
+  });
+  return { player_states: out };
+}
+
 const TEAMS = ['', 'villagers', 'werewolves'];
 const VIEW = { size: addon.roomViewSize(), players: 20, det: 20 + 16 * 12 };
 
@@ -193,5 +248,5 @@ class RoomBatch {
 
 const { compileCriteria, audienceGroups, uiToolCalls } = require('./ui_script.js');
 
-module.exports = { GameTable, RoomBatch, loadDslByGamename, turnToolCalls, compileCriteria, audienceGroups, uiToolCalls,
+module.exports = { GameTable, RoomBatch, loadDslByGamename, findGameFile, initializePlayers, turnToolCalls, compileCriteria, audienceGroups, uiToolCalls,
                    deviceCount: addon.deviceCount, addon };

@@ -5,6 +5,15 @@ const { GameTable, RoomBatch, deviceCount, turnToolCalls } = require('./index.js
 const dsl = JSON.parse(fs.readFileSync(process.argv[2], 'utf8'));
 const table = new GameTable(dsl);
 const out = { phases: table.info.phases.length, pack: table.info.pack, devices: deviceCount() };
+{ // room setup helpers (no GPU): initialize-players twin and game-file matching
+  const { initializePlayers, findGameFile } = require('./index.js');
+  const players = [{ id: 'u-7', name: 'Ann', isHost: true, gamePlayerId: '1' }, { name: 'Bob' }, { id: 'u-9', name: 'Cy', gamePlayerId: '3' }];
+  out.init = initializePlayers(dsl, players);
+  const bare = JSON.parse(JSON.stringify(dsl)); delete bare.declaration.player_states_template;
+  out.initFromSchema = initializePlayers(bare, players.slice(0, 1));
+  out.initFallback = initializePlayers({ declaration: {} }, players);
+  if (process.env.GE_TEST_GAMES_DIR) out.found = [findGameFile('Werewolf (Mafia)', process.env.GE_TEST_GAMES_DIR), findGameFile('chess', process.env.GE_TEST_GAMES_DIR)];
+}
 if (deviceCount() === 0) {
   try { new RoomBatch({ segments: [{ table, nPlayers: 8, nRooms: 4 }] }); out.noDevice = 'created?!'; } catch (e) { out.noDevice = e.code; }
   console.log(JSON.stringify(out));

@@ -30,6 +30,39 @@ def test_addon_loads_and_compiles_without_gpu():
 
 
 @needs_node
+def test_initialize_players_twin(tmp_path, monkeypatch):
+    """initializePlayers = POST /api/games/initialize-players (route.ts:83-166) without HTTP: the
+    template copy must agree with the agent-side initialize_player_states_from_dsl (utils.py:584-653)
+    on every declared field; name / id / isHost come from the room's players."""
+    from game_engine_amd import initialize_player_states_from_dsl
+    (tmp_path / "Werewolf-(Mafia).yaml").write_text("x: 1\n")
+    (tmp_path / "two-truths-and-a-lie.yaml").write_text("x: 1\n")
+    monkeypatch.setenv("GE_TEST_GAMES_DIR", str(tmp_path))
+    dsl_path = os.path.join(GOLD, "dsl", "werewolf-(mafia).json")
+    r = _run(dsl_path, os.path.join(GOLD, "traj_werewolf_n8.json"))
+    dsl = json.load(open(dsl_path))
+    agent_side = initialize_player_states_from_dsl(dsl, [{"name": "Ann"}, {"name": "Bob"}, {"name": "Cy"}])
+    ps = r["init"]["player_states"]
+    assert sorted(ps) == ["1", "2", "3"]                          # gamePlayerId, else 1-based position
+    for pid in ps:
+        for field, value in agent_side[pid].items():
+            if field != "name":
+                assert ps[pid][field] == value, (pid, field)
+    assert (ps["1"]["name"], ps["1"]["id"], ps["1"]["isHost"]) == ("Ann", "u-7", True)
+    assert (ps["2"]["name"], ps["2"]["id"], ps["2"]["isHost"]) == ("Bob", "2", False)
+    # no template: defaults from the declared schema (boolean -> example or true, num -> example or 0 ...)
+    schema = dsl["declaration"]["player_states"]
+    gen = r["initFromSchema"]["player_states"]["1"]
+    for field, d in schema.items():
+        assert field in gen
+        if d.get("type") == "boolean":
+            assert gen[field] == (d["example"] if "example" in d else True)
+    assert r["initFallback"] == {"player_states": {}, "fallback_mode": True,
+                                 "message": "No template found, agent will generate player_states"}
+    assert r["found"] == ["Werewolf-(Mafia).yaml", None]
+
+
+@needs_node
 @pytest.mark.gpu
 @pytest.mark.parametrize("dsl,gold", [("werewolf-(mafia).json", "traj_werewolf_n8.json"),
                                       ("two-truths-and-a-lie.json", "traj_two_truths_and_a_lie_n4.json")])
