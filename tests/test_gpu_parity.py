@@ -107,6 +107,27 @@ def test_high_occupancy_path_equals_oracle(game, n, n_rooms):
     assert_views_equal(got, want, f"{game} n={n} rooms={n_rooms}")
 
 
+@pytest.mark.parametrize("game,n,n_rooms,first", [("two-truths-and-a-lie", 4, 1 << 20, 0),            # C3
+                                                  ("werewolf-(mafia)", 8, 1 << 20, 1 << 33),
+                                                  ("werewolf-(mafia)", 12, 1 << 21, 5 << 21)])      # rank 5's share of C4
+def test_full_baseline_sizes_equal_oracle(game, n, n_rooms, first):
+    """The BASELINE shapes at their full per-GPU size (256-room blocks, 16+ wavefronts per SIMD), every
+    room against the oracle: the oracle runs chunk by chunk on the host cores (rooms are independent
+    and keyed by their global index), the GPU batch in one piece."""
+    dsl = load_dsl(game)
+    orc = _oracle(dsl, n)
+    seed, turns, chunk = 0xC0FFEE, 80, 1 << 18
+    with RoomBatch([(GameTable(dsl), n, n_rooms)], seed=seed, first_room=first, restart=True) as b:
+        b.step(turns)
+        s = b.summary()
+        recycled = 0
+        for lo in range(0, n_rooms, chunk):
+            want = oracle_batch(orc, chunk, seed, first + lo, turns, restart=True)
+            assert_views_equal(b.read_rooms(lo, chunk), want, f"{game} n={n} rooms {lo}..{lo + chunk}")
+            recycled += int(want["games"].sum())
+    assert s["games_recycled"] == recycled and s["rooms"] == n_rooms
+
+
 @pytest.mark.parametrize("name", human_files())
 def test_host_driven_player_golden(name):
     """Player 1 host-driven (human_mask) + ge_batch_inject_action, against reference-run vectors."""
@@ -183,6 +204,19 @@ def test_mixed_batch_one_launch(dsl_ww, dsl_tt):
     assert_views_equal(got[n_ww:n_ww + n_tt], oracle_batch(_oracle(dsl_tt, 4), n_tt, seed, first + n_ww, turns), "tt4 segment")
     assert_views_equal(got[n_ww + n_tt:], oracle_batch(_oracle(dsl_ww, 12), 700, seed, first + n_ww + n_tt, turns), "ww12 segment")
     assert s["rooms"] == n_ww + n_tt + 700 and s["finished"] == int((got["end_turn"] >= 0).sum())
+
+
+def test_mixed_batch_full_c5_share_equals_oracle(dsl_ww, dsl_tt):
+    """One GPU's share of BASELINE config C5 at full size: 524 288 Werewolf x 8 + 524 288 Two-Truths x 4
+    rooms in the same launches (mixed kernel, 256-room blocks), steady state, every room vs the oracle."""
+    half, seed, turns, first, chunk = 1 << 19, 0xC0FFEE, 80, 7 << 20, 1 << 18
+    with RoomBatch([(GameTable(dsl_ww), 8, half), (GameTable(dsl_tt), 4, half)], seed=seed, first_room=first, restart=True) as b:
+        b.step(turns)
+        for dsl, n, base in ((dsl_ww, 8, 0), (dsl_tt, 4, half)):
+            orc = _oracle(dsl, n)
+            for lo in range(base, base + half, chunk):
+                want = oracle_batch(orc, chunk, seed, first + lo, turns, restart=True)
+                assert_views_equal(b.read_rooms(lo, chunk), want, f"n={n} rooms {lo}..{lo + chunk}")
 
 
 def test_summary_matches_readback(dsl_ww, dsl_tt):
