@@ -35,6 +35,9 @@ GE_HD uint32_t room_key(uint32_t seed_lo, uint32_t seed_hi, uint64_t room) {
     k = mix32(k ^ (uint32_t)(room >> 32));
     return k;
 }
+// the two seed rounds of room_key are the same for every room: done once on the host
+GE_HD uint32_t seed_key(uint32_t seed_lo, uint32_t seed_hi) { return mix32(mix32(seed_lo ^ 0x243F6A88u) ^ seed_hi); }
+GE_HD uint32_t room_key_from(uint32_t sk, uint64_t room) { return mix32(mix32(sk ^ (uint32_t)room) ^ (uint32_t)(room >> 32)); }
 GE_HD uint32_t turn_key(uint32_t rk, uint32_t turn) { return mix32(rk ^ (turn * GOLDEN)); }
 GE_HD uint32_t draw(uint32_t tk, uint32_t idx) { return mix32(tk + (idx + 1u) * GOLDEN); }
 // role picks are keyed by the room's game index, not by the turn in which they are applied
@@ -66,12 +69,14 @@ template <int NB> __device__ __forceinline__ uint32_t nth_set_bit_lds(const uint
     return (in_lo ? 0u : 8u) + nth8[idx];
 }
 
-__device__ __forceinline__ void fill_nth8(uint8_t *nth8) {
-    for (uint32_t m = threadIdx.x; m < 256u; m += blockDim.x) {
+// host side: the table's content (nth8[mask][n] = position of the n-th set bit of the 8-bit mask)
+inline void fill_nth8_host(uint8_t *nth8) {
+    for (uint32_t m = 0; m < 256u; m++) {
         uint32_t x = m;
-#pragma unroll
         for (uint32_t n = 0; n < 8u; n++) {
-            nth8[m * 8u + n] = x ? (uint8_t)(__ffs((int)x) - 1) : (uint8_t)0;
+            uint32_t pos = 0;
+            while (x && !((x >> pos) & 1u)) pos++;
+            nth8[m * 8u + n] = (uint8_t)(x ? pos : 0u);
             x &= x - 1u;
         }
     }

@@ -243,6 +243,7 @@ struct DevRow { uint32_t r0, r1, r2, r3, r4, r5, r6, r7; };
 struct DevTable {
     DevRow rows[32];
     int32_t n_phases, rounds, n_players, pad;
+    uint8_t nth8[2048];      // n-th-set-bit table (ge_device.h), copied to LDS by the large-batch build
 };
 
 // plane geometry of a segment

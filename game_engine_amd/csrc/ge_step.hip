@@ -41,7 +41,7 @@ struct SegDev {
 };
 
 struct StepArgs {
-    uint32_t n_seg, turn0, n_turns, seed_lo, seed_hi, block_threads, restart, trace, lowocc;
+    uint32_t n_seg, turn0, n_turns, seed_key, block_threads, restart, trace, lowocc;
     uint32_t block_begin[GE_MAX_SEGMENTS];
 };
 
@@ -92,7 +92,10 @@ __device__ __forceinline__ void store_event(uint32_t *trace, uint64_t rooms_padd
 
 __device__ __forceinline__ void load_rows(DevRow *rows, const DevTable *tables, uint32_t table_idx, uint8_t *nth8) {
     if (threadIdx.x < GE_MAX_PHASES) rows[threadIdx.x] = tables[table_idx].rows[threadIdx.x];
-    if (nth8) fill_nth8(nth8);
+    if (nth8) {                                                // 2 KB, 16 B per thread and pass
+        const u32x4 *src = reinterpret_cast<const u32x4 *>(tables[table_idx].nth8);
+        for (uint32_t i = threadIdx.x; i < 128u; i += blockDim.x) reinterpret_cast<u32x4 *>(nth8)[i] = src[i];
+    }
     __syncthreads();
 }
 
@@ -114,7 +117,7 @@ __device__ __forceinline__ void run_ww(const SegDev *__restrict__ sgp, const Ste
         L::unpack(w, u);
         s.from(u);                                            // packed predicates, one-hot roles (ge_layout.h)
     }
-    const uint32_t rk = room_key(a.seed_lo, a.seed_hi, sg.first_global + room);
+    const uint32_t rk = room_key_from(a.seed_key, sg.first_global + room);
     DevRow row = rows[s.phase];
     // the fresh room a finished one is recycled into: wave-uniform, kept in scalar registers
     uint32_t iw[L::WORDS];
@@ -174,7 +177,7 @@ __device__ __forceinline__ void run_tt(const SegDev *__restrict__ sgp, const Ste
     load_rows(rows, tables, sg.table_idx, nullptr);
     TT<NB> s;
     L::unpack(w, s);
-    const uint32_t rk = room_key(a.seed_lo, a.seed_hi, sg.first_global + room);
+    const uint32_t rk = room_key_from(a.seed_key, sg.first_global + room);
     DevRow row = rows[s.phase];
     uint32_t iw[L::WORDS];
 #pragma unroll
@@ -561,7 +564,7 @@ static int fill_args(const ge_batch *b, StepArgs &a, uint32_t turn0, uint32_t n_
     a.n_seg = (uint32_t)b->segs.size();
     for (uint32_t k = 0; k < a.n_seg; k++) a.block_begin[k] = b->segs[k].dev.block_begin;
     a.turn0 = turn0; a.n_turns = n_turns;
-    a.seed_lo = (uint32_t)b->seed; a.seed_hi = (uint32_t)(b->seed >> 32);
+    a.seed_key = seed_key((uint32_t)b->seed, (uint32_t)(b->seed >> 32));
     a.block_threads = b->block_threads;
     a.restart = (b->flags & GE_FLAG_RESTART) ? 1u : 0u;
     a.trace = (b->flags & GE_FLAG_TRACE) ? 1u : 0u;
@@ -680,6 +683,7 @@ int ge_batch_create(const ge_batch_desc *desc, ge_batch **out) {
             memset(&dt, 0, sizeof dt);
             for (int r = 0; r < s.table.n_phases; r++) dt.rows[r] = to_dev_row(s.table, s.table.rows[r], s.dev.kind);
             dt.n_phases = s.table.n_phases; dt.rounds = s.table.rounds; dt.n_players = (int32_t)s.dev.n_players;
+            fill_nth8_host(dt.nth8);
         }
         if (hipMemcpy(b->tables, host_tables.data(), sizeof(DevTable) * host_tables.size(), hipMemcpyHostToDevice) != hipSuccess) { st = GE_ERR_HIP; break; }
     } while (0);
