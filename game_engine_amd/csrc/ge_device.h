@@ -22,6 +22,9 @@ enum { RES_ALWAYS = 0, RES_WOLVES_ZERO, RES_WOLVES_GE_VILLAGERS, RES_FOLLOWS_DAY
        RES_ALL_ROUNDS_DONE, RES_OTHERWISE };
 
 constexpr uint32_t GOLDEN = 0x9E3779B9u;
+#ifndef GE_DPP_SCAN
+#define GE_DPP_SCAN 1
+#endif
 
 // ---- POLICY.md §RNG: stateless 32-bit counter hash
 GE_HD uint32_t mix32(uint32_t x) {
@@ -284,12 +287,27 @@ __device__ __forceinline__ void ww_turn(WWR<NB> &s, DevRow &row, const DevRow *r
             // one ballot per bit of the count, mbcnt for the lanes below
             const uint32_t lane = __lane_id();
             const uint32_t cnt = popc(todo);
-            uint32_t off = 0, total = 0;
+            uint32_t off, total;
+            if (GE_DPP_SCAN) {
+                // wavefront inclusive scan by DPP: inside each row of 16 lanes (row_shr 1, 2, 4, 8), then
+                // row 0 -> 1 and 2 -> 3 (row_bcast:15), then rows 0-1 -> 2-3 (row_bcast:31)
+                uint32_t v = cnt;
+                v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+                v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+                v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
+                v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
+                v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+                v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
+                off = v - cnt;
+                total = (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+            } else {
+                off = 0; total = 0;
 #pragma unroll
-            for (int b = 0; b < 4; b++) {
-                const unsigned long long m = __ballot((cnt >> b) & 1u);
-                off += __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)) << b;
-                total += (uint32_t)__popcll(m) << b;
+                for (int b = 0; b < 4; b++) {
+                    const unsigned long long m = __ballot((cnt >> b) & 1u);
+                    off += __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)) << b;
+                    total += (uint32_t)__popcll(m) << b;
+                }
             }
             if (LOWOCC || total != 0u) {                        // wave-uniform; LOWOCC: some room almost always has a due bot
                 // per-room context of an action; `ky`: what the acting role knows (the Detective's memory
