@@ -85,6 +85,11 @@ inline void fill_nth8_host(uint8_t *nth8) {
     }
 }
 
+// x has at most bit 0 of each nibble set: widen every such bit to a full 0xF nibble.  ORs of shifts,
+// not (x << 4) - x: the compiler turns that into v_mul_lo_u32 by 15, a quarter-rate instruction
+__device__ __forceinline__ uint32_t nib_fill(uint32_t x) { x |= x << 1; return x | (x << 2); }
+__device__ __forceinline__ uint64_t nib_fill(uint64_t x) { x |= x << 1; return x | (x << 2); }
+
 // 1-based id with the most votes among `voters`, ties -> lowest id, 0 if nobody voted.
 // votes: one nibble per player (1-based target id, 0 = none).  Counters are nibbles too
 // (<= 12 voters), so the whole tally is one or two registers.
@@ -95,12 +100,12 @@ __device__ __forceinline__ uint32_t plurality(nib_t votes, uint32_t voters) {
     if (NB <= 8) {
         uint32_t x = voters & 0xFFu;
         x = (x | (x << 12)) & 0x000F000Fu; x = (x | (x << 6)) & 0x03030303u; x = (x | (x << 3)) & 0x11111111u;
-        vm = (nib_t)((x << 4) - x);
+        vm = (nib_t)nib_fill(x);
     } else {
         uint64_t x = voters & 0xFFFFu;
         x = (x | (x << 24)) & 0x000000FF000000FFull; x = (x | (x << 12)) & 0x000F000F000F000Full;
         x = (x | (x << 6)) & 0x0303030303030303ull; x = (x | (x << 3)) & 0x1111111111111111ull;
-        vm = (nib_t)((x << 4) - x);
+        vm = (nib_t)nib_fill(x);
     }
     const nib_t v = votes & vm;
     // tally: counter k (a nibble) counts votes for player id k; nibble 0 collects "no vote"
@@ -177,10 +182,10 @@ __device__ __forceinline__ uint32_t ww_choose(uint32_t act, uint32_t i, uint32_t
 
 // nibble mask (0xF per player) of the non-zero nibbles of x
 __device__ __forceinline__ uint32_t nib_nonzero(uint32_t x) {
-    uint32_t m = x | (x >> 1); m |= m >> 2; m &= 0x11111111u; return (m << 4) - m;
+    uint32_t m = x | (x >> 1); m |= m >> 2; m &= 0x11111111u; return nib_fill(m);
 }
 __device__ __forceinline__ uint64_t nib_nonzero(uint64_t x) {
-    uint64_t m = x | (x >> 1); m |= m >> 2; m &= 0x1111111111111111ull; return (m << 4) - m;
+    uint64_t m = x | (x >> 1); m |= m >> 2; m &= 0x1111111111111111ull; return nib_fill(m);
 }
 
 // A room's role deal (POLICY.md §3 ASSIGN_ROLES): nw werewolves, then a Doctor, then a Detective, by
@@ -237,7 +242,7 @@ __device__ __forceinline__ void ww_turn(WWR<NB> &s, DevRow &row, const DevRow *r
             X ^= row.r7;
             X &= X >> 16; X &= X >> 8;                         // 4 terms, one byte each
         } else {
-            X = __builtin_amdgcn_perm(s.W[1], s.W[0], row.r4) & __builtin_amdgcn_perm(s.W[3], s.W[2], row.r5) &
+            X = __builtin_amdgcn_perm(s.W[1], s.W[0], row.r4) & __builtin_amdgcn_perm(s.W[R::NW > 3 ? 3 : 0], s.W[2], row.r5) &
                 __builtin_amdgcn_perm(s.W[R::NW - 1], s.W[R::NW - 2], row.r6);
             X ^= row.r7;
             X &= X >> 16;                                      // terms 0..1, one half-word each
@@ -400,7 +405,7 @@ __device__ __forceinline__ void ww_turn(WWR<NB> &s, DevRow &row, const DevRow *r
         uint64_t m = 0;
 #pragma unroll
         for (int i = 0; i < NB; i++) m |= (uint64_t)((x >> i) & 1u) << (4 * i);
-        ev_choice = (uint64_t)s.choice & ((m << 4) - m);
+        ev_choice = (uint64_t)s.choice & nib_fill(m);
     }
 
     // ---- PhaseNode: phase-0 guard (v2:1025-1052): first turn only records phase 0, Referee skipped
@@ -416,7 +421,7 @@ __device__ __forceinline__ void ww_turn(WWR<NB> &s, DevRow &row, const DevRow *r
                            ((prev_eff == EFF_NIGHT_RESOLVE) << RES_FOLLOWS_NIGHT) | (1u << RES_OTHERWISE);
         // first branch (DSL order) whose resolver holds: row.r2 has one byte per branch with the bit of
         // its resolver set (0 for absent branches), so the lowest non-zero byte of r2 & (C in every byte) wins
-        const uint32_t hit = row.r2 & (C * 0x01010101u);
+        const uint32_t hit = row.r2 & __builtin_amdgcn_perm(C, C, 0u);   // C (< 256) in every byte
         const uint32_t sh = ctz(hit) & 24u;
         qe = (open && hit != 0u) ? ((row.r3 >> sh) & 255u) : qe;
     }
@@ -534,7 +539,7 @@ __device__ __forceinline__ void tt_turn(TT<NB> &s, DevRow &row, const DevRow *ro
                 if ((uint32_t)i < n && ((uint32_t)(s.rounds >> (4 * i)) & 15u) < rounds) all_done = 0u;
         }
         const uint32_t C = 1u | (all_done << RES_ALL_ROUNDS_DONE) | (1u << RES_OTHERWISE);
-        const uint32_t hit = row.r2 & (C * 0x01010101u);       // see ww_turn
+        const uint32_t hit = row.r2 & __builtin_amdgcn_perm(C, C, 0u);       // see ww_turn
         const uint32_t sh = ctz(hit) & 24u;
         q = hit != 0u ? ((row.r3 >> sh) & 31u) : q;
     }
