@@ -617,6 +617,10 @@ int ge_batch_create(const ge_batch_desc *desc, ge_batch **out) {
     uint64_t total = 0;
     for (uint32_t k = 0; k < desc->n_segments; k++) total += desc->seg[k].n_rooms;
     b->block_threads = total >= (1u << 19) ? 256u : 64u;
+    if (const char *e = getenv("GE_BLOCK_THREADS")) {          // tuning / A-B runs: 64, 128 or 256
+        const unsigned long v = strtoul(e, nullptr, 10);
+        if (v == 64 || v == 128 || v == 256) b->block_threads = (uint32_t)v;
+    }
     uint64_t local = 0, global = desc->first_room;
     size_t bytes = 0;
     uint32_t blocks = 0;
