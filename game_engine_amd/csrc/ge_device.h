@@ -87,8 +87,10 @@ inline void fill_nth8_host(uint8_t *nth8) {
 
 // x has at most bit 0 of each nibble set: widen every such bit to a full 0xF nibble.  ORs of shifts,
 // not (x << 4) - x: the compiler turns that into v_mul_lo_u32 by 15, a quarter-rate instruction
-__device__ __forceinline__ uint32_t nib_fill(uint32_t x) { x |= x << 1; return x | (x << 2); }
-__device__ __forceinline__ uint64_t nib_fill(uint64_t x) { x |= x << 1; return x | (x << 2); }
+// (the empty asm hides the intermediate from the optimiser, which would otherwise prove the bits disjoint
+// and fold the ORs back into that multiply)
+__device__ __forceinline__ uint32_t nib_fill(uint32_t x) { x |= x << 1; asm("" : "+v"(x)); return x | (x << 2); }
+__device__ __forceinline__ uint64_t nib_fill(uint64_t x) { x |= x << 1; asm("" : "+v"(x)); return x | (x << 2); }
 
 // 1-based id with the most votes among `voters`, ties -> lowest id, 0 if nobody voted.
 // votes: one nibble per player (1-based target id, 0 = none).  Counters are nibbles too
