@@ -9,7 +9,7 @@ import pytest
 from conftest import golden_files, human_files, load_dsl, load_golden, restart_files
 from game_engine_amd import GameTable, GeError, RoomBatch
 from game_engine_amd.stepper import project_view
-from parity_util import assert_views_equal, oracle_batch
+from parity_util import assert_views_equal, oracle_batch, oracle_rooms_as_views
 
 pytestmark = pytest.mark.gpu
 SEEDS = [0, 1, 0xC0FFEE]
@@ -308,6 +308,28 @@ def test_invariants_at_full_sizes(dsl_ww, dsl_tt):
     dead = r2["players"][:, :12, 2] == 0
     assert (r2["players"][:, :12, 4][dead] == 0).all() and (r2["players"][:, :12, 3][dead] == 1).all()
     assert s2["alive_players"] <= s1["alive_players"] <= 12 << 21
+
+
+@pytest.mark.parametrize("game,n", [("werewolf-(mafia)", 8), ("two-truths-and-a-lie", 4)])
+def test_counters_saturate_like_the_oracle(game, n):
+    """Long-running steady state: end_turn saturates at 65 534 for games that end later (POLICY §1.3), the
+    per-slot game counter - which also keys the role deal - at 65 535 (§2).  Rooms start with the
+    counter just below its ceiling and run past turn 65 534."""
+    dsl = load_dsl(game)
+    orc = _oracle(dsl, n)
+    R, seed, first, turns = 512, 3, 1 << 20, 65700
+    rooms = orc.init_rooms(R)
+    rooms["games"] = 65535 - 20 - (np.arange(R) % 7)
+    with RoomBatch([(GameTable(dsl), n, R)], seed=seed, first_room=first, restart=True, max_fuse=1024) as b:
+        b.write_rooms(0, oracle_rooms_as_views(orc, rooms))
+        b.step(turns)
+        got = b.read_rooms()
+    orc.run(rooms, seed, first, 0, turns, threads=0, restart=True)
+    want = oracle_rooms_as_views(orc, rooms)
+    assert_views_equal(got, want, f"{game} after {turns} turns")
+    assert (want["games"] == 65535).all()
+    done = want["end_turn"] >= 0
+    assert done.any() and (want["end_turn"][done] == 65534).all()      # whoever is finished right now finished late
 
 
 def test_argument_and_range_errors(dsl_ww, dsl_tt):
