@@ -55,6 +55,18 @@ export class RoomBatch {
   readEvents(first: number, count: number): TurnEvent[][];
   summary(): Summary;
 }
+/** One Node process, several GPUs: device d owns the global rooms [firstRoom + d*R, firstRoom + (d+1)*R). */
+export class ShardedBatch {
+  constructor(opts: { segments: Segment[]; devices: number[]; seed?: bigint; firstRoom?: bigint; maxFuse?: number; restart?: boolean; trace?: boolean });
+  readonly nRooms: number;
+  readonly roomsPerDevice: number;
+  readonly shards: RoomBatch[];
+  step(nTurns?: number): Promise<bigint | number>;
+  reset(): void;
+  readRoom(room: number): RoomState;
+  injectAction(room: number, playerId: number, choice: number): void;
+  summary(): Summary;
+}
 export function turnToolCalls(table: GameTable, before: RoomState, after: RoomState, event: TurnEvent): ToolCall[];
 export function loadDslByGamename(gamename: string, gamesDir?: string): object;
 export function deviceCount(): number;

@@ -246,7 +246,48 @@ class RoomBatch {
   }
 }
 
+/**
+ * The same rooms spread over several GPUs of one node, from ONE Node process (SURVEY §8e): device d
+ * owns the global rooms [firstRoom + d*R, firstRoom + (d+1)*R) with R = rooms per device, so per-room
+ * results equal those of a single batch or of any other device count (the RNG is keyed by the global
+ * index).  Rooms never interact: step() just runs every shard's launches concurrently (one async
+ * work item per shard, each on its own device); the only cross-GPU step is summary(), a host-side
+ * sum of the fixed-size per-device summaries (the multi-process Python host does the same sum after
+ * one RCCL all-gather, game_engine_amd/dist.py).
+ */
+class ShardedBatch {
+  /** segments: per-device segments (every device gets the same mix); devices: HIP device indices */
+  constructor({ segments, devices, seed = 0n, firstRoom = 0n, maxFuse = 0, restart = false, trace = false }) {
+    if (!devices || !devices.length) throw new RangeError('devices');
+    this.roomsPerDevice = segments.reduce((a, s) => a + s.nRooms, 0);
+    this.shards = devices.map((device, d) => new RoomBatch({
+      segments, seed, device, maxFuse, restart, trace,
+      firstRoom: BigInt(firstRoom) + BigInt(d) * BigInt(this.roomsPerDevice),
+    }));
+    this.nRooms = this.roomsPerDevice * devices.length;
+  }
+  async step(nTurns = 1) { return (await Promise.all(this.shards.map((b) => b.step(nTurns))))[0]; }
+  reset() { this.shards.forEach((b) => b.reset()); }
+  shardOf(room) {
+    if (!(room >= 0 && room < this.nRooms)) throw new RangeError(`room ${room}`);
+    return [this.shards[Math.floor(room / this.roomsPerDevice)], room % this.roomsPerDevice];
+  }
+  readRoom(room) { const [b, r] = this.shardOf(room); return b.readRoom(r); }
+  injectAction(room, playerId, choice) { const [b, r] = this.shardOf(room); b.injectAction(r, playerId, choice); }
+  /** whole-job summary: every field is a sum over rooms (checksum: mod 2^64), `turn` is common */
+  summary() {
+    const parts = this.shards.map((b) => b.summary());
+    const add = (f) => BigInt.asUintN(64, parts.reduce((a, p) => a + p[f], 0n));
+    const addHist = (f) => parts[0][f].map((_, i) => BigInt.asUintN(64, parts.reduce((a, p) => a + p[f][i], 0n)));
+    return {
+      rooms: add('rooms'), finished: add('finished'), village_wins: add('village_wins'), wolf_wins: add('wolf_wins'),
+      alive_players: add('alive_players'), sum_end_turn: add('sum_end_turn'), end_turn_hist: addHist('end_turn_hist'),
+      score_hist: addHist('score_hist'), checksum: add('checksum'), turn: parts[0].turn, games_recycled: add('games_recycled'),
+    };
+  }
+}
+
 const { compileCriteria, audienceGroups, uiToolCalls } = require('./ui_script.js');
 
-module.exports = { GameTable, RoomBatch, loadDslByGamename, findGameFile, initializePlayers, turnToolCalls, compileCriteria, audienceGroups, uiToolCalls,
+module.exports = { GameTable, RoomBatch, ShardedBatch, loadDslByGamename, findGameFile, initializePlayers, turnToolCalls, compileCriteria, audienceGroups, uiToolCalls,
                    deviceCount: addon.deviceCount, addon };

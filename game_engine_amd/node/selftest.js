@@ -53,6 +53,18 @@ if (deviceCount() === 0) {
   const big = new RoomBatch({ segments: [{ table, nPlayers: golden.n_players, nRooms: 10000 }], seed: 7n });
   await big.step(64);
   const s = big.summary();
+  { // three shards (all on device 0 here) == one batch of the same rooms: per room and in the summary
+    const { ShardedBatch } = require('./index.js');
+    const seg = [{ table, nPlayers: golden.n_players, nRooms: 3000 }];
+    const sh = new ShardedBatch({ segments: seg, devices: [0, 0, 0], seed: 11n, firstRoom: 1000n, restart: true });
+    const one = new RoomBatch({ segments: [{ table, nPlayers: golden.n_players, nRooms: 9000 }], seed: 11n, firstRoom: 1000n, restart: true });
+    await Promise.all([sh.step(100), one.step(100)]);
+    const a = sh.summary(), b = one.summary();
+    out.shardSummaryEqual = ['rooms', 'finished', 'village_wins', 'wolf_wins', 'alive_players', 'sum_end_turn', 'checksum', 'turn', 'games_recycled']
+      .every((f) => a[f] === b[f]) && a.end_turn_hist.every((x, i) => x === b.end_turn_hist[i]);
+    out.shardRoomsEqual = [0, 2999, 3000, 4567, 8999].every((r) => JSON.stringify(sh.readRoom(r)) === JSON.stringify(one.readRoom(r)));
+    out.shardRooms = Number(a.rooms);
+  }
   out.checked = checked; out.finished = Number(s.finished); out.turn = Number(s.turn);
   out.sample = big.readRoom(123).current_phase_name;
   console.log(JSON.stringify(out));

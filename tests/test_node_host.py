@@ -71,6 +71,8 @@ def test_node_host_matches_golden(dsl, gold):
     g = json.load(open(os.path.join(GOLD, gold)))
     assert r["devices"] >= 1 and r["checked"] == sum(len(c["turns"]) for c in g["cases"])
     assert r["turn"] == 64 and r["finished"] > 0 and isinstance(r["sample"], str)
+    # ShardedBatch (one Node process, several devices): shard-count invariance per room and in the summary
+    assert r["shardRooms"] == 9000 and r["shardSummaryEqual"] and r["shardRoomsEqual"]
     # the JS host renders the same backend tool calls as the Python host for the same traced room
     from conftest import load_dsl
     from game_engine_amd import GameTable, RoomBatch
