@@ -191,19 +191,21 @@ def test_fused_equals_unfused_and_chunked(dsl_ww):
     assert outs[0] == outs[1] == outs[2] == outs[3]
 
 
-def test_mixed_batch_one_launch(dsl_ww, dsl_tt):
+@pytest.mark.parametrize("n_ww,n_tt,n_ww12", [(3000, 5000, 700),          # lone-wavefront build of the mixed kernel
+                                               (60000, 50000, 30001)])     # large-batch build, 64-room blocks
+def test_mixed_batch_one_launch(dsl_ww, dsl_tt, n_ww, n_tt, n_ww12):
     """BASELINE config C5 shape: Werewolf and Two-Truths rooms (different phase graphs and record
     layouts) advanced by the same launches; global room indices run across segments."""
     ww, tt = GameTable(dsl_ww), GameTable(dsl_tt)
-    n_ww, n_tt, turns, seed, first = 3000, 5000, 64, 0xC0FFEE, 1 << 33
-    with RoomBatch([(ww, 8, n_ww), (tt, 4, n_tt), (ww, 12, 700)], seed=seed, first_room=first) as b:
+    turns, seed, first = 64, 0xC0FFEE, 1 << 33
+    with RoomBatch([(ww, 8, n_ww), (tt, 4, n_tt), (ww, 12, n_ww12)], seed=seed, first_room=first) as b:
         b.step(turns)
         got = b.read_rooms()
         s = b.summary()
     assert_views_equal(got[:n_ww], oracle_batch(_oracle(dsl_ww, 8), n_ww, seed, first, turns), "ww8 segment")
     assert_views_equal(got[n_ww:n_ww + n_tt], oracle_batch(_oracle(dsl_tt, 4), n_tt, seed, first + n_ww, turns), "tt4 segment")
-    assert_views_equal(got[n_ww + n_tt:], oracle_batch(_oracle(dsl_ww, 12), 700, seed, first + n_ww + n_tt, turns), "ww12 segment")
-    assert s["rooms"] == n_ww + n_tt + 700 and s["finished"] == int((got["end_turn"] >= 0).sum())
+    assert_views_equal(got[n_ww + n_tt:], oracle_batch(_oracle(dsl_ww, 12), n_ww12, seed, first + n_ww + n_tt, turns), "ww12 segment")
+    assert s["rooms"] == n_ww + n_tt + n_ww12 and s["finished"] == int((got["end_turn"] >= 0).sum())
 
 
 def test_mixed_batch_full_c5_share_equals_oracle(dsl_ww, dsl_tt):
