@@ -153,7 +153,7 @@ struct WaveLds {
 // The lone-wavefront build pays ~150 cycles for every dependent LDS round trip and has LDS to spare, so
 // there a slot holds the owning room's whole context (one read per item instead of lane id -> context).
 struct WaveLdsLow {
-    uint4 slot[64 * 13];
+    uint4 slot[64 * 13 + 80];  // + scratch for rooms without a due bot (lane .. lane + 12)
     uint4 res[64];
 };
 template <bool LOWOCC> struct WaveLdsOf { using type = WaveLds; };
@@ -330,13 +330,12 @@ __device__ __forceinline__ void ww_turn(WWR<NB> &s, DevRow &row, const DevRow *r
                 // (they would tie with the next owner inside one instruction).
                 if (LOWOCC) {
                     auto *lo = reinterpret_cast<WaveLdsLow *>(lw);
-                    if (cnt != 0u) {
-                        uint4 *qp = lo->slot + off;
+                    // no predicate here either: a room without a due bot writes to a scratch range behind the queue
+                    uint4 *qp = lo->slot + (cnt != 0u ? off : 64u * 13u + lane);
 #pragma unroll
-                        for (int j = NB - 1; j >= 0; j--) {
-                            qp[j] = ctx;
-                            asm volatile("" ::: "memory");         // the stores must issue in this order
-                        }
+                    for (int j = NB - 1; j >= 0; j--) {
+                        qp[j] = ctx;
+                        asm volatile("" ::: "memory");             // the stores must issue in this order
                     }
                 } else {
                     auto *hi = reinterpret_cast<WaveLds *>(lw);
@@ -439,26 +438,42 @@ __device__ __forceinline__ void ww_turn(WWR<NB> &s, DevRow &row, const DevRow *r
     // ---- RefereeNode (B): effect of entering q
     const DevRow qrow = rows[q];                               // LDS read in flight during the effect: first used at the end
     const uint32_t eff = qe >> 5;
-    if (eff == EFF_ASSIGN_ROLES) {
-        // the deal of this game was normally prepared ahead (run loop, every 8th turn, for all lanes
-        // of the wavefront at once); fall back to dealing here if it was not
-        if (!(deal.valid && deal.game == s.games)) deal_roles<NB, LOWOCC>(deal, deal_key(rkey, s.games), s.games, n, nw, nth8);
-        const uint32_t rem = deal.rem, wolves = deal.wolves, doc = deal.doc, det = deal.det;
-        deal.valid = 0u;
-        const uint32_t special = ALL & ~rem;
-        s.template put<F_VIL>(rem); s.template put<F_WOLF>(wolves); s.template put<F_DOC>(doc); s.template put<F_DET>(det);
-        s.template put<F_TEAM_W>(wolves); s.template put<F_TEAM_V>(ALL & ~wolves);
-        s.template put<F_SECRET>(special); s.template put<F_ELIG>(special);
-    } else if (eff == EFF_NIGHT_RESOLVE || eff == EFF_DAY_RESOLVE) {
-        const bool day = eff == EFF_DAY_RESOLVE;
+    // night / day resolution: the plurality victim dies unless the (highest-id living) Doctor guards it
+    auto resolve = [&](bool on, bool day) {
         const uint32_t voters = day ? (alive & s.acted) : (alive & s.template get<F_WOLF>());
         const uint32_t victim = plurality<NB, nib_t>(day ? s.choice : s.sel, voters);
-        const uint32_t docs = alive & s.template get<F_DOC>();  // the highest-id living Doctor protects
+        const uint32_t docs = alive & s.template get<F_DOC>();
         const uint32_t guarded = (uint32_t)(s.sel >> (4u * (31u - (uint32_t)__clz((int)(docs | 1u))))) & 15u;
         const uint32_t protect = (!day && docs) ? guarded : 0u;
-        const uint32_t bit = (victim != 0u && victim != protect) ? (1u << ((victim - 1u) & 15u)) : 0u;
+        const uint32_t bit = (on && victim != 0u && victim != protect) ? (1u << ((victim - 1u) & 15u)) : 0u;
         s.template clear<F_ALIVE>(bit); s.template clear<F_CAN_VOTE>(bit); s.template clear<F_ELIG>(bit);
         s.template set<F_REVEALED>(bit);
+    };
+    // role assignment: the deal of this game was normally prepared ahead (run loop, every 8th turn, for
+    // all lanes of the wavefront at once); fall back to dealing here if it was not
+    const bool is_assign = eff == EFF_ASSIGN_ROLES;
+    if (is_assign && !(deal.valid && deal.game == s.games)) deal_roles<NB, LOWOCC>(deal, deal_key(rkey, s.games), s.games, n, nw, nth8);
+    auto assign = [&](WWR<NB> &t) {
+        const uint32_t special = ALL & ~deal.rem;
+        t.template put<F_VIL>(deal.rem); t.template put<F_WOLF>(deal.wolves); t.template put<F_DOC>(deal.doc); t.template put<F_DET>(deal.det);
+        t.template put<F_TEAM_W>(deal.wolves); t.template put<F_TEAM_V>(ALL & ~deal.wolves);
+        t.template put<F_SECRET>(special); t.template put<F_ELIG>(special);
+    };
+    if (LOWOCC) {
+        // lone wavefront: every divergent block costs an exec-mask sequence and a branch bubble, and both
+        // effects are entered by some room of the wavefront on most turns anyway - so both are evaluated
+        // for every lane and applied by selects
+        WWR<NB> t = s;
+        assign(t);
+#pragma unroll
+        for (int k = 0; k < R::NW; k++) s.W[k] = is_assign ? t.W[k] : s.W[k];
+        deal.valid = is_assign ? 0u : deal.valid;
+        resolve(eff == EFF_NIGHT_RESOLVE || eff == EFF_DAY_RESOLVE, eff == EFF_DAY_RESOLVE);
+    } else if (is_assign) {
+        assign(s);
+        deal.valid = 0u;
+    } else if (eff == EFF_NIGHT_RESOLVE || eff == EFF_DAY_RESOLVE) {
+        resolve(true, eff == EFF_DAY_RESOLVE);
     }
     const bool nbeg = eff == EFF_NIGHT_BEGIN;
     s.template clear<F_SUB>(nbeg ? R::FM : 0u);
