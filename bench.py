@@ -115,7 +115,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4096)
-    ap.add_argument("--warmup", type=int, default=256)
+    ap.add_argument("--warmup", type=int, default=1024)
     ap.add_argument("--fuse", type=int, default=1024, help="turns fused per launch (1 = one launch per turn)")
     ap.add_argument("--rooms", type=int, default=None, help="rooms per GPU (overrides the workload's count; c2 only)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2", help="BASELINE.json config (default c2 = configs[1])")
