@@ -487,35 +487,57 @@ __device__ __forceinline__ void ww_turn(WWR<NB> &s, DevRow &row, const DevRow *r
 }
 
 // ------------------------------------------------------------------ two truths and a lie
+// per-player mask of rounds_as_speaker >= R (kept beside the room in registers: "whose turn is next"
+// and "all rounds done" are then one bit operation instead of a scan over the nibble array)
+template <int NB> __device__ __forceinline__ uint32_t tt_done_mask(uint64_t rounds_nib, uint32_t R) {
+    uint32_t m = 0;
+#pragma unroll
+    for (int i = 0; i < NB; i++) m |= (((uint32_t)(rounds_nib >> (4 * i)) & 15u) >= R ? 1u : 0u) << i;
+    return m;
+}
+
+// the even bits of x (bit 2i -> bit i), 12 fields at most
+__device__ __forceinline__ uint32_t even_bits(uint32_t x) {
+    x &= 0x00555555u;
+    x = (x | (x >> 1)) & 0x00333333u; x = (x | (x >> 2)) & 0x000F0F0Fu;
+    x = (x | (x >> 4)) & 0x00FF00FFu; x = (x | (x >> 8)) & 0x0000FFFFu;
+    return x;
+}
+
 template <int NB>
-__device__ __forceinline__ void tt_turn(TT<NB> &s, DevRow &row, const DevRow *rows, bool valid, uint32_t n, uint32_t rounds,
+__device__ __forceinline__ void tt_turn(TT<NB> &s, uint32_t &done, DevRow &row, const DevRow *rows, bool valid, uint32_t n, uint32_t rounds,
                                         uint32_t phase0_idx, uint32_t rkey, uint32_t turn,
                                         bool trace, uint32_t human, uint32_t &ev_newly, uint64_t &ev_choice) {
+    // done: tt_done_mask of s.rounds, maintained here (the caller derives it when it loads or replaces s)
     const uint32_t ALL = (1u << n) - 1u;
     const uint32_t comp = row.r0 & 3u, act = (row.r0 >> 2) & 7u, p_eff = (row.r0 >> 5) & 7u;
-    const uint32_t nterms = (row.r0 >> 8) & 7u, nbr = (row.r0 >> 11) & 7u;
+    const uint32_t nterms = (row.r0 >> 8) & 7u;
     const uint32_t tk = turn_key(rkey, turn);
 
     uint32_t T = 0;
     if (comp == COMP_ACTION) {
-        // the 5 base predicates, two per 32-bit word (see ww_turn)
+        // the 5 base predicates, two per 32-bit word; terms 0..1 by byte permute (see ww_turn, ge_layout.h DevRow)
         const uint32_t W0 = s.speaker | (s.submitted << 16), W1 = s.revealed | (s.can_vote << 16), W2 = s.has_voted;
-        auto term = [&](uint32_t j) -> uint32_t {
-            const uint32_t e = (row.r1 >> (8u * j)) & 255u;
-            const uint32_t wi = e >> 5;
-            uint32_t word = 0xFFFFFFFFu;
-            word = wi == 0u ? W0 : word; word = wi == 1u ? W1 : word; word = wi == 2u ? W2 : word;
-            const uint32_t m = word >> (e & 31u);
-            return m ^ (uint32_t)((int32_t)(row.r0 << (15u - j)) >> 31);   // term_neg bit j -> 0 / ~0
-        };
-        T = term(0) & term(1);
-        if (nterms > 2u) T &= term(2) & term(3);
-        T &= ALL;
+        uint32_t X = __builtin_amdgcn_perm(W1, W0, row.r4) & __builtin_amdgcn_perm(W2, W2, row.r5);
+        X ^= row.r7;
+        X &= X >> 16;
+        if (nterms > 2u) {                                     // no shipped phase has more than two terms
+            auto term = [&](uint32_t j) -> uint32_t {
+                const uint32_t e = (row.r1 >> (8u * j)) & 255u;
+                const uint32_t wi = e >> 5;
+                uint32_t word = 0xFFFFFFFFu;
+                word = wi == 0u ? W0 : word; word = wi == 1u ? W1 : word; word = wi == 2u ? W2 : word;
+                const uint32_t m = word >> (e & 31u);
+                return m ^ (uint32_t)((int32_t)(row.r0 << (15u - j)) >> 31);   // term_neg bit j -> 0 / ~0
+            };
+            X &= term(2) & term(3);
+        }
+        T = X & ALL;
     }
 
     uint32_t newly = 0;
     {
-        uint32_t todo = T & ~s.acted & ~human;
+        uint32_t todo = valid ? (T & ~s.acted & ~human) : 0u;
         const bool a_stm = act == ACT_TT_STATEMENTS, a_lie = act == ACT_TT_LIE, a_vote = act == ACT_TT_VOTE;
         while (todo) {
             const uint32_t i = ctz(todo);
@@ -547,59 +569,52 @@ __device__ __forceinline__ void tt_turn(TT<NB> &s, DevRow &row, const DevRow *ro
         s.flags |= FLAG_PHASE0_DONE;
         return;
     }
-    uint32_t q = s.phase;
-    if (nbr != 0u && (comp != COMP_ACTION || (T & ~s.acted) == 0u)) {
-        uint32_t all_done = 1u;
-        if ((row.r0 >> 20) & 1u) {                       // some branch asks "all rounds done?"
-#pragma unroll
-            for (int i = 0; i < NB; i++)
-                if ((uint32_t)i < n && ((uint32_t)(s.rounds >> (4 * i)) & 15u) < rounds) all_done = 0u;
-        }
+    uint32_t qe = s.phase;
+    if (comp != COMP_ACTION || (T & ~s.acted) == 0u) {
+        const uint32_t all_done = (done & ALL) == ALL;         // every player has spoken R rounds
         const uint32_t C = 1u | (all_done << RES_ALL_ROUNDS_DONE) | (1u << RES_OTHERWISE);
         const uint32_t hit = row.r2 & __builtin_amdgcn_perm(C, C, 0u);       // see ww_turn
         const uint32_t sh = ctz(hit) & 24u;
-        q = hit != 0u ? ((row.r3 >> sh) & 31u) : q;
+        qe = hit != 0u ? ((row.r3 >> sh) & 255u) : qe;
     }
+    const uint32_t q = qe & 31u;
     if (q == s.phase) return;
 
-    const DevRow qrow = rows[q];
-    const uint32_t q0 = qrow.r0;
-    const uint32_t eff = (q0 >> 5) & 7u;
+    const DevRow qrow = rows[q];                               // in flight during the effect (see ww_turn)
+    const uint32_t eff = qe >> 5;
     if (eff == EFF_TT_ROUND_START) {
-        uint32_t speaker = 0;
-#pragma unroll
-        for (int i = NB - 1; i >= 0; i--)
-            if ((uint32_t)i < n && ((uint32_t)(s.rounds >> (4 * i)) & 15u) < rounds) speaker = 1u << i;
+        const uint32_t cand = ALL & ~done;                     // lowest id that has not spoken R rounds yet
+        const uint32_t speaker = cand & (0u - cand);
         s.speaker = speaker; s.can_vote = ALL & ~speaker;
         s.submitted = 0; s.lie = 0; s.revealed = 0; s.vote = 0; s.has_voted = 0;
     } else if (eff == EFF_TT_REVEAL) {
         s.revealed |= s.speaker;
     } else if (eff == EFF_TT_SCORE) {
-        if (s.speaker) {
-            const uint32_t sp = ctz(s.speaker);
-            const uint32_t lie = (s.lie >> (2u * sp)) & 3u;
-            uint32_t fooled = 0;
+        // all voters at once: a voter scores if its 2-bit vote equals the speaker's lie index, else the
+        // speaker does (tt:5-6); scores are bytes, 4 players per word
+        const bool on = s.speaker != 0u;
+        const uint32_t sp = ctz(s.speaker | 0x80000000u) & 15u;
+        const uint32_t lie = (s.lie >> (2u * sp)) & 3u;
+        const uint32_t x = s.vote ^ (lie * 0x00555555u);       // lie index replicated into every field
+        const uint32_t eq = even_bits(~(x | (x >> 1)));        // field == 0  <=>  vote == lie
+        const uint32_t spbit = s.speaker & (0u - s.speaker);    // written states may flag several: the lowest one counts
+        const uint32_t voters = on ? (s.has_voted & ~spbit) : 0u;
+        const uint32_t right = eq & voters, fooled = popc(~eq & voters);
 #pragma unroll
-            for (int i = 0; i < NB; i++) {
-                const bool voter = (uint32_t)i != sp && ((s.has_voted >> i) & 1u);
-                const bool right = ((s.vote >> (2 * i)) & 3u) == lie;
-                uint32_t add = (voter && right) ? 1u : 0u;
-                fooled += (voter && !right) ? 1u : 0u;
-                // the speaker's own slot takes `fooled` below; everyone else +1 if right
-                s.score[i / 4] += add << (8 * (i % 4));
-            }
-#pragma unroll
-            for (int i = 0; i < NB; i++)
-                s.score[i / 4] += ((uint32_t)i == sp ? fooled : 0u) << (8 * (i % 4));
-            s.rounds += uint64_t(1) << (4u * sp);
+        for (int w = 0; w < (NB + 3) / 4; w++) {
+            const uint32_t nib = (right >> (4 * w)) & 15u;       // 4 players -> bit 0 of 4 bytes
+            s.score[w] += ((nib * 0x00204081u) & 0x01010101u) + ((sp >> 2) == (uint32_t)w ? fooled << (8u * (sp & 3u)) : 0u);
         }
+        const uint32_t had = (uint32_t)(s.rounds >> (4u * sp)) & 15u;
+        s.rounds += (uint64_t)(on ? 1u : 0u) << (4u * sp);
+        done |= (on && had + 1u >= rounds) ? spbit : 0u;
     }
     s.acted = 0; s.choice = 0;
     s.flags = (s.flags & FLAG_PHASE0_DONE) | (p_eff << 1);
     s.prev = s.phase;
     s.phase = q;
     row = qrow;
-    if (((q0 >> 11) & 7u) == 0u && s.end_turn == END_NONE) s.end_turn = turn < 0xFFFEu ? turn : 0xFFFEu;
+    if (((qrow.r0 >> 11) & 7u) == 0u && s.end_turn == END_NONE) s.end_turn = turn < 0xFFFEu ? turn : 0xFFFEu;
 }
 #endif  // __HIPCC__
 

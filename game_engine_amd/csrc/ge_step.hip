@@ -185,6 +185,8 @@ __device__ __forceinline__ void run_tt(const SegDev *__restrict__ sgp, const Ste
     TT<NB> s0;
     L::unpack(iw, s0);
     const DevRow row0 = rows[sg.phase0_idx];
+    uint32_t done = tt_done_mask<NB>(s.rounds, sg.rounds);   // who has spoken all agreed rounds (ge_device.h)
+    const uint32_t done0 = tt_done_mask<NB>(s0.rounds, sg.rounds);
     for (uint32_t t = 0; t < a.n_turns; t++) {
         uint32_t restarted = 0;
         if (a.restart && ((row.r0 >> 11) & 7u) == 0u) {
@@ -192,12 +194,13 @@ __device__ __forceinline__ void run_tt(const SegDev *__restrict__ sgp, const Ste
             s = s0;
             s.games = g < 0xFFFFu ? g + 1u : g;
             row = row0;
+            done = done0;
             restarted = 1;
         }
         const uint32_t p = s.phase;
         uint32_t ev_newly = 0;
         uint64_t ev_choice = 0;
-        tt_turn<NB>(s, row, rows, valid, sg.n_players, sg.rounds, sg.phase0_idx, rk, a.turn0 + t, a.trace != 0u, sg.human_mask, ev_newly, ev_choice);
+        tt_turn<NB>(s, done, row, rows, valid, sg.n_players, sg.rounds, sg.phase0_idx, rk, a.turn0 + t, a.trace != 0u, sg.human_mask, ev_newly, ev_choice);
         if (a.trace && valid) store_event(sg.trace, sg.rooms_padded, t, room, a.turn0 + t, p, s.phase, restarted, ev_newly, ev_choice);
     }
     if (!valid) return;
@@ -398,7 +401,8 @@ DevRow to_dev_row(const ge_game_table &tb, const ge_phase_row &r, uint32_t kind)
         d.r3 |= (tgt | ((uint32_t)(tb.rows[tgt].effect & 7u) << 5)) << (8 * b);
         if (b < r.n_branches && r.br_res[b] == GE_RES_ALL_ROUNDS_DONE) d.r0 |= 1u << 20;
     }
-    if (kind == K_WW8 || kind == K_WW12) {
+    {
+        // all kinds (two-truths: three words of two half-word fields, pairs (W1:W0) and (W2:W2)).
         // v_perm_b32 selector bytes: 0..3 = bytes of the pair's low word, 4..7 = of its high word, 0x0D = 0xFF
         uint32_t sel[3] = {0x0D0D0D0Du, 0x0D0D0D0Du, 0x0D0D0D0Du};
         const int fbytes = bytes4 ? 1 : 2;                       // bytes per field
