@@ -165,6 +165,32 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// exclusive prefix sum of a small per-lane count over the wavefront, and the wave total (uniform)
+__device__ __forceinline__ void wave_excl_scan(uint32_t cnt, uint32_t &off, uint32_t &total) {
+    if (GE_DPP_SCAN) {
+        // inclusive scan by DPP: inside each row of 16 lanes (row_shr 1, 2, 4, 8), then
+        // row 0 -> 1 and 2 -> 3 (row_bcast:15), then rows 0-1 -> 2-3 (row_bcast:31)
+        uint32_t v = cnt;
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
+        off = v - cnt;
+        total = (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+    } else {
+        // one ballot per bit of the count (<= 15), mbcnt for the lanes below
+        off = 0; total = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const unsigned long long m = __ballot((cnt >> b) & 1u);
+            off += __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)) << b;
+            total += (uint32_t)__popcll(m) << b;
+        }
+    }
+}
+
 // candidate choice of one bot action (POLICY.md §3); shared by the per-lane loop and the queue
 template <int NB, bool TABLE>
 __device__ __forceinline__ uint32_t ww_choose(uint32_t act, uint32_t i, uint32_t d, uint32_t alive, uint32_t team_w,
@@ -290,32 +316,10 @@ __device__ __forceinline__ void ww_turn(WWR<NB> &s, DevRow &row, const DevRow *r
                 new_det_v |= tb & ~team_w;
             }
         } else {
-            // exclusive prefix sum of the per-room item counts (<= 12) over the wavefront:
-            // one ballot per bit of the count, mbcnt for the lanes below
             const uint32_t lane = __lane_id();
             const uint32_t cnt = popc(todo);
             uint32_t off, total;
-            if (GE_DPP_SCAN) {
-                // wavefront inclusive scan by DPP: inside each row of 16 lanes (row_shr 1, 2, 4, 8), then
-                // row 0 -> 1 and 2 -> 3 (row_bcast:15), then rows 0-1 -> 2-3 (row_bcast:31)
-                uint32_t v = cnt;
-                v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
-                v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
-                v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
-                v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
-                v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
-                v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
-                off = v - cnt;
-                total = (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
-            } else {
-                off = 0; total = 0;
-#pragma unroll
-                for (int b = 0; b < 4; b++) {
-                    const unsigned long long m = __ballot((cnt >> b) & 1u);
-                    off += __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)) << b;
-                    total += (uint32_t)__popcll(m) << b;
-                }
-            }
+            wave_excl_scan(cnt, off, total);
             if (LOWOCC || total != 0u) {                        // wave-uniform; LOWOCC: some room almost always has a due bot
                 // per-room context of an action; `ky`: what the acting role knows (the Detective's memory
                 // at night, who the Detective is by day - ww_choose reads only one of the two per kind)
@@ -504,8 +508,11 @@ __device__ __forceinline__ uint32_t even_bits(uint32_t x) {
     return x;
 }
 
-template <int NB>
-__device__ __forceinline__ void tt_turn(TT<NB> &s, uint32_t &done, DevRow &row, const DevRow *rows, bool valid, uint32_t n, uint32_t rounds,
+// QUEUE: bot actions through the wavefront work queue (see ww_turn) - pays from 8 players on, where the
+// first turn of a vote has 7-11 due bots in some room of every wavefront; TABLE: n-th-set-bit from LDS
+template <int NB, bool QUEUE, bool TABLE>
+__device__ __forceinline__ void tt_turn(TT<NB> &s, uint32_t &done, DevRow &row, const DevRow *rows, void *wave_lds, const uint8_t *nth8,
+                                        bool valid, uint32_t n, uint32_t rounds,
                                         uint32_t phase0_idx, uint32_t rkey, uint32_t turn,
                                         bool trace, uint32_t human, uint32_t &ev_newly, uint64_t &ev_choice) {
     // done: tt_done_mask of s.rounds, maintained here (the caller derives it when it loads or replaces s)
@@ -539,18 +546,63 @@ __device__ __forceinline__ void tt_turn(TT<NB> &s, uint32_t &done, DevRow &row, 
     {
         uint32_t todo = valid ? (T & ~s.acted & ~human) : 0u;
         const bool a_stm = act == ACT_TT_STATEMENTS, a_lie = act == ACT_TT_LIE, a_vote = act == ACT_TT_VOTE;
-        while (todo) {
-            const uint32_t i = ctz(todo);
-            todo &= todo - 1u;
-            const uint32_t d = draw(tk, i);
-            const bool go = (d & 3u) != 0u;
-            const uint32_t c = a_stm ? 1u : 1u + pick(d, 3u);
-            const uint32_t sh = 2u * i;
-            const uint32_t clr = ~(3u << sh), put = c << sh;
-            s.choice = go ? ((s.choice & clr) | put) : s.choice;
-            newly |= go ? (1u << i) : 0u;
-            s.lie = (go && a_lie) ? ((s.lie & clr) | put) : s.lie;
-            s.vote = (go && a_vote) ? ((s.vote & clr) | put) : s.vote;
+        if (!QUEUE) {
+            while (todo) {
+                const uint32_t i = ctz(todo);
+                todo &= todo - 1u;
+                const uint32_t d = draw(tk, i);
+                const bool go = (d & 3u) != 0u;
+                const uint32_t c = a_stm ? 1u : 1u + pick(d, 3u);
+                const uint32_t sh = 2u * i;
+                const uint32_t clr = ~(3u << sh), put = c << sh;
+                s.choice = go ? ((s.choice & clr) | put) : s.choice;
+                newly |= go ? (1u << i) : 0u;
+                s.lie = (go && a_lie) ? ((s.lie & clr) | put) : s.lie;
+                s.vote = (go && a_vote) ? ((s.vote & clr) | put) : s.vote;
+            }
+        } else {
+            // same slot protocol as ww_turn: prefix sum of the due counts, lane ids written highest slot
+            // first with immediate offsets, one slot per lane and round, results by LDS atomic OR
+            auto *lw = static_cast<WaveLds *>(wave_lds);
+            const uint32_t lane = __lane_id();
+            const uint32_t cnt = popc(todo);
+            uint32_t off, total;
+            wave_excl_scan(cnt, off, total);
+            if (total != 0u) {                                  // wave-uniform
+                lw->ctx[lane] = make_uint4(a_stm ? 1u : 0u, 0u, todo | (off << 16) | (lane << 26), tk);
+                lw->res[lane] = make_uint4(0u, 0u, 0u, 0u);
+                if (cnt != 0u) {
+                    uint8_t *qp = lw->queue + off;
+#pragma unroll
+                    for (int j = NB - 1; j >= 0; j--) {
+                        qp[j] = (uint8_t)lane;
+                        asm volatile("" ::: "memory");             // the stores must issue in this order
+                    }
+                }
+                wave_sync();
+                for (uint32_t base = 0; base < total; base += 64u) {
+                    const uint32_t k = base + lane;
+                    const uint4 c4 = lw->ctx[lw->queue[k] & 63u]; // slots past `total`: stale, result dropped
+                    const uint32_t L = c4.z >> 26;
+                    const uint32_t due = c4.z & 0xFFFFu, rank = (k - ((c4.z >> 16) & 0x3FFu)) & 15u;
+                    const uint32_t i = (TABLE ? nth_set_bit_lds<NB>(nth8, due, rank) : nth_set_bit<NB>(due | (1u << 31), rank)) & 15u;
+                    const uint32_t d = draw(c4.w, i);
+                    if (k < total && (d & 3u) != 0u) {
+                        const uint32_t c = c4.x ? 1u : 1u + pick(d, 3u);
+                        uint32_t *r = reinterpret_cast<uint32_t *>(&lw->res[L]);
+                        atomicOr(r, 1u << i);
+                        atomicOr(r + 1, c << (2u * i));
+                    }
+                }
+                wave_sync();
+                const uint4 r = lw->res[lane];
+                newly = r.x;
+                const uint32_t got = r.y;                        // 2 bits per player, c >= 1 for every actor
+                const uint32_t t1 = (got | (got >> 1)) & 0x00555555u, m2 = t1 | (t1 << 1);
+                s.choice = (s.choice & ~m2) | got;
+                s.lie = a_lie ? ((s.lie & ~m2) | got) : s.lie;
+                s.vote = a_vote ? ((s.vote & ~m2) | got) : s.vote;
+            }
         }
     }
     s.acted |= newly;

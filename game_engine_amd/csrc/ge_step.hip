@@ -165,16 +165,17 @@ __device__ __forceinline__ void run_ww(const SegDev *__restrict__ sgp, const Ste
     store_words<L::WORDS>(sg.base, sg.rooms_padded, room, w);
 }
 
-template <int NB>
-__device__ __forceinline__ void run_tt(const SegDev *__restrict__ sgp, const StepArgs &a, DevRow *rows,
+template <int NB, bool LOWOCC>
+__device__ __forceinline__ void run_tt(const SegDev *__restrict__ sgp, const StepArgs &a, DevRow *rows, void *lw, uint8_t *nth8,
                                        const DevTable *__restrict__ tables, uint64_t room_in) {
+    constexpr bool QUEUE = NB > 4;                            // the action queue pays from 8 players on (ge_device.h)
     const SegDev &sg = *sgp;
     using L = TTLayout<NB>;
     const bool valid = room_in < sg.rooms;
     const uint64_t room = valid ? room_in : 0;
     uint32_t w[L::WORDS];
     load_words<L::WORDS>(sg.base, sg.rooms_padded, room, w);
-    load_rows(rows, tables, sg.table_idx, nullptr);
+    load_rows(rows, tables, sg.table_idx, (QUEUE && !LOWOCC) ? nth8 : nullptr);
     TT<NB> s;
     L::unpack(w, s);
     const uint32_t rk = room_key_from(a.seed_key, sg.first_global + room);
@@ -200,7 +201,7 @@ __device__ __forceinline__ void run_tt(const SegDev *__restrict__ sgp, const Ste
         const uint32_t p = s.phase;
         uint32_t ev_newly = 0;
         uint64_t ev_choice = 0;
-        tt_turn<NB>(s, done, row, rows, valid, sg.n_players, sg.rounds, sg.phase0_idx, rk, a.turn0 + t, a.trace != 0u, sg.human_mask, ev_newly, ev_choice);
+        tt_turn<NB, QUEUE, !LOWOCC>(s, done, row, rows, lw, nth8, valid, sg.n_players, sg.rounds, sg.phase0_idx, rk, a.turn0 + t, a.trace != 0u, sg.human_mask, ev_newly, ev_choice);
         if (a.trace && valid) store_event(sg.trace, sg.rooms_padded, t, room, a.turn0 + t, p, s.phase, restarted, ev_newly, ev_choice);
     }
     if (!valid) return;
@@ -218,9 +219,9 @@ __device__ __forceinline__ void run_kind(const SegDev *__restrict__ sg, const St
                                          uint8_t *nth8, const DevTable *__restrict__ tables, uint64_t room) {
     if (KIND == K_WW8) run_ww<8, LOWOCC>(sg, a, rows, lw, nth8, tables, room);
     else if (KIND == K_WW12) run_ww<12, LOWOCC>(sg, a, rows, lw, nth8, tables, room);
-    else if (KIND == K_TT4) run_tt<4>(sg, a, rows, tables, room);
-    else if (KIND == K_TT8) run_tt<8>(sg, a, rows, tables, room);
-    else run_tt<12>(sg, a, rows, tables, room);
+    else if (KIND == K_TT4) run_tt<4, LOWOCC>(sg, a, rows, lw, nth8, tables, room);
+    else if (KIND == K_TT8) run_tt<8, LOWOCC>(sg, a, rows, lw, nth8, tables, room);
+    else run_tt<12, LOWOCC>(sg, a, rows, lw, nth8, tables, room);
 }
 
 // LDS of a step block, sized at launch (a 64-room block must not pay for four wavefronts' queues, or
@@ -229,8 +230,8 @@ constexpr uint32_t LDS_ROWS = sizeof(DevRow) * GE_MAX_PHASES;
 constexpr uint32_t LDS_NTH8 = 2048;
 static_assert(sizeof(WaveLds) % 16 == 0 && sizeof(WaveLdsLow) % 16 == 0 && LDS_ROWS % 16 == 0, "LDS sections stay 16-byte aligned");
 
-inline uint32_t step_lds_bytes(bool werewolf, bool lowocc, uint32_t block_threads) {
-    if (!werewolf) return LDS_ROWS;
+inline uint32_t step_lds_bytes(bool queue, bool lowocc, uint32_t block_threads) {
+    if (!queue) return LDS_ROWS;                              // Two-Truths N <= 4: phase rows only
     return LDS_ROWS + (lowocc ? 0u : LDS_NTH8) + (uint32_t)(lowocc ? sizeof(WaveLdsLow) : sizeof(WaveLds)) * (block_threads / 64u);
 }
 
@@ -241,7 +242,7 @@ extern __shared__ __align__(16) unsigned char ge_lds[];
 template <int KIND, bool LOWOCC>
 __global__ void __launch_bounds__(256) ge_step_kernel(const StepArgs a, const SegDev *__restrict__ segs,
                                                       const DevTable *__restrict__ tables) {
-    constexpr bool WWK = KIND == K_WW8 || KIND == K_WW12;
+    constexpr bool WWK = KIND != K_TT4;                       // kinds that use the action queue
     DevRow *rows = reinterpret_cast<DevRow *>(ge_lds);
     uint8_t *nth8 = ge_lds + LDS_ROWS;
     auto *wl = reinterpret_cast<typename WaveLdsOf<LOWOCC>::type *>(ge_lds + LDS_ROWS + (LOWOCC ? 0u : LDS_NTH8));
@@ -768,17 +769,17 @@ int ge_batch_step(ge_batch *b, uint32_t n_turns, void *hip_stream) {
             HIP_TRY(hipEventRecord(e0, st));
         }
         const dim3 grid(b->n_blocks), block(b->block_threads);
-#define GE_LAUNCH(KERNEL, WWK) hipLaunchKernelGGL(KERNEL, grid, block, step_lds_bytes(WWK, low, b->block_threads), st, a, b->segs_dev, b->tables)
+#define GE_LAUNCH(KERNEL, QUEUE, LOW) hipLaunchKernelGGL(KERNEL, grid, block, step_lds_bytes(QUEUE, LOW, b->block_threads), st, a, b->segs_dev, b->tables)
         const bool low = a.lowocc != 0u;
         if (b->segs.size() > 1) {
-            if (low) GE_LAUNCH(ge_step_kernel_mixed<true>, true); else GE_LAUNCH(ge_step_kernel_mixed<false>, true);
+            if (low) GE_LAUNCH(ge_step_kernel_mixed<true>, true, true); else GE_LAUNCH(ge_step_kernel_mixed<false>, true, false);
         } else {
             switch (b->segs[0].dev.kind) {
-            case K_WW8: if (low) GE_LAUNCH((ge_step_kernel<K_WW8, true>), true); else GE_LAUNCH((ge_step_kernel<K_WW8, false>), true); break;
-            case K_WW12: if (low) GE_LAUNCH((ge_step_kernel<K_WW12, true>), true); else GE_LAUNCH((ge_step_kernel<K_WW12, false>), true); break;
-            case K_TT4: GE_LAUNCH((ge_step_kernel<K_TT4, false>), false); break;
-            case K_TT8: GE_LAUNCH((ge_step_kernel<K_TT8, false>), false); break;
-            default: GE_LAUNCH((ge_step_kernel<K_TT12, false>), false); break;
+            case K_WW8: if (low) GE_LAUNCH((ge_step_kernel<K_WW8, true>), true, true); else GE_LAUNCH((ge_step_kernel<K_WW8, false>), true, false); break;
+            case K_WW12: if (low) GE_LAUNCH((ge_step_kernel<K_WW12, true>), true, true); else GE_LAUNCH((ge_step_kernel<K_WW12, false>), true, false); break;
+            case K_TT4: GE_LAUNCH((ge_step_kernel<K_TT4, false>), false, false); break;      // Two-Truths: one build
+            case K_TT8: GE_LAUNCH((ge_step_kernel<K_TT8, false>), true, false); break;
+            default: GE_LAUNCH((ge_step_kernel<K_TT12, false>), true, false); break;
             }
         }
 #undef GE_LAUNCH

@@ -191,21 +191,27 @@ def test_fused_equals_unfused_and_chunked(dsl_ww):
     assert outs[0] == outs[1] == outs[2] == outs[3]
 
 
-@pytest.mark.parametrize("n_ww,n_tt,n_ww12", [(3000, 5000, 700),          # lone-wavefront build of the mixed kernel
-                                               (60000, 50000, 30001)])     # large-batch build, 64-room blocks
-def test_mixed_batch_one_launch(dsl_ww, dsl_tt, n_ww, n_tt, n_ww12):
-    """BASELINE config C5 shape: Werewolf and Two-Truths rooms (different phase graphs and record
-    layouts) advanced by the same launches; global room indices run across segments."""
+@pytest.mark.parametrize("players,sizes", [
+    ((8, 4, 12, 12), (3000, 5000, 700, 1100)),               # (Werewolf, Two-Truths, Werewolf, Two-Truths) players; lone-wavefront build
+    ((8, 7, 9, 4), (2000, 900, 1500, 3000)),
+    ((8, 4, 12, 12), (50000, 40000, 30001, 15000)),          # large-batch build of the mixed kernel, 64-room blocks
+    ((8, 7, 9, 4), (60000, 20000, 30000, 25000))])
+def test_mixed_batch_one_launch(dsl_ww, dsl_tt, players, sizes):
+    """BASELINE config C5 shape and beyond: Werewolf and Two-Truths rooms of several sizes (different
+    phase graphs, record layouts and action paths) advanced by the same launches; global room indices
+    run across segments."""
     ww, tt = GameTable(dsl_ww), GameTable(dsl_tt)
     turns, seed, first = 64, 0xC0FFEE, 1 << 33
-    with RoomBatch([(ww, 8, n_ww), (tt, 4, n_tt), (ww, 12, n_ww12)], seed=seed, first_room=first) as b:
+    segs = [(dsl_ww, ww, players[0]), (dsl_tt, tt, players[1]), (dsl_ww, ww, players[2]), (dsl_tt, tt, players[3])]
+    with RoomBatch([(tb, n, r) for (_, tb, n), r in zip(segs, sizes)], seed=seed, first_room=first) as b:
         b.step(turns)
         got = b.read_rooms()
         s = b.summary()
-    assert_views_equal(got[:n_ww], oracle_batch(_oracle(dsl_ww, 8), n_ww, seed, first, turns), "ww8 segment")
-    assert_views_equal(got[n_ww:n_ww + n_tt], oracle_batch(_oracle(dsl_tt, 4), n_tt, seed, first + n_ww, turns), "tt4 segment")
-    assert_views_equal(got[n_ww + n_tt:], oracle_batch(_oracle(dsl_ww, 12), n_ww12, seed, first + n_ww + n_tt, turns), "ww12 segment")
-    assert s["rooms"] == n_ww + n_tt + n_ww12 and s["finished"] == int((got["end_turn"] >= 0).sum())
+    lo = 0
+    for (dsl, _, n), r in zip(segs, sizes):
+        assert_views_equal(got[lo:lo + r], oracle_batch(_oracle(dsl, n), r, seed, first + lo, turns), f"segment n={n} at {lo}")
+        lo += r
+    assert s["rooms"] == sum(sizes) and s["finished"] == int((got["end_turn"] >= 0).sum())
 
 
 def test_mixed_batch_full_c5_share_equals_oracle(dsl_ww, dsl_tt):
