@@ -165,10 +165,18 @@ __device__ __forceinline__ void run_ww(const SegDev *__restrict__ sgp, const Ste
     store_words<L::WORDS>(sg.base, sg.rooms_padded, room, w);
 }
 
+// Two-Truths: which builds route bot actions through the wavefront queue.  Many wavefronts per SIMD:
+// always (x4: 5.35 -> 4.87 us/turn at 1M rooms).  Lone wavefront: the two extra LDS round trips cost more
+// than the per-lane loop saves for few players (x4: 0.91 vs 1.03 us/turn at 65 536 rooms).
+#ifndef GE_TT_LOW_QUEUE_MIN
+#define GE_TT_LOW_QUEUE_MIN 5
+#endif
+constexpr bool tt_uses_queue(int nb, bool lowocc) { return !lowocc || nb >= GE_TT_LOW_QUEUE_MIN; }
+
 template <int NB, bool LOWOCC>
 __device__ __forceinline__ void run_tt(const SegDev *__restrict__ sgp, const StepArgs &a, DevRow *rows, void *lw, uint8_t *nth8,
                                        const DevTable *__restrict__ tables, uint64_t room_in) {
-    constexpr bool QUEUE = NB > 4;                            // the action queue pays from 8 players on (ge_device.h)
+    constexpr bool QUEUE = tt_uses_queue(NB, LOWOCC);
     const SegDev &sg = *sgp;
     using L = TTLayout<NB>;
     const bool valid = room_in < sg.rooms;
@@ -242,7 +250,7 @@ extern __shared__ __align__(16) unsigned char ge_lds[];
 template <int KIND, bool LOWOCC>
 __global__ void __launch_bounds__(256) ge_step_kernel(const StepArgs a, const SegDev *__restrict__ segs,
                                                       const DevTable *__restrict__ tables) {
-    constexpr bool WWK = KIND != K_TT4;                       // kinds that use the action queue
+    constexpr bool WWK = KIND == K_WW8 || KIND == K_WW12 || tt_uses_queue(KIND == K_TT4 ? 4 : KIND == K_TT8 ? 8 : 12, LOWOCC);   // uses the action queue
     DevRow *rows = reinterpret_cast<DevRow *>(ge_lds);
     uint8_t *nth8 = ge_lds + LDS_ROWS;
     auto *wl = reinterpret_cast<typename WaveLdsOf<LOWOCC>::type *>(ge_lds + LDS_ROWS + (LOWOCC ? 0u : LDS_NTH8));
@@ -777,9 +785,9 @@ int ge_batch_step(ge_batch *b, uint32_t n_turns, void *hip_stream) {
             switch (b->segs[0].dev.kind) {
             case K_WW8: if (low) GE_LAUNCH((ge_step_kernel<K_WW8, true>), true, true); else GE_LAUNCH((ge_step_kernel<K_WW8, false>), true, false); break;
             case K_WW12: if (low) GE_LAUNCH((ge_step_kernel<K_WW12, true>), true, true); else GE_LAUNCH((ge_step_kernel<K_WW12, false>), true, false); break;
-            case K_TT4: GE_LAUNCH((ge_step_kernel<K_TT4, false>), false, false); break;      // Two-Truths: one build
-            case K_TT8: GE_LAUNCH((ge_step_kernel<K_TT8, false>), true, false); break;
-            default: GE_LAUNCH((ge_step_kernel<K_TT12, false>), true, false); break;
+            case K_TT4: if (low) GE_LAUNCH((ge_step_kernel<K_TT4, true>), tt_uses_queue(4, true), true); else GE_LAUNCH((ge_step_kernel<K_TT4, false>), true, false); break;
+            case K_TT8: if (low) GE_LAUNCH((ge_step_kernel<K_TT8, true>), tt_uses_queue(8, true), true); else GE_LAUNCH((ge_step_kernel<K_TT8, false>), true, false); break;
+            default: if (low) GE_LAUNCH((ge_step_kernel<K_TT12, true>), tt_uses_queue(12, true), true); else GE_LAUNCH((ge_step_kernel<K_TT12, false>), true, false); break;
             }
         }
 #undef GE_LAUNCH
