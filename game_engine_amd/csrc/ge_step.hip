@@ -41,6 +41,7 @@ struct SegDev {
 };
 
 struct StepArgs {
+    const uint32_t *turn_dev;  // launches replayed from a hipGraph: turn0 is relative to this device word (else null)
     uint32_t n_seg, turn0, n_turns, seed_key, block_threads, restart, trace, lowocc;
     uint32_t block_begin[GE_MAX_SEGMENTS];
 };
@@ -130,6 +131,7 @@ __device__ __forceinline__ void run_ww(const SegDev *__restrict__ sgp, const Ste
         s0.from(u);
     }
     const DevRow row0 = rows[sg.phase0_idx];
+    const uint32_t turn0 = a.turn0 + (a.turn_dev ? *a.turn_dev : 0u);   // uniform (scalar load)
     // Role deals are keyed by (room, game index), so they can be prepared before the turn that applies
     // them.  Entering the role-assignment phase is rare per room (once a game) but in a wavefront of 64
     // rooms some room does it on ~80 % of the turns; instead of running the deal for that one lane, every
@@ -154,9 +156,9 @@ __device__ __forceinline__ void run_ww(const SegDev *__restrict__ sgp, const Ste
         const uint32_t p = s.phase;
         uint32_t ev_newly = 0;
         uint64_t ev_choice = 0;
-        ww_turn<NB, GE_WAVE_QUEUE, LOWOCC>(s, row, rows, lw, nth8, valid, sg.n_players, sg.nw, sg.phase0_idx, rk, a.turn0 + t,
+        ww_turn<NB, GE_WAVE_QUEUE, LOWOCC>(s, row, rows, lw, nth8, valid, sg.n_players, sg.nw, sg.phase0_idx, rk, turn0 + t,
                                    a.trace != 0u, sg.human_mask, deal, ev_newly, ev_choice);
-        if (a.trace && valid) store_event(sg.trace, sg.rooms_padded, t, room, a.turn0 + t, p, s.phase, restarted, ev_newly, ev_choice);
+        if (a.trace && valid) store_event(sg.trace, sg.rooms_padded, t, room, turn0 + t, p, s.phase, restarted, ev_newly, ev_choice);
     }
     if (!valid) return;
     WW<NB> u;
@@ -194,6 +196,7 @@ __device__ __forceinline__ void run_tt(const SegDev *__restrict__ sgp, const Ste
     TT<NB> s0;
     L::unpack(iw, s0);
     const DevRow row0 = rows[sg.phase0_idx];
+    const uint32_t turn0 = a.turn0 + (a.turn_dev ? *a.turn_dev : 0u);
     uint32_t done = tt_done_mask<NB>(s.rounds, sg.rounds);   // who has spoken all agreed rounds (ge_device.h)
     const uint32_t done0 = tt_done_mask<NB>(s0.rounds, sg.rounds);
     for (uint32_t t = 0; t < a.n_turns; t++) {
@@ -209,8 +212,8 @@ __device__ __forceinline__ void run_tt(const SegDev *__restrict__ sgp, const Ste
         const uint32_t p = s.phase;
         uint32_t ev_newly = 0;
         uint64_t ev_choice = 0;
-        tt_turn<NB, QUEUE, !LOWOCC>(s, done, row, rows, lw, nth8, valid, sg.n_players, sg.rounds, sg.phase0_idx, rk, a.turn0 + t, a.trace != 0u, sg.human_mask, ev_newly, ev_choice);
-        if (a.trace && valid) store_event(sg.trace, sg.rooms_padded, t, room, a.turn0 + t, p, s.phase, restarted, ev_newly, ev_choice);
+        tt_turn<NB, QUEUE, !LOWOCC>(s, done, row, rows, lw, nth8, valid, sg.n_players, sg.rounds, sg.phase0_idx, rk, turn0 + t, a.trace != 0u, sg.human_mask, ev_newly, ev_choice);
+        if (a.trace && valid) store_event(sg.trace, sg.rooms_padded, t, room, turn0 + t, p, s.phase, restarted, ev_newly, ev_choice);
     }
     if (!valid) return;
     L::pack(s, w);
@@ -374,6 +377,10 @@ __global__ void __launch_bounds__(256) ge_summary_kernel(const StepArgs a, const
     if (threadIdx.x >= 64 && threadIdx.x < 80 && h_end[threadIdx.x - 64]) atomicAdd(&out[5 + threadIdx.x - 64], (unsigned long long)h_end[threadIdx.x - 64]);
     if (threadIdx.x >= 128 && threadIdx.x < 144 && h_score[threadIdx.x - 128]) atomicAdd(&out[21 + threadIdx.x - 128], (unsigned long long)h_score[threadIdx.x - 128]);
 }
+
+// last node of a captured sequence of step launches: the device-side turn base moves on, so the same
+// graph can be replayed for the next n turns
+__global__ void ge_turn_bump(uint32_t *turn, uint32_t n) { *turn += n; }
 
 thread_local int g_last_hip = 0;
 
@@ -565,6 +572,12 @@ struct ge_batch {
     SegDev *segs_dev = nullptr;
     unsigned long long *sum_dev = nullptr;
     hipStream_t last_stream = nullptr;
+    // hipGraph replay of launch-bound step sequences (many short launches per ge_batch_step call)
+    uint32_t *turn_dev = nullptr;     // turn base the captured launches read
+    uint64_t turn_dev_value = ~0ull;  // what *turn_dev holds (host mirror)
+    hipStream_t cap_stream = nullptr; // capture needs a non-default stream
+    std::vector<std::pair<uint32_t, hipGraphExec_t>> graphs;   // per n_turns
+    bool graphs_ok = true;
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     size_t events_used = 0;
@@ -752,6 +765,60 @@ int ge_batch_set_timing(ge_batch *b, int on) {
     return GE_OK;
 }
 
+static hipError_t launch_step(const ge_batch *b, const StepArgs &a, hipStream_t st) {
+    const dim3 grid(b->n_blocks), block(b->block_threads);
+#define GE_LAUNCH(KERNEL, QUEUE, LOW) hipLaunchKernelGGL(KERNEL, grid, block, step_lds_bytes(QUEUE, LOW, b->block_threads), st, a, b->segs_dev, b->tables)
+    const bool low = a.lowocc != 0u;
+    if (b->segs.size() > 1) {
+        if (low) GE_LAUNCH(ge_step_kernel_mixed<true>, true, true); else GE_LAUNCH(ge_step_kernel_mixed<false>, true, false);
+    } else {
+        switch (b->segs[0].dev.kind) {
+        case K_WW8: if (low) GE_LAUNCH((ge_step_kernel<K_WW8, true>), true, true); else GE_LAUNCH((ge_step_kernel<K_WW8, false>), true, false); break;
+        case K_WW12: if (low) GE_LAUNCH((ge_step_kernel<K_WW12, true>), true, true); else GE_LAUNCH((ge_step_kernel<K_WW12, false>), true, false); break;
+        case K_TT4: if (low) GE_LAUNCH((ge_step_kernel<K_TT4, true>), tt_uses_queue(4, true), true); else GE_LAUNCH((ge_step_kernel<K_TT4, false>), true, false); break;
+        case K_TT8: if (low) GE_LAUNCH((ge_step_kernel<K_TT8, true>), tt_uses_queue(8, true), true); else GE_LAUNCH((ge_step_kernel<K_TT8, false>), true, false); break;
+        default: if (low) GE_LAUNCH((ge_step_kernel<K_TT12, true>), tt_uses_queue(12, true), true); else GE_LAUNCH((ge_step_kernel<K_TT12, false>), true, false); break;
+        }
+    }
+#undef GE_LAUNCH
+    return hipGetLastError();
+}
+
+// A ge_batch_step call that needs many launches (small max_fuse: interactive or traced stepping) is
+// launch-bound for small batches; the sequence is captured once per n_turns into a hipGraph whose
+// launches take their first turn relative to a device word, and replayed.
+constexpr uint32_t GRAPH_MIN_LAUNCHES = 4;
+
+static hipGraphExec_t graph_for(ge_batch *b, uint32_t n_turns) {
+    for (auto &g : b->graphs)
+        if (g.first == n_turns) return g.second;
+    if (!b->turn_dev && hipMalloc(reinterpret_cast<void **>(&b->turn_dev), sizeof(uint32_t)) != hipSuccess) return nullptr;
+    if (!b->cap_stream && hipStreamCreateWithFlags(&b->cap_stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    if (hipStreamBeginCapture(b->cap_stream, hipStreamCaptureModeThreadLocal) != hipSuccess) return nullptr;
+    bool ok = true;
+    for (uint32_t done = 0; done < n_turns && ok; ) {
+        const uint32_t k = (n_turns - done) < b->max_fuse ? (n_turns - done) : b->max_fuse;
+        StepArgs a;
+        fill_args(b, a, done, k);
+        a.turn_dev = b->turn_dev;
+        ok = launch_step(b, a, b->cap_stream) == hipSuccess;
+        done += k;
+    }
+    if (ok) {
+        hipLaunchKernelGGL(ge_turn_bump, dim3(1), dim3(1), 0, b->cap_stream, b->turn_dev, n_turns);
+        ok = hipGetLastError() == hipSuccess;
+    }
+    hipGraph_t graph = nullptr;
+    if (hipStreamEndCapture(b->cap_stream, &graph) != hipSuccess || !graph) return nullptr;   // always ends the capture
+    hipGraphExec_t exec = nullptr;
+    if (ok && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) exec = nullptr;
+    (void)hipGraphDestroy(graph);
+    if (!ok || !exec) return nullptr;
+    if (b->graphs.size() >= 8) { (void)hipGraphExecDestroy(b->graphs.front().second); b->graphs.erase(b->graphs.begin()); }
+    b->graphs.emplace_back(n_turns, exec);
+    return exec;
+}
+
 int ge_batch_step(ge_batch *b, uint32_t n_turns, void *hip_stream) {
     if (!b) return GE_ERR_ARG;
     if (b->turn + n_turns > 0xFFFFFFFFull) return GE_ERR_RANGE;
@@ -760,6 +827,22 @@ int ge_batch_step(ge_batch *b, uint32_t n_turns, void *hip_stream) {
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     HIP_TRY(hipSetDevice(b->device));
     b->last_stream = st;
+    const uint32_t n_launch = (n_turns + b->max_fuse - 1) / b->max_fuse;
+    static const bool no_graph = getenv("GE_NO_GRAPH") != nullptr;           // A/B runs
+    if (n_launch >= GRAPH_MIN_LAUNCHES && !b->timing && b->graphs_ok && !no_graph) {
+        hipGraphExec_t exec = graph_for(b, n_turns);
+        if (exec) {
+            if (b->turn_dev_value != b->turn)
+                HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(b->turn_dev), (int)(uint32_t)b->turn, 1, st));
+            HIP_TRY(hipGraphLaunch(exec, st));
+            b->turn += n_turns;
+            b->turn_dev_value = b->turn;
+            b->launches += n_launch;
+            return GE_OK;
+        }
+        b->graphs_ok = false;                                   // capture unsupported here: plain launches from now on
+        (void)hipGetLastError();
+    }
     uint32_t left = n_turns;
     while (left) {
         const uint32_t k = left < b->max_fuse ? left : b->max_fuse;
@@ -776,22 +859,7 @@ int ge_batch_step(ge_batch *b, uint32_t n_turns, void *hip_stream) {
             b->events_used++;
             HIP_TRY(hipEventRecord(e0, st));
         }
-        const dim3 grid(b->n_blocks), block(b->block_threads);
-#define GE_LAUNCH(KERNEL, QUEUE, LOW) hipLaunchKernelGGL(KERNEL, grid, block, step_lds_bytes(QUEUE, LOW, b->block_threads), st, a, b->segs_dev, b->tables)
-        const bool low = a.lowocc != 0u;
-        if (b->segs.size() > 1) {
-            if (low) GE_LAUNCH(ge_step_kernel_mixed<true>, true, true); else GE_LAUNCH(ge_step_kernel_mixed<false>, true, false);
-        } else {
-            switch (b->segs[0].dev.kind) {
-            case K_WW8: if (low) GE_LAUNCH((ge_step_kernel<K_WW8, true>), true, true); else GE_LAUNCH((ge_step_kernel<K_WW8, false>), true, false); break;
-            case K_WW12: if (low) GE_LAUNCH((ge_step_kernel<K_WW12, true>), true, true); else GE_LAUNCH((ge_step_kernel<K_WW12, false>), true, false); break;
-            case K_TT4: if (low) GE_LAUNCH((ge_step_kernel<K_TT4, true>), tt_uses_queue(4, true), true); else GE_LAUNCH((ge_step_kernel<K_TT4, false>), true, false); break;
-            case K_TT8: if (low) GE_LAUNCH((ge_step_kernel<K_TT8, true>), tt_uses_queue(8, true), true); else GE_LAUNCH((ge_step_kernel<K_TT8, false>), true, false); break;
-            default: if (low) GE_LAUNCH((ge_step_kernel<K_TT12, true>), tt_uses_queue(12, true), true); else GE_LAUNCH((ge_step_kernel<K_TT12, false>), true, false); break;
-            }
-        }
-#undef GE_LAUNCH
-        HIP_TRY(hipGetLastError());
+        HIP_TRY(launch_step(b, a, st));
         if (b->timing) HIP_TRY(hipEventRecord(e1, st));
         b->launches++;
         b->turn += k;
@@ -1017,6 +1085,9 @@ void ge_batch_destroy(ge_batch *b) {
     if (!b) return;
     (void)hipSetDevice(b->device);
     for (auto &ev : b->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    for (auto &g : b->graphs) (void)hipGraphExecDestroy(g.second);
+    if (b->cap_stream) (void)hipStreamDestroy(b->cap_stream);
+    if (b->turn_dev) (void)hipFree(b->turn_dev);
     if (b->state) (void)hipFree(b->state);
     if (b->trace) (void)hipFree(b->trace);
     if (b->tables) (void)hipFree(b->tables);

@@ -340,6 +340,26 @@ def test_counters_saturate_like_the_oracle(game, n):
     assert done.any() and (want["end_turn"][done] == 65534).all()      # whoever is finished right now finished late
 
 
+def test_graph_replay_of_short_launches_equals_fused(dsl_ww, dsl_tt):
+    """A step() call that needs >= 4 launches (small max_fuse) is captured into a hipGraph per n_turns and
+    replayed with a device-side turn base; mixing replays, plain launches and resets must not change a bit."""
+    for dsl, n in ((dsl_ww, 8), (dsl_tt, 4)):
+        tb, R, seed, first = GameTable(dsl), 5000, 77, 12345
+        plan = [7, 7, 7, 2, 7, 9, 1, 9, 7]
+        with RoomBatch([(tb, n, R)], seed=seed, first_room=first, max_fuse=1, restart=True) as g, \
+             RoomBatch([(tb, n, R)], seed=seed, first_room=first, max_fuse=64, restart=True) as f:
+            for rep in range(2):
+                for k in plan:
+                    g.step(k)
+                f.step(sum(plan))
+                assert g.turn == f.turn == sum(plan)
+                assert g.read_rooms().tobytes() == f.read_rooms().tobytes(), f"n={n} pass {rep}"
+                if rep == 0:
+                    want = oracle_batch(_oracle(dsl, n), R, seed, first, sum(plan), restart=True)
+                    assert_views_equal(g.read_rooms(), want, f"graph path vs oracle n={n}")
+                    g.reset(); f.reset()
+
+
 def test_argument_and_range_errors(dsl_ww, dsl_tt):
     tb = GameTable(dsl_ww)
     for n in (3, 13):
