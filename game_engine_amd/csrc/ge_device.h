@@ -3,10 +3,11 @@
 // What a turn is: one graph run of the reference,
 //   BotBehaviorNode (agent/game_agent_v2.py:468) -> PhaseNode (:987) -> RefereeNode (:619),
 // with the LLM decisions fixed by POLICY.md.  Lane = room: a 64-wide wavefront advances 64
-// independent rooms; all per-player work inside a room is bit-parallel over N-bit masks
-// (ge_layout.h), so there is no cross-lane traffic on the step path at all.
-// Integer / branchy code: no MFMA (there is no contraction here), VALU + a little LDS
-// (the phase table, 16 B per row).
+// independent rooms; the per-room rules (conditions, tallies, eliminations, scoring) are bit-parallel
+// over N-bit masks (ge_layout.h).  The one badly balanced part, the bots' actions, is spread over
+// the wavefront through a work queue in LDS (WaveLds below).
+// Integer / branchy code: no MFMA (there is no contraction here), VALU + LDS (the phase table,
+// 32 B per row, the queue, a 2 KB n-th-set-bit table).
 #pragma once
 #include <hip/hip_runtime.h>
 #include "ge_layout.h"

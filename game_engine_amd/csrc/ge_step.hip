@@ -20,8 +20,8 @@ using namespace ge;
 namespace {
 
 // A/B switch for the bot-action step: wave-level work queue in LDS (true) or per-lane loop (false).
-// Measured on MI355X (steady state, K=64): 1 048 576 Werewolf x8 rooms 6.35e10 vs 4.45e10 steps/s,
-// 2 097 152 x12 4.89e10 vs 2.90e10, 65 536 x8 2.38e10 vs 2.26e10 (profiles/r01_queue_ab.txt).
+// Measured on MI355X (steady state, K=64): 1 048 576 Werewolf x8 rooms 1.19e11 vs 6.2e10 steps/s,
+// 2 097 152 x12 9.4e10 vs 3.7e10, 65 536 x8 4.4e10 vs 3.6e10 (profiles/r01_queue_ab.txt).
 #ifndef GE_WAVE_QUEUE
 #define GE_WAVE_QUEUE true
 #endif
