@@ -4,8 +4,8 @@ set -u
 TAG=$1; ROOMS=$2
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/sq_$TAG; mkdir -p "$OUT"
-rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_ANY --output-format csv -d "$OUT/a" -- python3 bench.py --no-cpu-baseline --no-unfused --no-other-shapes --no-from-init --steps 512 --rooms $ROOMS > "$OUT/a.json" 2> "$OUT/a.err" || echo a failed
-rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_INSTS_BRANCH SQ_INSTS_SMEM SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_SALU --output-format csv -d "$OUT/b" -- python3 bench.py --no-cpu-baseline --no-unfused --no-other-shapes --no-from-init --steps 512 --rooms $ROOMS > "$OUT/b.json" 2> "$OUT/b.err" || echo b failed
+rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_ANY --output-format csv -d "$OUT/a" -- python3 bench.py --no-cpu-baseline --no-unfused --no-other-shapes --no-from-init --fuse 64 --warmup 64 --steps 512 --rooms $ROOMS > "$OUT/a.json" 2> "$OUT/a.err" || echo a failed
+rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_INSTS_BRANCH SQ_INSTS_SMEM SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_SALU --output-format csv -d "$OUT/b" -- python3 bench.py --no-cpu-baseline --no-unfused --no-other-shapes --no-from-init --fuse 64 --warmup 64 --steps 512 --rooms $ROOMS > "$OUT/b.json" 2> "$OUT/b.err" || echo b failed
 python3 - "$OUT" $ROOMS <<'PY'
 import csv, glob, sys, statistics
 out, rooms = sys.argv[1], int(sys.argv[2])
