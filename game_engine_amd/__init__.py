@@ -7,5 +7,7 @@ libge_step.so (HIP, gfx950) behind the C ABI of include/ge_step.h; there is no C
 from .stepper import (GameTable, RoomBatch, GeError, load_dsl_by_gamename, initialize_player_states_from_dsl, library_path,
                       ROOM_VIEW_DTYPE, EVENT_DTYPE, WW_FIELDS, TT_FIELDS)
 
-__all__ = ["GameTable", "RoomBatch", "GeError", "load_dsl_by_gamename", "initialize_player_states_from_dsl", "library_path",
+from .room_service import RoomService, room_index_of
+
+__all__ = ["RoomService", "room_index_of", "GameTable", "RoomBatch", "GeError", "load_dsl_by_gamename", "initialize_player_states_from_dsl", "library_path",
            "ROOM_VIEW_DTYPE", "EVENT_DTYPE", "WW_FIELDS", "TT_FIELDS"]

@@ -12,6 +12,7 @@ const out = { phases: table.info.phases.length, pack: table.info.pack, devices: 
   const bare = JSON.parse(JSON.stringify(dsl)); delete bare.declaration.player_states_template;
   out.initFromSchema = initializePlayers(bare, players.slice(0, 1));
   out.initFallback = initializePlayers({ declaration: {} }, players);
+  out.roomIndex = require('./room_service.js').roomIndexOf('thread-42 ✓').toString();
   if (process.env.GE_TEST_GAMES_DIR) out.found = [findGameFile('Werewolf (Mafia)', process.env.GE_TEST_GAMES_DIR), findGameFile('chess', process.env.GE_TEST_GAMES_DIR)];
 }
 if (deviceCount() === 0) {

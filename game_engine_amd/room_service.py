@@ -1,0 +1,96 @@
+"""RoomService — the single-room drop-in for Python hosts (twin of node/room_service.js).
+
+In the reference one LangGraph thread is one room, and every "Continue" message is one run of the
+graph (agent/game_agent_v2.py:1571-1587) that returns the AgentState (v2:97-117) plus an AIMessage
+whose tool calls drive the frontend.  `continue_room(thread_id)` is that run without the LLM: an N=1
+traced batch advances the room by one turn; the turn comes back as the reference's backend tool
+calls (toolcalls.turn_tool_calls, agent/tools/backend_tools.py:10-157) and the phase now showing as
+frontend tool calls (ui_script.ui_tool_calls); the log-shaped parts of AgentState the packed state
+does not carry — playerActions (bt:285-344), game_notes (bt:163-202), phase_history (v2:1207-1215) —
+are folded from those calls exactly as the reference's `_execute_*` functions would.
+"""
+from __future__ import annotations
+
+import time
+from typing import Any, Dict, List, Optional
+
+from .stepper import GameTable, RoomBatch, load_dsl_by_gamename, view_to_agent_state
+from .toolcalls import turn_tool_calls
+from .ui_script import ui_tool_calls
+
+
+def room_index_of(thread_id: str) -> int:
+    """Stable 48-bit global room index of a thread id (FNV-1a 64, low 48 bits; same as the JS host):
+    the RNG is keyed by it, so a thread replays identically on any host."""
+    h = 0xCBF29CE484222325
+    for ch in str(thread_id).encode("utf-8"):
+        h ^= ch
+        h = (h * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF
+    return h & 0xFFFFFFFFFFFF
+
+
+class RoomService:
+    def __init__(self, games_dir: str = "games", seed: int = 0, device: int = 0):
+        self.games_dir, self.seed, self.device = games_dir, seed, device
+        self._tables: Dict[str, GameTable] = {}
+        self._rooms: Dict[str, Dict[str, Any]] = {}
+
+    def table(self, game_name: str, dsl: Optional[dict] = None) -> GameTable:
+        if game_name not in self._tables:
+            self._tables[game_name] = GameTable(dsl if dsl else load_dsl_by_gamename(game_name, self.games_dir))
+        return self._tables[game_name]
+
+    def create_room(self, thread_id: str, game_name: str, players: List[Dict[str, Any]], dsl: Optional[dict] = None) -> Dict[str, Any]:
+        """players: roomSession.players as the lobby builds it; `isBot: False` marks a human seat, which
+        the bot policy never acts for (bot_behavior_system_prompt.txt:3) — use human_action for it."""
+        tb = self.table(game_name, dsl)
+        human_mask = sum(1 << i for i, p in enumerate(players) if p.get("isBot") is False)
+        batch = RoomBatch([(tb, len(players), 1, human_mask)], seed=self.seed, first_room=room_index_of(thread_id),
+                          device=self.device, max_fuse=1, trace=True)
+        room = {"batch": batch, "table": tb, "gameName": game_name,
+                "names": [p.get("name") or f"Player {i + 1}" for i, p in enumerate(players)],
+                "view": batch.read_rooms(0, 1)[0], "phase_history": [], "playerActions": {}, "game_notes": []}
+        self._rooms[thread_id] = room
+        return self._agent_state(room)
+
+    def _agent_state(self, room: Dict[str, Any]) -> Dict[str, Any]:
+        s = view_to_agent_state(room["table"], room["view"])
+        for i, pid in enumerate(sorted(s["player_states"], key=int)):
+            s["player_states"][pid] = {"name": room["names"][i], **s["player_states"][pid]}
+        s.update(gameName=room["gameName"], playerActions=room["playerActions"], phase_history=room["phase_history"],
+                 game_notes=room["game_notes"])
+        return s
+
+    def human_action(self, thread_id: str, player_id: int, choice: int) -> Dict[str, Any]:
+        """A human's vote / choice (logged by process_human_action_if_needed, agent/tools/utils.py:310-358)."""
+        room = self._rooms[thread_id]
+        room["batch"].inject_action(0, player_id, choice)
+        room["view"] = room["batch"].read_rooms(0, 1)[0]
+        return self._agent_state(room)
+
+    def continue_room(self, thread_id: str) -> Dict[str, Any]:
+        """One turn (one graph run): {"state": AgentState, "toolCalls": [...], "uiCalls": [...]}."""
+        room = self._rooms[thread_id]
+        batch, before = room["batch"], room["view"]
+        batch.step(1)
+        after = batch.read_rooms(0, 1)[0]
+        event = batch.read_events(0, 1)[0][0]
+        calls = turn_tool_calls(room["table"], before, after, event)
+        for c in calls:
+            if c["name"] == "update_player_actions":                                   # bt:285-344
+                pid = c["args"]["player_id"]
+                rec = room["playerActions"].setdefault(pid, {"name": room["names"][int(pid) - 1], "actions": {}})
+                aid = str(len(rec["actions"]) + 1)
+                rec["actions"][aid] = {"action": c["args"]["actions"], "timestamp": int(time.time() * 1000),
+                                       "phase": c["args"]["phase"], "id": aid}
+            elif c["name"] == "add_game_note":                                          # bt:163-202
+                mark = "🔴" if c["args"]["note_type"] == "CRITICAL" else "⏳"
+                room["game_notes"].append(f"{mark} {c['args']['note_type']}: {c['args']['content']}")
+        room["view"] = after
+        state = self._agent_state(room)
+        room["phase_history"].append({"phase_id": state["current_phase_id"], "phase_name": state["current_phase_name"]})   # v2:1207-1215
+        return {"state": state, "toolCalls": calls, "uiCalls": ui_tool_calls(room["table"].dsl, state)}
+
+    def close(self, thread_id: Optional[str] = None):
+        for tid in ([thread_id] if thread_id else list(self._rooms)):
+            self._rooms.pop(tid)["batch"].close()

@@ -60,6 +60,9 @@ def test_initialize_players_twin(tmp_path, monkeypatch):
     assert r["initFallback"] == {"player_states": {}, "fallback_mode": True,
                                  "message": "No template found, agent will generate player_states"}
     assert r["found"] == ["Werewolf-(Mafia).yaml", None]
+    # both hosts derive the same global room index (= RNG key) from a thread id
+    from game_engine_amd.room_service import room_index_of
+    assert int(r["roomIndex"]) == room_index_of("thread-42 ✓")
 
 
 @needs_node

@@ -146,3 +146,64 @@ def test_kernel_event_trace_equals_oracle(game, n, restart):
         assert b.read_rooms().tobytes() == oracle_rooms_as_views(orc, rooms).tobytes()
         with pytest.raises(Exception):
             b.step(17)                               # a traced step may not exceed max_fuse turns
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("game,n", [("werewolf-(mafia)", 8), ("two-truths-and-a-lie", 4)])
+def test_python_room_service_single_thread(game, n):
+    """RoomService (Python twin of node/room_service.js): one thread = one N=1 traced batch.  The state it
+    returns is the stepped room's; the log-shaped AgentState parts are the fold of the turn's tool calls;
+    a human seat only moves through human_action; the same thread id replays identically."""
+    from game_engine_amd import GameTable, RoomBatch, RoomService, room_index_of
+    from game_engine_amd.stepper import view_to_agent_state
+    dsl = load_dsl(game)
+    players = [{"name": f"P{i + 1}", "isBot": i != 0} for i in range(n)]          # seat 1 is a person
+    pick = 2 if game.startswith("werewolf") else 1             # "Player 2" / "statement 1": what the person always answers
+    svc = RoomService(seed=9)
+    st = svc.create_room("thread-A", game, players, dsl=dsl)
+    assert st["current_phase_id"] == 0 and sorted(st["player_states"], key=int) == [str(i + 1) for i in range(n)]
+    assert st["player_states"]["1"]["name"] == "P1"
+    tb = GameTable(dsl)
+    n_actions = n_notes = 0
+    with RoomBatch([(tb, n, 1, 1)], seed=9, first_room=room_index_of("thread-A"), max_fuse=1) as ref:
+        from game_engine_amd import GeError
+        accepted = 0
+        for t in range(60):
+            # the person in seat 1 tries to act before every turn; refusals (not a target, already acted,
+            # dead target) must agree between the service and a bare batch
+            ok_svc = ok_ref = True
+            try:
+                svc.human_action("thread-A", 1, pick)
+            except GeError:
+                ok_svc = False
+            try:
+                ref.inject_action(0, 1, pick)
+            except GeError:
+                ok_ref = False
+            assert ok_svc == ok_ref, t
+            accepted += ok_svc
+            out = svc.continue_room("thread-A")
+            ref.step(1)
+            want = view_to_agent_state(tb, ref.read_rooms(0, 1)[0])
+            got = out["state"]
+            assert got["current_phase_id"] == want["current_phase_id"], t
+            for pid, rec in want["player_states"].items():
+                assert {k: v for k, v in got["player_states"][pid].items() if k != "name"} == rec, (t, pid)
+            n_actions += sum(c["name"] == "update_player_actions" for c in out["toolCalls"])
+            n_notes += sum(c["name"] == "add_game_note" for c in out["toolCalls"])
+            assert all(c["args"]["player_id"] != "1" for c in out["toolCalls"] if c["name"] == "update_player_actions")
+            assert isinstance(out["uiCalls"], list)
+        assert len(got["phase_history"]) == 60 and len(got["game_notes"]) == n_notes
+        assert sum(len(r["actions"]) for r in got["playerActions"].values()) == n_actions > 0
+        assert accepted > 0 or game.startswith("werewolf")      # (seat 1 dies in the first night of this thread)
+    # a second service replays the same thread bit for bit
+    svc2 = RoomService(seed=9)
+    svc2.create_room("thread-A", game, players, dsl=dsl)
+    for _ in range(60):
+        try:
+            svc2.human_action("thread-A", 1, pick)
+        except GeError:
+            pass
+        last = svc2.continue_room("thread-A")
+    assert last["state"]["player_states"] == got["player_states"] and last["state"]["game_notes"] == got["game_notes"]
+    svc.close(); svc2.close()
