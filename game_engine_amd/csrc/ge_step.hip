@@ -1084,6 +1084,7 @@ int ge_batch_state(ge_batch *b, uint32_t segment, void **dev_ptr, size_t *bytes,
 void ge_batch_destroy(ge_batch *b) {
     if (!b) return;
     (void)hipSetDevice(b->device);
+    (void)hipStreamSynchronize(b->last_stream);               // nothing of this batch may still be running
     for (auto &ev : b->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     for (auto &g : b->graphs) (void)hipGraphExecDestroy(g.second);
     if (b->cap_stream) (void)hipStreamDestroy(b->cap_stream);
