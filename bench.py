@@ -1,28 +1,45 @@
 #!/usr/bin/env python3
 """bench.py — room-phase steps/sec of the batch stepper on N MI355X of one node.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]          (N>1: launched by torch.distributed.run)
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+N > 1 without WORLD_SIZE in the environment: this process starts N fresh rank processes
+(`python -m torch.distributed.run --nproc-per-node N bench.py ...`) BEFORE anything touches the GPU
+and relays rank 0's JSON line.  Launched under torch.distributed.run it is one rank of N.
 
 Workload (BASELINE.json configs[1], per GPU): 65 536 Werewolf rooms x 8 players,
-games/werewolf-(mafia).yaml, all players bots, LLM replaced by the fixed policy, in STEADY STATE
-(a finished room is recycled into a new game on its next turn) so that every one of the K timed
-steps advances every room through real game logic.  A "step" = one turn (= one LangGraph run in
-the reference) of every room of the batch.  Inputs are resident in HBM before the timed region.
+games/werewolf-(mafia).yaml, all players bots, LLM replaced by the fixed policy, in STEADY STATE:
+a finished room is recycled into a new game on its next turn, and the batch is always pre-rolled
+(untimed, >= PREROLL_TURNS turns, whatever --warmup says) so that the timed turns see rooms spread
+over all phases of the game.
+
+One bench STEP = one pass of the hot path over the whole batch = ONE fused launch: every room record
+is loaded from HBM once, advanced by `turns_fused_per_launch` turns (= LangGraph runs of the
+reference) in registers, and stored once.  `value` counts room-phase steps (room-turns):
+    value = rooms x ranks x turns_fused_per_launch x K / time of the K launches.
+Inputs are resident in HBM before the timed region.
 
 Prints ONE JSON line on rank 0 (contract in the task brief) with `roofline` (dominant kernel, HIP
-events on the launch stream) and `cpu_baseline` (the oracle's C restatement on the host cores;
-the ONLY place bench.py touches oracle/).
+events on the launch stream), `issue` (the bound that really holds for the fused kernel: wave
+instructions per second against the SIMD issue ceiling), `hbm_streaming` (the max_fuse=1 point, where
+every turn really streams the state) and `cpu_baseline` (the oracle's C restatement on the host
+cores; the ONLY place bench.py touches oracle/).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md:36
+HBM_COPY_GBS = 6290.0          # measured float4 copy, same line
+N_SIMD = 1024                  # 256 CUs x 4 SIMD-32
+CLOCK_HZ = 2.4e9               # max shader clock (guide :34)
+PREROLL_TURNS = 1024           # a Werewolf x8 game lasts ~40 turns: >= 25 games per slot before timing
 ROOMS_PER_GPU = 65536
 N_PLAYERS = 8
 GAME = "werewolf-(mafia)"
@@ -91,32 +108,50 @@ def cpu_baseline(dsl, budget_s=12.0):
             "single_thread_value": 4096 * t1 / dt_one}
 
 
-def pmc_traffic(alg_bytes_per_launch):
-    """HBM bytes per launch from a committed rocprofv3 --pmc pass of this same command
-    (profiles/pmc_traffic.json, written by tools/pmc_summary.py), or None.  The state is read once and
-    written once per launch whatever the number of fused turns, so the counters only describe a run
-    with the same rooms x record bytes: the file records the launch's read+write floor and is ignored
-    when this run's differs."""
-    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if not os.path.exists(p):
-        return None
+def committed_profile(workload):
+    """Counters of a committed rocprofv3 --pmc run of this same command (profiles/pmc_<workload>.json,
+    written by tools/pmc_summary.py), or {}.  PMC counters cannot be collected from inside the timed
+    run, so the bench line quotes the committed passes and says so (`source`)."""
+    p = os.path.join(ROOT, "profiles", f"pmc_{workload}.json")
     try:
         with open(p) as f:
             d = json.load(f)
-        floor = d.get("state_bytes_read_plus_written")
-        if floor is not None and abs(floor - alg_bytes_per_launch) > 1e-6 * alg_bytes_per_launch:
-            return None
-        return d.get("bytes_per_launch")
-    except Exception:
-        return None
+        d["_path"] = os.path.relpath(p, ROOT)
+        return d
+    except (OSError, ValueError):
+        return {}
+
+
+def spawn_ranks(args, argv):
+    """--gpus N > 1 and no WORLD_SIZE: start N fresh rank processes.  The parent has imported neither
+    torch nor the HIP library at this point, so nothing here has touched the GPU."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
+    line = None
+    for ln in p.stdout.decode("utf-8", "replace").splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+    if p.returncode != 0 or line is None:
+        sys.stderr.write(p.stdout.decode("utf-8", "replace"))
+        raise SystemExit(p.returncode or 1)
+    sys.stdout.write(line + "\n")
+    sys.stdout.flush()
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4096)
-    ap.add_argument("--warmup", type=int, default=1024)
-    ap.add_argument("--fuse", type=int, default=1024, help="turns fused per launch (1 = one launch per turn)")
+    ap.add_argument("--steps", type=int, default=16, help="timed steps; one step = one fused launch of --fuse turns of every room")
+    ap.add_argument("--warmup", type=int, default=2, help="untimed steps (launches) before the timed region, after the fixed pre-roll")
+    ap.add_argument("--fuse", type=int, default=1024, help="turns fused per launch = turns per bench step")
     ap.add_argument("--rooms", type=int, default=None, help="rooms per GPU (overrides the workload's count; c2 only)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2", help="BASELINE.json config (default c2 = configs[1])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -124,6 +159,16 @@ def main():
     ap.add_argument("--no-other-shapes", action="store_true", help="skip the informational larger shapes")
     ap.add_argument("--no-from-init", action="store_true", help="skip the S=64-from-initial-state variant")
     args = ap.parse_args()
+    if args.gpus < 1 or args.steps < 1 or args.warmup < 0 or args.fuse < 1:
+        raise SystemExit("bench.py: --gpus/--steps/--fuse must be >= 1, --warmup >= 0")
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return spawn_ranks(args, sys.argv[1:])
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
 
     # stdout carries exactly ONE line (the JSON): everything else any library prints there — RCCL
     # writes a version banner to stdout at communicator creation — is diverted to stderr
@@ -136,15 +181,15 @@ def main():
     from game_engine_amd import GameTable, RoomBatch
     from game_engine_amd.dist import allgather_summary, shard_first_room
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the stepper has no CPU path")
     # one process per GPU; GE_DIST_BACKEND=gloo is only for rehearsing the multi-process flow on a
     # box with fewer GPUs than ranks (ranks then share devices and collectives run on CPU tensors)
     backend = os.environ.get("GE_DIST_BACKEND", "nccl")
-    device_index = local_rank % torch.cuda.device_count()
+    n_dev = torch.cuda.device_count()
+    if backend == "nccl" and world > n_dev:
+        raise SystemExit(f"bench.py: {world} ranks but {n_dev} GPUs (one process per GPU; GE_DIST_BACKEND=gloo rehearses with shared devices)")
+    device_index = local_rank % n_dev
     torch.cuda.set_device(device_index)
     coll_device = torch.device("cuda", device_index) if backend == "nccl" else torch.device("cpu")
     use_dist = world > 1 or bool(os.environ.get("GE_FORCE_DIST"))      # GE_FORCE_DIST: rehearse RCCL with one rank
@@ -178,13 +223,20 @@ def main():
     bytes_per_room = sum(batch.bytes_per_room(k) * r for k, (_, _, r) in enumerate(spec)) / rooms
     stream = torch.cuda.current_stream().cuda_stream
 
-    batch.step(args.warmup, stream)                   # untimed; also brings the batch to steady state
+    # untimed: fixed pre-roll to steady state, then W warm-up steps of the timed shape
+    preroll = 0
+    while preroll < PREROLL_TURNS:
+        batch.step(args.fuse, stream)
+        preroll += args.fuse
+    for _ in range(args.warmup):
+        batch.step(args.fuse, stream)
     batch.sync()
     batch.set_timing(True)
     batch.kernel_time(reset=True)
     barrier()
     t0 = time.perf_counter()
-    batch.step(args.steps, stream)
+    for _ in range(args.steps):                       # K steps = K fused launches
+        batch.step(args.fuse, stream)
     barrier()
     elapsed = time.perf_counter() - t0
     kernel_ms, launches = batch.kernel_time(reset=True)
@@ -201,11 +253,11 @@ def main():
     barrier()
     summary_ms = (time.perf_counter() - ts) * 1e3
 
-    # un-fused reference point: one launch per turn, same workload, short
+    # the HBM-streaming point: one launch per turn, same workload, short (N=1 only: keeps multi-GPU runs symmetric)
     unfused = None
-    if rank == 0 and world == 1 and not args.no_unfused:      # N=1 only: keeps multi-GPU runs symmetric
+    if rank == 0 and world == 1 and not args.no_unfused:
         b1 = RoomBatch(segments, seed=SEED, device=device_index, max_fuse=1, restart=True)
-        b1.step(256, stream); b1.sync()
+        b1.step(PREROLL_TURNS, stream); b1.sync()
         # wall clock first, without per-launch events (they serialise the launches; here the 256
         # launches of a step() call are replayed from a hipGraph), then the kernel time per launch
         t1 = time.perf_counter()
@@ -216,9 +268,14 @@ def main():
         b1.set_timing(True); b1.kernel_time(reset=True)
         b1.step(256, stream); b1.sync()
         k1, l1 = b1.kernel_time(reset=True)
-        unfused = {"value": rooms * 256 / w1, "ms_per_step": w1 * 1e3 / 256, "kernel_us_per_launch": k1 * 1e3 / max(l1, 1),
-                   "achieved_GBs_wall": 2 * bytes_per_room * rooms * 256 / w1 / 1e9,
-                   "note": "one launch per turn (max_fuse=1): every turn streams the state through HBM"}
+        gbs_wall = 2 * bytes_per_room * rooms * 256 / w1 / 1e9
+        gbs_kernel = 2 * bytes_per_room * rooms / (k1 * 1e-3 / max(l1, 1)) / 1e9
+        unfused = {"value": rooms * 256 / w1, "unit": "room-phase steps/s (wall)", "ms_per_turn": w1 * 1e3 / 256,
+                   "kernel_us_per_launch": k1 * 1e3 / max(l1, 1),
+                   "achieved_GBs_wall": gbs_wall, "frac_wall": gbs_wall / HBM_PEAK_GBS,
+                   "achieved_GBs_kernel": gbs_kernel, "frac_kernel": gbs_kernel / HBM_PEAK_GBS,
+                   "note": "max_fuse=1: one launch per turn, every turn reads and writes every record through HBM; "
+                           "wall = 256-launch hipGraph replays, kernel = HIP events around single launches"}
         b1.close()
 
     # BASELINE.md §3 variant: S = 64 turns from the initial state (no recycling), 3 warm-ups, median of 10
@@ -247,44 +304,56 @@ def main():
     other = None
     if rank == 0 and world == 1 and not args.no_other_shapes and args.workload == "c2":
         other = {}
-        tt_dsl = json.load(open(os.path.join(ROOT, "tests", "golden", "dsl", "two-truths-and-a-lie.json"), encoding="utf-8"))
-        for label, tb, n, r in (("1048576 Werewolf x8", table, 8, 1 << 20),
-                                ("2097152 Werewolf x12 (one GPU's share of C4)", table, 12, 1 << 21),
-                                ("1048576 Two-Truths x4 (C3)", GameTable(tt_dsl), 4, 1 << 20)):
+        tt_dsl = load_dsl("two-truths-and-a-lie")
+        for label, key, tb, n, r in (("1048576 Werewolf x8", "ww8_1048576", table, 8, 1 << 20),
+                                     ("2097152 Werewolf x12 (one GPU's share of C4)", "c4", table, 12, 1 << 21),
+                                     ("1048576 Two-Truths x4 (C3)", "c3", GameTable(tt_dsl), 4, 1 << 20)):
             bb = RoomBatch([(tb, n, r)], seed=SEED, device=device_index, max_fuse=args.fuse, restart=True)
-            bb.step(128, stream); bb.sync()
+            bb.step(256, stream); bb.sync()
             bb.set_timing(True); bb.kernel_time(reset=True)
             bb.step(512, stream); bb.sync()
             ms, nl = bb.kernel_time(reset=True)
             bpr = bb.bytes_per_room(0)
             other[label] = {"value": r * 512 / (ms * 1e-3), "unit": "room-phase steps/s (device time)",
-                            "achieved_GBs": 2 * bpr * r * 512 / (ms * 1e-3) / 1e9,
-                            "frac": 2 * bpr * r * 512 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "bytes_per_room_record": bpr}
+                            "us_per_turn": ms * 1e3 / 512,
+                            "algorithmic_GBs": 2 * bpr * r * 512 / (ms * 1e-3) / 1e9,
+                            "algorithmic_frac": 2 * bpr * r * 512 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "bytes_per_room_record": bpr,
+                            "issue": issue_block(committed_profile(key), r, 512, ms * 1e-3)}
             bb.close()
 
     if rank == 0:
-        total_steps = rooms * world * args.steps
-        per_launch_units = rooms * (args.steps / max(launches, 1))
+        turns_timed = args.fuse * args.steps
+        total_steps = rooms * world * turns_timed
+        per_launch_units = rooms * (turns_timed / max(launches, 1))
         alg_bytes = 2 * bytes_per_room * per_launch_units
         avg_launch_s = kernel_ms * 1e-3 / max(launches, 1)
         achieved = alg_bytes / avg_launch_s / 1e9
+        prof = committed_profile(args.workload if not args.rooms else f"ww8_{args.rooms}")
+        state_rw = 2.0 * bytes_per_room * rooms
+        traffic = prof.get("hbm_bytes_per_launch") if abs(prof.get("state_bytes_read_plus_written", -1) - state_rw) < 1 else None
         out = {
             "metric": "room-phase steps/sec", "value": total_steps / elapsed, "unit": "room-phase steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {"workload": args.workload + ": " + " + ".join(f"{r} {g} rooms x {n} players" for g, n, r in spec) +
-                                   " per GPU, steady state (finished rooms recycled), fixed policy, seed 0xC0FFEE",
+                                   " per GPU, steady state (finished rooms recycled, untimed pre-roll), fixed policy, seed 0xC0FFEE",
+                       "step": f"one fused launch = {args.fuse} turns of every room (record loaded once, stored once)",
                        "rooms_per_gpu": rooms, "n_players": [n for _, n, _ in spec], "turns_fused_per_launch": args.fuse,
+                       "room_phase_steps_per_bench_step": rooms * world * args.fuse, "preroll_turns": preroll,
                        "bytes_per_room_record": bytes_per_room, "sharding": f"rooms x{world}, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_copy_peak": achieved / 6290.0,
-                         "traffic": pmc_traffic(2.0 * bytes_per_room * rooms),
+                         "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_copy_peak": achieved / HBM_COPY_GBS,
+                         "traffic": traffic,
+                         "traffic_source": (prof.get("_path", None) and f"{prof['_path']} (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; not measured in this run)"),
                          "kernel": "ge_step_kernel", "avg_launch_us": avg_launch_s * 1e6, "launches": launches,
                          "algorithmic_bytes_per_launch": alg_bytes,
-                         "note": "algorithmic bytes = 2 x record x rooms x turns in the launch; with fused turns the "
-                                 "state stays in registers, so real HBM traffic is ~1/fuse of this (see traffic)"},
-            "unfused": unfused,
+                         "note": "SURVEY 8(d) yardstick: algorithmic bytes = 2 x record x rooms x turns in the launch. With fused "
+                                 "turns the state stays in registers: real HBM traffic is `traffic` (~1/fuse of the algorithmic "
+                                 "figure) and the kernel is bound by instruction issue, see `issue`; the launch that really streams "
+                                 "the state every turn is `hbm_streaming`"},
+            "issue": issue_block(prof, rooms, turns_timed, kernel_ms * 1e-3),
+            "hbm_streaming": unfused,
             "from_init_64": from_init,
             "other_shapes": other,
             "summary": {k: summary[k] for k in ("rooms", "finished", "village_wins", "wolf_wins", "games_recycled", "checksum")},
@@ -296,6 +365,35 @@ def main():
     batch.close()
     if use_dist:
         dist.destroy_process_group()
+
+
+def issue_block(prof, rooms, turns, kernel_s):
+    """The bound of the fused kernel: wave-instructions issued per second against the SIMD issue
+    ceiling.  A wave64 VALU instruction occupies its SIMD-32 for 2 cycles (MI355X_MICROARCH.md:54, :473)
+    -> 1 024 SIMDs x 2.4 GHz / 2 = 1.23e12 wave-instr/s with >= 2 wavefronts per SIMD; a wavefront ALONE
+    on its SIMD issues one instruction per 4 cycles (same table, row 'vector-instruction ISSUE cost')
+    -> 6.1e11.  Instructions per wave-turn come from the committed SQ counter pass (PMC cannot be
+    collected inside the timed run)."""
+    waves = (rooms + 63) // 64
+    waves_per_simd = waves / N_SIMD
+    cyc = 4.0 if waves_per_simd < 2.0 else 2.0
+    ceiling = N_SIMD * CLOCK_HZ / cyc
+    wave_turns_per_s = waves * turns / kernel_s
+    out = {"bound": "valu-issue", "waves_per_simd": waves_per_simd, "cycles_per_wave_instruction": cyc,
+           "ceiling_wave_instr_per_s": ceiling, "wave_turns_per_s": wave_turns_per_s,
+           # SIMD cycles (at 2.4 GHz) one wave-turn has to itself: busy SIMDs x clock / wave-turns per second
+           "simd_cycles_per_wave_turn": min(waves, N_SIMD) * CLOCK_HZ / wave_turns_per_s}
+    ipt = prof.get("instructions_per_wave_turn")
+    if ipt:
+        total = float(ipt.get("valu", 0)) + float(ipt.get("salu", 0)) + float(ipt.get("lds", 0))
+        out.update({"instructions_per_wave_turn": ipt, "wave_instr_per_s": total * wave_turns_per_s,
+                    "frac": total * wave_turns_per_s / ceiling,
+                    "valu_frac": float(ipt.get("valu", 0)) * wave_turns_per_s / ceiling,
+                    "wait_any_frac_of_wave_cycles": prof.get("wait_any_frac"),
+                    "source": f"{prof.get('_path')} (committed rocprofv3 --pmc SQ pass of this shape)"})
+    else:
+        out.update({"instructions_per_wave_turn": None, "frac": None, "source": None})
+    return out
 
 
 if __name__ == "__main__":

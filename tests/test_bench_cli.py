@@ -1,0 +1,89 @@
+"""bench.py's command line (the driver's contract): `--gpus N` must start N ranks itself when it is
+not already one rank of a torch.distributed.run job, before anything touches the GPU, and a
+`--gpus` / WORLD_SIZE mismatch must fail instead of silently running one rank."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_cli_under_test", os.path.join(ROOT, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_gpus_n_spawns_n_ranks_before_touching_the_gpu(monkeypatch, capsys):
+    bench = _bench_module()
+    seen = {}
+
+    class Done:
+        returncode = 0
+        stdout = b'NCCL version banner\n{"metric": "room-phase steps/sec", "n_gpus": 4}\n'
+
+    def fake_run(cmd, env=None, stdout=None):
+        seen["cmd"], seen["env"] = cmd, env
+        seen["torch_loaded"] = "torch" in sys.modules and getattr(sys.modules["torch"], "cuda", None) is not None and \
+            sys.modules["torch"].cuda.is_initialized()
+        return Done()
+
+    monkeypatch.setattr(bench.subprocess, "run", fake_run)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "20", "--warmup", "5"])
+    bench.main()
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"]
+    assert "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "20", "--warmup", "5"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert not seen["torch_loaded"]                        # the parent never initialised the GPU
+    out = capsys.readouterr().out.strip().splitlines()
+    assert len(out) == 1 and json.loads(out[0])["n_gpus"] == 4   # exactly rank 0's line is relayed
+
+
+def test_world_size_mismatch_fails():
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode != 0 and b"WORLD_SIZE=2" in p.stderr and p.stdout == b""
+
+
+def test_spawned_rank_failure_is_reported(monkeypatch):
+    bench = _bench_module()
+
+    class Failed:
+        returncode = 3
+        stdout = b"rank 1 died\n"
+
+    monkeypatch.setattr(bench.subprocess, "run", lambda *a, **k: Failed())
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2"])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 3
+
+
+@pytest.mark.gpu
+def test_gpus_2_rehearsal_on_one_card_reports_two_ranks():
+    """`python bench.py --gpus 2` end to end on the one-GPU test box: both ranks share GPU 0 and
+    the collectives run over gloo (GE_DIST_BACKEND=gloo); the line must say n_gpus 2 and count
+    both shards' rooms."""
+    env = dict(os.environ, GE_DIST_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = p.stdout.decode().strip().splitlines()
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak"
+    assert d["summary"]["rooms"] == 2 * 65536
+    assert d["config"]["room_phase_steps_per_bench_step"] == 2 * 65536 * 1024
+    assert d["value"] > 1e9 and "cpu_baseline" not in d
