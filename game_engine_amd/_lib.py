@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libge_step.so")
 
 GE_MAX_PHASES, GE_MAX_SEGMENTS, GE_NAME_LEN = 32, 4, 64
-GE_ABI_VERSION = 1
+GE_ABI_VERSION = 2
 
 
 class PhaseRow(C.Structure):
@@ -46,7 +46,7 @@ class Summary(C.Structure):
 SUMMARY_WORDS = C.sizeof(Summary) // 8
 
 # every symbol include/ge_step.h declares (tests/test_abi.py checks the library exports them all)
-SYMBOLS = ["ge_table_compile_json", "ge_batch_create", "ge_batch_step", "ge_batch_reset", "ge_batch_sync", "ge_batch_turn",
+SYMBOLS = ["ge_table_compile_json", "ge_batch_create", "ge_batch_step", "ge_batch_reset", "ge_batch_set_turn", "ge_batch_inject_actions", "ge_batch_sync", "ge_batch_turn",
            "ge_batch_n_rooms", "ge_batch_read_rooms", "ge_batch_write_rooms", "ge_batch_read_events", "ge_batch_inject_action", "ge_batch_summary",
            "ge_batch_state", "ge_batch_set_timing", "ge_batch_kernel_time", "ge_batch_destroy",
            "ge_strerror", "ge_last_hip_error", "ge_abi_version", "ge_device_count"]
@@ -81,6 +81,8 @@ def load() -> C.CDLL:
     lib.ge_batch_write_rooms.argtypes = [vp, u64, u64, vp]
     lib.ge_batch_read_events.argtypes = [vp, u64, u64, C.POINTER(u32), vp, C.c_size_t]
     lib.ge_batch_inject_action.argtypes = [vp, u64, u32, u32]
+    lib.ge_batch_inject_actions.argtypes = [vp, u64, vp, vp, vp, vp]
+    lib.ge_batch_set_turn.argtypes = [vp, u64]
     lib.ge_batch_summary.argtypes = [vp, C.POINTER(Summary)]
     lib.ge_batch_state.argtypes = [vp, u32, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(u32)]
     lib.ge_batch_set_timing.argtypes = [vp, C.c_int]

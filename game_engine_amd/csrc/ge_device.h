@@ -86,6 +86,16 @@ inline void fill_nth8_host(uint8_t *nth8) {
     }
 }
 
+// ord8[mask]: nibble r = position of the r-th set bit of the 8-bit mask (0 past the last one)
+inline void fill_ord8_host(uint32_t *ord8) {
+    for (uint32_t m = 0; m < 256u; m++) {
+        uint32_t v = 0, r = 0;
+        for (uint32_t i = 0; i < 8u; i++)
+            if ((m >> i) & 1u) v |= i << (4u * r++);
+        ord8[m] = v;
+    }
+}
+
 // x has at most bit 0 of each nibble set: widen every such bit to a full 0xF nibble.  ORs of shifts,
 // not (x << 4) - x: the compiler turns that into v_mul_lo_u32 by 15, a quarter-rate instruction
 // (the empty asm hides the intermediate from the optimiser, which would otherwise prove the bits disjoint

@@ -244,6 +244,7 @@ struct DevTable {
     DevRow rows[32];
     int32_t n_phases, rounds, n_players, pad;
     uint8_t nth8[2048];      // n-th-set-bit table (ge_device.h), copied to LDS by the large-batch build
+    uint32_t ord8[256];      // ord8[mask] = the positions of the set bits of an 8-bit mask, ascending, one nibble each
 };
 
 // plane geometry of a segment

@@ -8,6 +8,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
 #include <new>
 #include <vector>
 
@@ -36,6 +37,7 @@ struct SegDev {
     uint32_t kind, n_players, nw, rounds;
     uint32_t phase0_idx, block_begin, table_idx, words;
     uint32_t human_mask, pad0;
+    uint64_t local_first;      // index of the segment's room 0 inside the batch
     uint32_t init_words[12];   // the initial record (player_states_template, phase 0)
     uint32_t *trace;           // GE_FLAG_TRACE: [turn in launch][rooms_padded] x 4 words, else null
 };
@@ -378,6 +380,155 @@ __global__ void __launch_bounds__(256) ge_summary_kernel(const StepArgs a, const
     if (threadIdx.x >= 128 && threadIdx.x < 144 && h_score[threadIdx.x - 128]) atomicAdd(&out[21 + threadIdx.x - 128], (unsigned long long)h_score[threadIdx.x - 128]);
 }
 
+// ---- reset: every room record <- the DSL's initial record (player_states_template, phase 0)
+__global__ void __launch_bounds__(256) ge_fill_kernel(const SegDev *__restrict__ segs, uint32_t n_seg) {
+    for (uint32_t k = 0; k < n_seg; k++) {
+        const SegDev &sg = segs[k];
+        const int np = planes_of((int)sg.words);
+        for (uint64_t room = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; room < sg.rooms_padded; room += (uint64_t)gridDim.x * blockDim.x) {
+            for (int j = 0; j < np; j++) {
+                char *plane = reinterpret_cast<char *>(sg.base) + plane_offset(sg.rooms_padded, j);
+                if ((int)sg.words - 4 * j >= 4) {
+                    u32x4 v; v.x = sg.init_words[4 * j]; v.y = sg.init_words[4 * j + 1]; v.z = sg.init_words[4 * j + 2]; v.w = sg.init_words[4 * j + 3];
+                    ((__attribute__((address_space(1))) u32x4 *)(uintptr_t)plane)[room] = v;
+                } else {
+                    u32x2 v; v.x = sg.init_words[4 * j]; v.y = sg.init_words[4 * j + 1];
+                    ((__attribute__((address_space(1))) u32x2 *)(uintptr_t)plane)[room] = v;
+                }
+            }
+        }
+    }
+}
+
+// ---- host-driven players: a batch of logged actions (ge_batch_inject_actions), one thread per distinct room.
+// What the reference does with a human's message at the start of the next graph run
+// (agent/tools/utils.py:310-358 -> bt:285-344) + the Referee's record effect (POLICY.md §3).
+struct InjectArgs {
+    const uint64_t *rooms;     // sorted by room (stable): action k of the sorted order
+    const uint32_t *players, *choices;
+    const uint32_t *group;     // group g = sorted actions [group[g], group[g + 1])
+    int32_t *status;           // per sorted action
+    uint32_t n_groups, n_seg;
+};
+
+// base predicate `base` of player bit `bit` (POLICY.md §3 numbering)
+template <int NB> __device__ __forceinline__ bool ww_base(const WW<NB> &s, uint32_t base, uint32_t bit) {
+    const uint32_t n2 = ~s.rb2;
+    switch (base) {
+    case 0: return s.alive & bit; case 1: return s.can_vote & bit; case 2: return s.revealed & bit; case 3: return s.secret & bit;
+    case 4: return s.elig & bit; case 5: return s.sub & bit; case 6: return s.team_v & bit; case 7: return s.team_w & bit;
+    case 8: return s.rb0 & ~s.rb1 & n2 & bit; case 9: return ~s.rb0 & s.rb1 & n2 & bit;
+    case 10: return s.rb0 & s.rb1 & n2 & bit; default: return s.rb2 & ~s.rb1 & ~s.rb0 & bit;
+    }
+}
+template <int NB> __device__ __forceinline__ bool tt_base(const TT<NB> &s, uint32_t base, uint32_t bit) {
+    switch (base) {
+    case 0: return s.speaker & bit; case 1: return s.submitted & bit; case 2: return s.revealed & bit;
+    case 3: return s.can_vote & bit; default: return s.has_voted & bit;
+    }
+}
+// the row's j-th term as (base, negated): r1 encodes {word, shift} into the packed predicate words
+__device__ __forceinline__ void row_term(const DevRow &row, uint32_t j, uint32_t fpw, uint32_t &base, bool &neg) {
+    const uint32_t e = (row.r1 >> (8u * j)) & 255u;
+    base = (e >> 5) * fpw + (e & 31u) / (32u / fpw);
+    neg = (row.r0 >> (16u + j)) & 1u;
+}
+
+template <int NB> __device__ int inject_ww(WW<NB> &s, const DevRow &row, uint32_t n, uint32_t player, uint32_t choice) {
+    using nib_t = typename WW<NB>::nib_t;
+    if (player < 1 || player > n) return GE_ERR_ARG;
+    if ((row.r0 & 3u) != COMP_ACTION) return GE_ERR_ARG;
+    const uint32_t bit = 1u << (player - 1u);
+    if (!(s.alive & bit)) return GE_ERR_ARG;
+    const uint32_t nt = (row.r0 >> 8) & 7u;
+    for (uint32_t j = 0; j < nt; j++) {
+        uint32_t base; bool neg;
+        row_term(row, j, NB <= 8 ? 4u : 2u, base, neg);
+        if (ww_base<NB>(s, base, bit) == neg) return GE_ERR_ARG;
+    }
+    if (s.acted & bit) return GE_ERR_ARG;
+    if (choice < 1 || choice > n || !(s.alive & (1u << (choice - 1u)))) return GE_ERR_ARG;   // targets must be alive
+    const uint32_t sh = 4u * (player - 1u);
+    const nib_t clr = ~(nib_t(15) << sh), put = nib_t(choice) << sh;
+    s.acted |= bit;
+    s.choice = (s.choice & clr) | put;
+    const uint32_t act = (row.r0 >> 2) & 7u;
+    if (act == ACT_DETECTIVE) {
+        const uint32_t tb = 1u << (choice - 1u);
+        s.det_v &= ~tb; s.det_w &= ~tb;
+        if (s.team_w & tb) s.det_w |= tb; else s.det_v |= tb;
+    }
+    if (act >= ACT_WOLF_TARGET && act <= ACT_DETECTIVE) { s.sub |= bit; s.sel = (s.sel & clr) | put; }
+    return GE_OK;
+}
+
+template <int NB> __device__ int inject_tt(TT<NB> &s, const DevRow &row, uint32_t n, uint32_t player, uint32_t choice) {
+    if (player < 1 || player > n) return GE_ERR_ARG;
+    if ((row.r0 & 3u) != COMP_ACTION) return GE_ERR_ARG;
+    const uint32_t bit = 1u << (player - 1u);
+    const uint32_t nt = (row.r0 >> 8) & 7u;
+    for (uint32_t j = 0; j < nt; j++) {
+        uint32_t base; bool neg;
+        row_term(row, j, 2u, base, neg);
+        if (tt_base<NB>(s, base, bit) == neg) return GE_ERR_ARG;
+    }
+    if (s.acted & bit) return GE_ERR_ARG;
+    const uint32_t act = (row.r0 >> 2) & 7u;
+    if (act == ACT_TT_STATEMENTS ? choice != 1u : (choice < 1u || choice > 3u)) return GE_ERR_ARG;
+    const uint32_t sh = 2u * (player - 1u), clr = ~(3u << sh), put = choice << sh;
+    s.acted |= bit;
+    s.choice = (s.choice & clr) | put;
+    if (act == ACT_TT_STATEMENTS) s.submitted |= bit;
+    else if (act == ACT_TT_LIE) s.lie = (s.lie & clr) | put;
+    else if (act == ACT_TT_VOTE) { s.vote = (s.vote & clr) | put; s.has_voted |= bit; }
+    return GE_OK;
+}
+
+template <int NB> __device__ void inject_group_ww(const SegDev &sg, const DevTable *tables, uint64_t room, const InjectArgs &a, uint32_t lo, uint32_t hi) {
+    using L = WWLayout<NB>;
+    uint32_t w[L::WORDS];
+    load_words<L::WORDS>(sg.base, sg.rooms_padded, room, w);
+    WW<NB> s;
+    L::unpack(w, s);
+    const DevRow row = tables[sg.table_idx].rows[s.phase];
+    for (uint32_t k = lo; k < hi; k++) a.status[k] = inject_ww<NB>(s, row, sg.n_players, a.players[k], a.choices[k]);
+    L::pack(s, w);
+    store_words<L::WORDS>(sg.base, sg.rooms_padded, room, w);
+}
+template <int NB> __device__ void inject_group_tt(const SegDev &sg, const DevTable *tables, uint64_t room, const InjectArgs &a, uint32_t lo, uint32_t hi) {
+    using L = TTLayout<NB>;
+    uint32_t w[L::WORDS];
+    load_words<L::WORDS>(sg.base, sg.rooms_padded, room, w);
+    TT<NB> s;
+    L::unpack(w, s);
+    const DevRow row = tables[sg.table_idx].rows[s.phase];
+    for (uint32_t k = lo; k < hi; k++) a.status[k] = inject_tt<NB>(s, row, sg.n_players, a.players[k], a.choices[k]);
+    L::pack(s, w);
+    store_words<L::WORDS>(sg.base, sg.rooms_padded, room, w);
+}
+
+__global__ void __launch_bounds__(64) ge_inject_kernel(const InjectArgs a, const SegDev *__restrict__ segs, const DevTable *__restrict__ tables) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= a.n_groups) return;
+    const uint32_t lo = a.group[g], hi = a.group[g + 1];
+    const uint64_t room = a.rooms[lo];
+    const SegDev *sg = nullptr;
+    for (uint32_t k = 0; k < a.n_seg; k++)
+        if (room >= segs[k].local_first && room < segs[k].local_first + segs[k].rooms) sg = segs + k;
+    if (!sg) {
+        for (uint32_t k = lo; k < hi; k++) a.status[k] = GE_ERR_RANGE;
+        return;
+    }
+    const uint64_t r = room - sg->local_first;
+    switch (sg->kind) {
+    case K_WW8: inject_group_ww<8>(*sg, tables, r, a, lo, hi); break;
+    case K_WW12: inject_group_ww<12>(*sg, tables, r, a, lo, hi); break;
+    case K_TT4: inject_group_tt<4>(*sg, tables, r, a, lo, hi); break;
+    case K_TT8: inject_group_tt<8>(*sg, tables, r, a, lo, hi); break;
+    default: inject_group_tt<12>(*sg, tables, r, a, lo, hi); break;
+    }
+}
+
 // last node of a captured sequence of step launches: the device-side turn base moves on, so the same
 // graph can be replayed for the next n turns
 __global__ void ge_turn_bump(uint32_t *turn, uint32_t n) { *turn += n; }
@@ -387,7 +538,7 @@ thread_local int g_last_hip = 0;
 #define HIP_TRY(expr)                                   \
     do {                                                \
         hipError_t e__ = (expr);                        \
-        if (e__ != hipSuccess) { g_last_hip = (int)e__; return GE_ERR_HIP; } \
+        if (e__ != hipSuccess) { g_last_hip = (int)e__; return (int)GE_ERR_HIP; } \
     } while (0)
 
 struct Segment {
@@ -572,6 +723,10 @@ struct ge_batch {
     SegDev *segs_dev = nullptr;
     unsigned long long *sum_dev = nullptr;
     hipStream_t last_stream = nullptr;
+    bool pending = false;             // work was queued on last_stream since the last synchronisation
+    hipEvent_t order_ev = nullptr;    // orders a step on a new stream behind the previous stream's work
+    void *inj_buf = nullptr;          // device scratch of ge_batch_inject_actions
+    size_t inj_cap = 0;
     // hipGraph replay of launch-bound step sequences (many short launches per ge_batch_step call)
     uint32_t *turn_dev = nullptr;     // turn base the captured launches read
     uint64_t turn_dev_value = ~0ull;  // what *turn_dev holds (host mirror)
@@ -605,6 +760,37 @@ static int fill_args(const ge_batch *b, StepArgs &a, uint32_t turn0, uint32_t n_
     return GE_OK;
 }
 
+// every entry point leaves the caller's current device as it found it
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) { hipError_t e = hipSetDevice(dev); if (e != hipSuccess) { g_last_hip = (int)e; ok = false; } } else prev = -1;
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+#define GE_ON_DEVICE(b) DeviceGuard dg__((b)->device); if (!dg__.ok) return (int)GE_ERR_HIP
+
+// nothing may throw across the C ABI (std::vector / new inside the entry points)
+template <class F> static int guarded(F &&f) {
+    try { return f(); }
+    catch (const std::bad_alloc &) { return GE_ERR_NOMEM; }
+    catch (...) { return GE_ERR_ARG; }
+}
+
+// a step on a stream other than the previous one is ordered behind it
+static int order_after_previous(ge_batch *b, hipStream_t st) {
+    if (b->pending && st != b->last_stream) {
+        if (!b->order_ev) HIP_TRY(hipEventCreateWithFlags(&b->order_ev, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(b->order_ev, b->last_stream));
+        HIP_TRY(hipStreamWaitEvent(st, b->order_ev, 0));
+    }
+    b->last_stream = st;
+    b->pending = true;
+    return GE_OK;
+}
+
 extern "C" {
 
 int ge_abi_version(void) { return GE_ABI_VERSION; }
@@ -630,7 +816,9 @@ const char *ge_strerror(int status) {
     }
 }
 
-int ge_batch_create(const ge_batch_desc *desc, ge_batch **out) {
+}  // extern "C"
+
+static int create_impl(const ge_batch_desc *desc, ge_batch **out) {
     if (!desc || !out || desc->n_segments == 0 || desc->n_segments > GE_MAX_SEGMENTS) return GE_ERR_ARG;
     *out = nullptr;
     if (ge_device_count() <= 0) return GE_ERR_NO_DEVICE;
@@ -672,6 +860,7 @@ int ge_batch_create(const ge_batch_desc *desc, ge_batch **out) {
         d.rooms = sd.n_rooms;
         d.rooms_padded = (sd.n_rooms + 255u) & ~uint64_t(255);
         d.first_global = global;
+        d.local_first = local;
         d.n_players = n; d.nw = n / 4 > 1 ? n / 4 : 1; d.rounds = (uint32_t)s.table.rounds;
         d.human_mask = sd.human_mask & ((1u << n) - 1u);
         d.phase0_idx = 255;
@@ -688,35 +877,52 @@ int ge_batch_create(const ge_batch_desc *desc, ge_batch **out) {
     }
     b->n_rooms = local; b->n_blocks = blocks; b->state_bytes = bytes;
     int st = GE_OK;
-    do {
-        if (hipSetDevice(b->device) != hipSuccess) { st = GE_ERR_HIP; break; }
-        hipError_t e = hipMalloc(&b->state, bytes);
-        if (e != hipSuccess) { g_last_hip = (int)e; st = e == hipErrorOutOfMemory ? GE_ERR_NOMEM : GE_ERR_HIP; break; }
-        if (hipMalloc(reinterpret_cast<void **>(&b->tables), sizeof(DevTable) * b->segs.size()) != hipSuccess ||
-            hipMalloc(reinterpret_cast<void **>(&b->segs_dev), sizeof(SegDev) * GE_MAX_SEGMENTS) != hipSuccess ||
-            hipMalloc(reinterpret_cast<void **>(&b->sum_dev), sizeof(unsigned long long) * 64) != hipSuccess) { st = GE_ERR_HIP; break; }
-        if (b->flags & GE_FLAG_TRACE) {
-            size_t tb = 0;
-            for (Segment &s : b->segs) tb += (size_t)b->max_fuse * s.dev.rooms_padded * 16u;
-            if (hipMalloc(&b->trace, tb) != hipSuccess) { st = GE_ERR_NOMEM; break; }
-            size_t off = 0;
-            for (Segment &s : b->segs) {
-                s.dev.trace = reinterpret_cast<uint32_t *>(static_cast<char *>(b->trace) + off);
-                off += (size_t)b->max_fuse * s.dev.rooms_padded * 16u;
+    {
+        DeviceGuard dg(b->device);
+        do {
+            if (!dg.ok) { st = GE_ERR_HIP; break; }
+            hipError_t e = hipMalloc(&b->state, bytes);
+            if (e != hipSuccess) { g_last_hip = (int)e; st = e == hipErrorOutOfMemory ? GE_ERR_NOMEM : GE_ERR_HIP; break; }
+            if (hipMalloc(reinterpret_cast<void **>(&b->tables), sizeof(DevTable) * b->segs.size()) != hipSuccess ||
+                hipMalloc(reinterpret_cast<void **>(&b->segs_dev), sizeof(SegDev) * GE_MAX_SEGMENTS) != hipSuccess ||
+                hipMalloc(reinterpret_cast<void **>(&b->sum_dev), sizeof(unsigned long long) * 64) != hipSuccess) { st = GE_ERR_HIP; break; }
+            if (b->flags & GE_FLAG_TRACE) {
+                size_t tb = 0;
+                for (Segment &s : b->segs) tb += (size_t)b->max_fuse * s.dev.rooms_padded * 16u;
+                if (hipMalloc(&b->trace, tb) != hipSuccess) { st = GE_ERR_NOMEM; break; }
+                size_t off = 0;
+                for (Segment &s : b->segs) {
+                    s.dev.trace = reinterpret_cast<uint32_t *>(static_cast<char *>(b->trace) + off);
+                    off += (size_t)b->max_fuse * s.dev.rooms_padded * 16u;
+                }
             }
-        }
-        std::vector<DevTable> host_tables(b->segs.size());
-        for (size_t k = 0; k < b->segs.size(); k++) {
-            Segment &s = b->segs[k];
-            s.dev.base = reinterpret_cast<uint32_t *>(static_cast<char *>(b->state) + reinterpret_cast<size_t>(s.dev.base));
-            DevTable &dt = host_tables[k];
-            memset(&dt, 0, sizeof dt);
-            for (int r = 0; r < s.table.n_phases; r++) dt.rows[r] = to_dev_row(s.table, s.table.rows[r], s.dev.kind);
-            dt.n_phases = s.table.n_phases; dt.rounds = s.table.rounds; dt.n_players = (int32_t)s.dev.n_players;
-            fill_nth8_host(dt.nth8);
-        }
-        if (hipMemcpy(b->tables, host_tables.data(), sizeof(DevTable) * host_tables.size(), hipMemcpyHostToDevice) != hipSuccess) { st = GE_ERR_HIP; break; }
-    } while (0);
+            std::vector<DevTable> host_tables(b->segs.size());
+            for (size_t k = 0; k < b->segs.size(); k++) {
+                Segment &s = b->segs[k];
+                s.dev.base = reinterpret_cast<uint32_t *>(static_cast<char *>(b->state) + reinterpret_cast<size_t>(s.dev.base));
+                DevTable &dt = host_tables[k];
+                memset(&dt, 0, sizeof dt);
+                for (int r = 0; r < s.table.n_phases; r++) dt.rows[r] = to_dev_row(s.table, s.table.rows[r], s.dev.kind);
+                dt.n_phases = s.table.n_phases; dt.rounds = s.table.rounds; dt.n_players = (int32_t)s.dev.n_players;
+                fill_nth8_host(dt.nth8);
+                fill_ord8_host(dt.ord8);
+                // the initial record: player_states_template for every player, phase id 0 (utils.py:642-647)
+                ge_room_view v;
+                memset(&v, 0, sizeof v);
+                v.phase_id = 0; v.prev_phase_id = 0; v.end_turn = -1; v.n_players = (uint8_t)s.dev.n_players;
+                v.pack = (uint8_t)s.table.pack;
+                for (uint32_t i = 0; i < s.dev.n_players; i++) memcpy(v.players[i], s.table.init_fields, 12);
+                uint32_t w[12] = {0};
+                view_to_words(s.dev.kind, v, s.table, w);
+                memcpy(s.dev.init_words, w, sizeof w);
+            }
+            if (hipMemcpy(b->tables, host_tables.data(), sizeof(DevTable) * host_tables.size(), hipMemcpyHostToDevice) != hipSuccess) { st = GE_ERR_HIP; break; }
+            SegDev host[GE_MAX_SEGMENTS];
+            memset(host, 0, sizeof host);
+            for (size_t k = 0; k < b->segs.size(); k++) host[k] = b->segs[k].dev;
+            if (hipMemcpy(b->segs_dev, host, sizeof host, hipMemcpyHostToDevice) != hipSuccess) { st = GE_ERR_HIP; break; }
+        } while (0);
+    }
     if (st != GE_OK) { ge_batch_destroy(b); return st; }
     st = ge_batch_reset(b);
     if (st != GE_OK) { ge_batch_destroy(b); return st; }
@@ -724,45 +930,24 @@ int ge_batch_create(const ge_batch_desc *desc, ge_batch **out) {
     return GE_OK;
 }
 
-int ge_batch_reset(ge_batch *b) {
-    if (!b) return GE_ERR_ARG;
-    int st = ge_batch_sync(b);
-    if (st != GE_OK) return st;
-    b->turn = 0;
-    // initial state: player_states_template for every player, phase id 0 (utils.py:642-647)
-    for (size_t k = 0; k < b->segs.size() && st == GE_OK; k++) {
-        Segment &s = b->segs[k];
-        ge_room_view v;
-        memset(&v, 0, sizeof v);
-        v.phase_id = 0; v.prev_phase_id = 0; v.end_turn = -1; v.n_players = (uint8_t)s.dev.n_players;
-        v.pack = (uint8_t)s.table.pack;
-        for (uint32_t i = 0; i < s.dev.n_players; i++) memcpy(v.players[i], s.table.init_fields, 12);
-        uint32_t w[12] = {0};
-        view_to_words(s.dev.kind, v, s.table, w);
-        memcpy(s.dev.init_words, w, sizeof w);
-        const int np = planes_of((int)s.dev.words);
-        for (int j = 0; j < np && st == GE_OK; j++) {
-            const int pw = plane_words((int)s.dev.words, j);
-            std::vector<uint32_t> plane((size_t)pw * s.dev.rooms_padded);
-            for (uint64_t r = 0; r < s.dev.rooms_padded; r++)
-                for (int x = 0; x < pw; x++) plane[r * pw + x] = w[4 * j + x];
-            char *dst = reinterpret_cast<char *>(s.dev.base) + plane_offset(s.dev.rooms_padded, j);
-            if (hipMemcpy(dst, plane.data(), plane.size() * 4, hipMemcpyHostToDevice) != hipSuccess) st = GE_ERR_HIP;
-        }
-    }
-    if (st == GE_OK) {
-        SegDev host[GE_MAX_SEGMENTS];
-        memset(host, 0, sizeof host);
-        for (size_t k = 0; k < b->segs.size(); k++) host[k] = b->segs[k].dev;
-        if (hipMemcpy(b->segs_dev, host, sizeof host, hipMemcpyHostToDevice) != hipSuccess) st = GE_ERR_HIP;
-    }
-    return st;
+static int sync_impl(ge_batch *b) {
+    HIP_TRY(hipStreamSynchronize(b->last_stream));
+    b->pending = false;
+    return GE_OK;
 }
 
-int ge_batch_set_timing(ge_batch *b, int on) {
-    if (!b) return GE_ERR_ARG;
-    b->timing = on != 0;
-    return GE_OK;
+static int reset_impl(ge_batch *b) {
+    GE_ON_DEVICE(b);
+    int st = sync_impl(b);
+    if (st != GE_OK) return st;
+    b->turn = 0;
+    // device-side fill: nothing the size of the state crosses PCIe
+    uint64_t most = 0;
+    for (const Segment &s : b->segs) most = s.dev.rooms_padded > most ? s.dev.rooms_padded : most;
+    const uint32_t blocks = (uint32_t)((most / 256u) < 2048u ? (most / 256u) : 2048u);
+    hipLaunchKernelGGL(ge_fill_kernel, dim3(blocks ? blocks : 1u), dim3(256), 0, b->last_stream, b->segs_dev, (uint32_t)b->segs.size());
+    HIP_TRY(hipGetLastError());
+    return sync_impl(b);
 }
 
 static hipError_t launch_step(const ge_batch *b, const StepArgs &a, hipStream_t st) {
@@ -814,34 +999,39 @@ static hipGraphExec_t graph_for(ge_batch *b, uint32_t n_turns) {
     if (ok && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) exec = nullptr;
     (void)hipGraphDestroy(graph);
     if (!ok || !exec) return nullptr;
-    if (b->graphs.size() >= 8) { (void)hipGraphExecDestroy(b->graphs.front().second); b->graphs.erase(b->graphs.begin()); }
+    if (b->graphs.size() >= 8) {
+        // the oldest executable may still be running on the last stream: wait before releasing it
+        (void)hipStreamSynchronize(b->last_stream);
+        (void)hipGraphExecDestroy(b->graphs.front().second);
+        b->graphs.erase(b->graphs.begin());
+    }
     b->graphs.emplace_back(n_turns, exec);
     return exec;
 }
 
-int ge_batch_step(ge_batch *b, uint32_t n_turns, void *hip_stream) {
-    if (!b) return GE_ERR_ARG;
+static int step_impl(ge_batch *b, uint32_t n_turns, void *hip_stream) {
     if (b->turn + n_turns > 0xFFFFFFFFull) return GE_ERR_RANGE;
     if ((b->flags & GE_FLAG_TRACE) && n_turns > b->max_fuse) return GE_ERR_RANGE;   // the trace holds one launch
+    GE_ON_DEVICE(b);
     b->last_step_turns = n_turns;
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
-    HIP_TRY(hipSetDevice(b->device));
-    b->last_stream = st;
     const uint32_t n_launch = (n_turns + b->max_fuse - 1) / b->max_fuse;
     static const bool no_graph = getenv("GE_NO_GRAPH") != nullptr;           // A/B runs
+    hipGraphExec_t exec = nullptr;
     if (n_launch >= GRAPH_MIN_LAUNCHES && !b->timing && b->graphs_ok && !no_graph) {
-        hipGraphExec_t exec = graph_for(b, n_turns);
-        if (exec) {
-            if (b->turn_dev_value != b->turn)
-                HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(b->turn_dev), (int)(uint32_t)b->turn, 1, st));
-            HIP_TRY(hipGraphLaunch(exec, st));
-            b->turn += n_turns;
-            b->turn_dev_value = b->turn;
-            b->launches += n_launch;
-            return GE_OK;
-        }
-        b->graphs_ok = false;                                   // capture unsupported here: plain launches from now on
-        (void)hipGetLastError();
+        exec = graph_for(b, n_turns);                       // may synchronise the previous stream (eviction)
+        if (!exec) { b->graphs_ok = false; (void)hipGetLastError(); }   // capture unsupported here: plain launches from now on
+    }
+    int ord = order_after_previous(b, st);
+    if (ord != GE_OK) return ord;
+    if (exec) {
+        if (b->turn_dev_value != b->turn)
+            HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(b->turn_dev), (int)(uint32_t)b->turn, 1, st));
+        HIP_TRY(hipGraphLaunch(exec, st));
+        b->turn += n_turns;
+        b->turn_dev_value = b->turn;
+        b->launches += n_launch;
+        return GE_OK;
     }
     uint32_t left = n_turns;
     while (left) {
@@ -868,16 +1058,9 @@ int ge_batch_step(ge_batch *b, uint32_t n_turns, void *hip_stream) {
     return GE_OK;
 }
 
-int ge_batch_sync(ge_batch *b) {
-    if (!b) return GE_ERR_ARG;
-    HIP_TRY(hipSetDevice(b->device));
-    HIP_TRY(hipStreamSynchronize(b->last_stream));
-    return GE_OK;
-}
-
-int ge_batch_kernel_time(ge_batch *b, int reset, double *total_ms, uint64_t *launches) {
-    if (!b) return GE_ERR_ARG;
-    int st = ge_batch_sync(b);
+static int kernel_time_impl(ge_batch *b, int reset, double *total_ms, uint64_t *launches) {
+    GE_ON_DEVICE(b);
+    int st = sync_impl(b);
     if (st != GE_OK) return st;
     for (size_t i = 0; i < b->events_used; i++) {
         float ms = 0.f;
@@ -891,21 +1074,10 @@ int ge_batch_kernel_time(ge_batch *b, int reset, double *total_ms, uint64_t *lau
     return GE_OK;
 }
 
-int ge_batch_turn(const ge_batch *b, uint64_t *turn) {
-    if (!b || !turn) return GE_ERR_ARG;
-    *turn = b->turn;
-    return GE_OK;
-}
-
-int ge_batch_n_rooms(const ge_batch *b, uint64_t *n) {
-    if (!b || !n) return GE_ERR_ARG;
-    *n = b->n_rooms;
-    return GE_OK;
-}
-
 static int rooms_io(ge_batch *b, uint64_t first, uint64_t count, ge_room_view *dst, const ge_room_view *src) {
     if (first + count > b->n_rooms || first + count < first) return GE_ERR_RANGE;
-    int st = ge_batch_sync(b);
+    GE_ON_DEVICE(b);
+    int st = sync_impl(b);
     if (st != GE_OK) return st;
     for (Segment &s : b->segs) {
         const uint64_t lo = first > s.local_first ? first : s.local_first;
@@ -943,76 +1115,66 @@ static int rooms_io(ge_batch *b, uint64_t first, uint64_t count, ge_room_view *d
     return GE_OK;
 }
 
-int ge_batch_read_rooms(ge_batch *b, uint64_t first, uint64_t count, ge_room_view *dst, size_t cap_bytes) {
-    if (!b || (!dst && count)) return GE_ERR_ARG;
-    if (cap_bytes / sizeof(ge_room_view) < count) return GE_ERR_ARG;
-    return rooms_io(b, first, count, dst, nullptr);
-}
-
-int ge_batch_write_rooms(ge_batch *b, uint64_t first, uint64_t count, const ge_room_view *src) {
-    if (!b || (!src && count)) return GE_ERR_ARG;
-    for (uint64_t k = 0; k < count; k++)                       // werewolf role classes are 0 (unassigned) .. 4
-        if (src[k].pack == GE_PACK_WEREWOLF)
-            for (int i = 0; i < src[k].n_players && i < 16; i++)
-                if (src[k].players[i][0] > 4) return GE_ERR_ARG;
-    return rooms_io(b, first, count, nullptr, src);
-}
-
-int ge_batch_inject_action(ge_batch *b, uint64_t room, uint32_t player_id, uint32_t choice) {
-    if (!b || room >= b->n_rooms) return GE_ERR_ARG;
-    ge_room_view v;
-    int st = ge_batch_read_rooms(b, room, 1, &v, sizeof v);
+// n logged actions of host-driven players: sorted by room on the host (stable, so a room's actions keep
+// their input order), applied by one device thread per distinct room
+static int inject_impl(ge_batch *b, uint64_t n, const uint64_t *rooms, const uint32_t *players, const uint32_t *choices, int32_t *status) {
+    if (n == 0) return GE_OK;
+    if (!rooms || !players || !choices || n > 0x7FFFFFFFull) return GE_ERR_ARG;
+    GE_ON_DEVICE(b);
+    int st = sync_impl(b);
     if (st != GE_OK) return st;
-    const Segment *seg = nullptr;
-    for (const Segment &s : b->segs)
-        if (room >= s.local_first && room < s.local_first + s.dev.rooms) seg = &s;
-    const ge_game_table &tb = seg->table;
-    const int n = v.n_players;
-    if (player_id < 1 || (int)player_id > n) return GE_ERR_ARG;
-    const ge_phase_row *row = nullptr;
-    for (int k = 0; k < tb.n_phases; k++)
-        if (tb.rows[k].phase_id == v.phase_id) row = &tb.rows[k];
-    if (!row || row->completion != GE_COMP_ACTION) return GE_ERR_ARG;
-    uint8_t *f = v.players[player_id - 1];
-    const bool ww = tb.pack == GE_PACK_WEREWOLF;
-    // the player must be a target of the phase (condition AND alive) and not have acted in this visit
-    auto base_true = [&](int base) -> bool {
-        if (ww) {
-            switch (base) {
-            case 0: return f[2]; case 1: return f[4]; case 2: return f[3]; case 3: return f[5]; case 4: return f[6];
-            case 5: return f[7]; case 6: return f[1] == 1; case 7: return f[1] == 2; default: return f[0] == base - 7;
-            }
-        }
-        switch (base) { case 0: return f[0]; case 1: return f[1]; case 2: return f[3]; case 3: return f[4]; default: return f[6]; }
-    };
-    if (ww && !f[2]) return GE_ERR_ARG;
-    for (int t = 0; t < row->n_terms; t++)
-        if (base_true(row->term_base[t]) == (row->term_neg[t] != 0)) return GE_ERR_ARG;
-    if (f[9]) return GE_ERR_ARG;
-    if (ww) {
-        if (choice < 1 || (int)choice > n || !v.players[choice - 1][2]) return GE_ERR_ARG;     // targets must be alive
-    } else if (row->act == GE_ACT_TT_STATEMENTS ? choice != 1 : (choice < 1 || choice > 3)) return GE_ERR_ARG;
-    f[9] = 1; f[10] = (uint8_t)choice;
-    switch (row->act) {                                   // Referee (A), POLICY.md §3 "record"
-    case GE_ACT_DETECTIVE: v.det[choice - 1] = v.players[choice - 1][1] == 2 ? 2 : 1; /* fallthrough */
-    case GE_ACT_WOLF_TARGET:
-    case GE_ACT_DOCTOR_PROTECT: f[7] = 1; f[8] = (uint8_t)choice; break;
-    case GE_ACT_TT_STATEMENTS: f[1] = 1; break;
-    case GE_ACT_TT_LIE: f[2] = (uint8_t)choice; break;
-    case GE_ACT_TT_VOTE: f[5] = (uint8_t)choice; f[6] = 1; break;
-    default: break;
+    std::vector<uint32_t> order((size_t)n);
+    for (size_t k = 0; k < n; k++) order[k] = (uint32_t)k;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return rooms[x] < rooms[y]; });
+    // one upload: [rooms u64 x n][players u32 x n][choices u32 x n][group u32 x (n+1)][status i32 x n]
+    const size_t off_pl = 8 * (size_t)n, off_ch = off_pl + 4 * (size_t)n, off_gr = off_ch + 4 * (size_t)n;
+    const size_t off_st = off_gr + 4 * ((size_t)n + 1), total = off_st + 4 * (size_t)n;
+    std::vector<unsigned char> host(total);
+    uint64_t *h_rooms = reinterpret_cast<uint64_t *>(host.data());
+    uint32_t *h_pl = reinterpret_cast<uint32_t *>(host.data() + off_pl), *h_ch = reinterpret_cast<uint32_t *>(host.data() + off_ch);
+    uint32_t *h_gr = reinterpret_cast<uint32_t *>(host.data() + off_gr);
+    uint32_t groups = 0;
+    for (size_t k = 0; k < n; k++) {
+        h_rooms[k] = rooms[order[k]]; h_pl[k] = players[order[k]]; h_ch[k] = choices[order[k]];
+        if (k == 0 || h_rooms[k] != h_rooms[k - 1]) h_gr[groups++] = (uint32_t)k;
     }
-    return ge_batch_write_rooms(b, room, 1, &v);
+    h_gr[groups] = (uint32_t)n;
+    if (b->inj_cap < total) {
+        if (b->inj_buf) (void)hipFree(b->inj_buf);
+        b->inj_buf = nullptr; b->inj_cap = 0;
+        const size_t cap = total < 4096 ? 4096 : total * 2;
+        if (hipMalloc(&b->inj_buf, cap) != hipSuccess) return GE_ERR_NOMEM;
+        b->inj_cap = cap;
+    }
+    char *dev = static_cast<char *>(b->inj_buf);
+    HIP_TRY(hipMemcpyAsync(dev, host.data(), off_st, hipMemcpyHostToDevice, b->last_stream));
+    InjectArgs a;
+    a.rooms = reinterpret_cast<const uint64_t *>(dev); a.players = reinterpret_cast<const uint32_t *>(dev + off_pl);
+    a.choices = reinterpret_cast<const uint32_t *>(dev + off_ch); a.group = reinterpret_cast<const uint32_t *>(dev + off_gr);
+    a.status = reinterpret_cast<int32_t *>(dev + off_st);
+    a.n_groups = groups; a.n_seg = (uint32_t)b->segs.size();
+    hipLaunchKernelGGL(ge_inject_kernel, dim3((groups + 63u) / 64u), dim3(64), 0, b->last_stream, a, b->segs_dev, b->tables);
+    HIP_TRY(hipGetLastError());
+    std::vector<int32_t> h_st((size_t)n);
+    HIP_TRY(hipMemcpyAsync(h_st.data(), dev + off_st, 4 * (size_t)n, hipMemcpyDeviceToHost, b->last_stream));
+    HIP_TRY(hipStreamSynchronize(b->last_stream));
+    int first_bad = GE_OK;
+    size_t first_bad_at = (size_t)n;
+    for (size_t k = 0; k < n; k++) {
+        if (status) status[order[k]] = h_st[k];
+        if (h_st[k] != GE_OK && order[k] < first_bad_at) { first_bad_at = order[k]; first_bad = h_st[k]; }
+    }
+    return first_bad;
 }
 
-int ge_batch_read_events(ge_batch *b, uint64_t first, uint64_t count, uint32_t *n_turns, ge_turn_event *dst, size_t cap_bytes) {
-    if (!b || !n_turns || (!dst && count)) return GE_ERR_ARG;
+static int read_events_impl(ge_batch *b, uint64_t first, uint64_t count, uint32_t *n_turns, ge_turn_event *dst, size_t cap_bytes) {
     if (!(b->flags & GE_FLAG_TRACE)) return GE_ERR_UNSUPPORTED;
     if (first + count > b->n_rooms || first + count < first) return GE_ERR_RANGE;
     const uint32_t T = b->last_step_turns;
     *n_turns = T;
     if (cap_bytes / sizeof(ge_turn_event) < count * (uint64_t)T) return GE_ERR_ARG;
-    int st = ge_batch_sync(b);
+    GE_ON_DEVICE(b);
+    int st = sync_impl(b);
     if (st != GE_OK) return st;
     std::vector<uint32_t> buf;
     for (Segment &s : b->segs) {
@@ -1021,7 +1183,6 @@ int ge_batch_read_events(ge_batch *b, uint64_t first, uint64_t count, uint32_t *
         if (lo >= hi) continue;
         const uint64_t r0 = lo - s.local_first, nr = hi - lo;
         buf.resize((size_t)nr * 4);
-        const bool tt = s.table.pack == GE_PACK_TWO_TRUTHS;
         for (uint32_t t = 0; t < T; t++) {
             const char *dev = reinterpret_cast<const char *>(s.dev.trace) + ((uint64_t)t * s.dev.rooms_padded + r0) * 16u;
             HIP_TRY(hipMemcpy(buf.data(), dev, (size_t)nr * 16u, hipMemcpyDeviceToHost));
@@ -1036,16 +1197,14 @@ int ge_batch_read_events(ge_batch *b, uint64_t first, uint64_t count, uint32_t *
                 e.acted_now = (uint16_t)(w[1] >> 20);
                 const uint64_t ch = (uint64_t)w[2] | ((uint64_t)w[3] << 32);
                 for (int i = 0; i < 16; i++) e.choice[i] = (uint8_t)((ch >> (4 * i)) & 15u);
-                (void)tt;
             }
         }
     }
     return GE_OK;
 }
 
-int ge_batch_summary(ge_batch *b, ge_summary *out) {
-    if (!b || !out) return GE_ERR_ARG;
-    HIP_TRY(hipSetDevice(b->device));
+static int summary_impl(ge_batch *b, ge_summary *out) {
+    GE_ON_DEVICE(b);
     hipStream_t st = b->last_stream;
     HIP_TRY(hipMemsetAsync(b->sum_dev, 0, sizeof(unsigned long long) * 64, st));
     StepArgs a;
@@ -1061,6 +1220,7 @@ int ge_batch_summary(ge_batch *b, ge_summary *out) {
     unsigned long long h[64];
     HIP_TRY(hipMemcpyAsync(h, b->sum_dev, sizeof h, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    b->pending = false;
     memset(out, 0, sizeof *out);
     out->rooms = b->n_rooms;
     out->finished = h[0]; out->village_wins = h[1]; out->wolf_wins = h[2]; out->alive_players = h[3];
@@ -1070,6 +1230,98 @@ int ge_batch_summary(ge_batch *b, ge_summary *out) {
     out->games_recycled = h[38];
     out->turn = b->turn;
     return GE_OK;
+}
+
+extern "C" {
+
+int ge_batch_create(const ge_batch_desc *desc, ge_batch **out) {
+    return guarded([&] { return create_impl(desc, out); });
+}
+
+int ge_batch_reset(ge_batch *b) {
+    if (!b) return GE_ERR_ARG;
+    return guarded([&] { return reset_impl(b); });
+}
+
+int ge_batch_set_turn(ge_batch *b, uint64_t turn) {
+    if (!b) return GE_ERR_ARG;
+    if (turn > 0xFFFFFFFFull) return GE_ERR_RANGE;
+    return guarded([&] {
+        GE_ON_DEVICE(b);
+        int st = sync_impl(b);
+        if (st != GE_OK) return st;
+        b->turn = turn;                                    // the graph path re-seeds its device word when it differs
+        return (int)GE_OK;
+    });
+}
+
+int ge_batch_set_timing(ge_batch *b, int on) {
+    if (!b) return GE_ERR_ARG;
+    b->timing = on != 0;
+    return GE_OK;
+}
+
+int ge_batch_step(ge_batch *b, uint32_t n_turns, void *hip_stream) {
+    if (!b) return GE_ERR_ARG;
+    return guarded([&] { return step_impl(b, n_turns, hip_stream); });
+}
+
+int ge_batch_sync(ge_batch *b) {
+    if (!b) return GE_ERR_ARG;
+    return guarded([&] { GE_ON_DEVICE(b); return sync_impl(b); });
+}
+
+int ge_batch_kernel_time(ge_batch *b, int reset, double *total_ms, uint64_t *launches) {
+    if (!b) return GE_ERR_ARG;
+    return guarded([&] { return kernel_time_impl(b, reset, total_ms, launches); });
+}
+
+int ge_batch_turn(const ge_batch *b, uint64_t *turn) {
+    if (!b || !turn) return GE_ERR_ARG;
+    *turn = b->turn;
+    return GE_OK;
+}
+
+int ge_batch_n_rooms(const ge_batch *b, uint64_t *n) {
+    if (!b || !n) return GE_ERR_ARG;
+    *n = b->n_rooms;
+    return GE_OK;
+}
+
+int ge_batch_read_rooms(ge_batch *b, uint64_t first, uint64_t count, ge_room_view *dst, size_t cap_bytes) {
+    if (!b || (!dst && count)) return GE_ERR_ARG;
+    if (cap_bytes / sizeof(ge_room_view) < count) return GE_ERR_ARG;
+    return guarded([&] { return rooms_io(b, first, count, dst, nullptr); });
+}
+
+int ge_batch_write_rooms(ge_batch *b, uint64_t first, uint64_t count, const ge_room_view *src) {
+    if (!b || (!src && count)) return GE_ERR_ARG;
+    for (uint64_t k = 0; k < count; k++)                       // werewolf role classes are 0 (unassigned) .. 4
+        if (src[k].pack == GE_PACK_WEREWOLF)
+            for (int i = 0; i < src[k].n_players && i < 16; i++)
+                if (src[k].players[i][0] > 4) return GE_ERR_ARG;
+    return guarded([&] { return rooms_io(b, first, count, nullptr, src); });
+}
+
+int ge_batch_inject_actions(ge_batch *b, uint64_t n, const uint64_t *rooms, const uint32_t *player_ids,
+                            const uint32_t *choices, int32_t *status) {
+    if (!b) return GE_ERR_ARG;
+    return guarded([&] { return inject_impl(b, n, rooms, player_ids, choices, status); });
+}
+
+int ge_batch_inject_action(ge_batch *b, uint64_t room, uint32_t player_id, uint32_t choice) {
+    if (!b || room >= b->n_rooms) return GE_ERR_ARG;
+    return ge_batch_inject_actions(b, 1, &room, &player_id, &choice, nullptr);
+}
+
+int ge_batch_read_events(ge_batch *b, uint64_t first, uint64_t count, uint32_t *n_turns, ge_turn_event *dst, size_t cap_bytes) {
+    if (!b || !n_turns || (!dst && count)) return GE_ERR_ARG;
+    return guarded([&] { return read_events_impl(b, first, count, n_turns, dst, cap_bytes); });
+}
+
+int ge_batch_summary(ge_batch *b, ge_summary *out) {
+    if (!b || !out) return GE_ERR_ARG;
+    return guarded([&] { return summary_impl(b, out); });
 }
 
 int ge_batch_state(ge_batch *b, uint32_t segment, void **dev_ptr, size_t *bytes, uint32_t *bytes_per_room) {
@@ -1083,17 +1335,21 @@ int ge_batch_state(ge_batch *b, uint32_t segment, void **dev_ptr, size_t *bytes,
 
 void ge_batch_destroy(ge_batch *b) {
     if (!b) return;
-    (void)hipSetDevice(b->device);
-    (void)hipStreamSynchronize(b->last_stream);               // nothing of this batch may still be running
-    for (auto &ev : b->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
-    for (auto &g : b->graphs) (void)hipGraphExecDestroy(g.second);
-    if (b->cap_stream) (void)hipStreamDestroy(b->cap_stream);
-    if (b->turn_dev) (void)hipFree(b->turn_dev);
-    if (b->state) (void)hipFree(b->state);
-    if (b->trace) (void)hipFree(b->trace);
-    if (b->tables) (void)hipFree(b->tables);
-    if (b->segs_dev) (void)hipFree(b->segs_dev);
-    if (b->sum_dev) (void)hipFree(b->sum_dev);
+    {
+        DeviceGuard dg(b->device);
+        (void)hipStreamSynchronize(b->last_stream);               // nothing of this batch may still be running
+        for (auto &ev : b->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+        if (b->order_ev) (void)hipEventDestroy(b->order_ev);
+        for (auto &g : b->graphs) (void)hipGraphExecDestroy(g.second);
+        if (b->cap_stream) (void)hipStreamDestroy(b->cap_stream);
+        if (b->turn_dev) (void)hipFree(b->turn_dev);
+        if (b->inj_buf) (void)hipFree(b->inj_buf);
+        if (b->state) (void)hipFree(b->state);
+        if (b->trace) (void)hipFree(b->trace);
+        if (b->tables) (void)hipFree(b->tables);
+        if (b->segs_dev) (void)hipFree(b->segs_dev);
+        if (b->sum_dev) (void)hipFree(b->sum_dev);
+    }
     delete b;
 }
 

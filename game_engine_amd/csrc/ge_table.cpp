@@ -13,6 +13,7 @@
 #include <string.h>
 
 #include <memory>
+#include <new>
 #include <string>
 #include <utility>
 #include <vector>
@@ -277,8 +278,8 @@ int resolver_for(const std::string &key) {
 
 }  // namespace
 
-extern "C" int ge_table_compile_json(const char *dsl_json, size_t len, int rounds, ge_game_table *out,
-                                     char *err_buf, size_t err_cap) {
+static int compile_impl(const char *dsl_json, size_t len, int rounds, ge_game_table *out,
+                        char *err_buf, size_t err_cap) {
     if (!dsl_json || !out || rounds < 1) return GE_ERR_ARG;
     Err err{err_buf, err_cap};
     if (err_buf && err_cap) err_buf[0] = 0;
@@ -448,4 +449,16 @@ extern "C" int ge_table_compile_json(const char *dsl_json, size_t len, int round
     }
     *out = t;
     return GE_OK;
+}
+
+// nothing throws across the C ABI: the parser and the compiler allocate (std::string / std::vector)
+extern "C" int ge_table_compile_json(const char *dsl_json, size_t len, int rounds, ge_game_table *out,
+                                     char *err_buf, size_t err_cap) {
+    try {
+        return compile_impl(dsl_json, len, rounds, out, err_buf, err_cap);
+    } catch (const std::bad_alloc &) {
+        return GE_ERR_NOMEM;
+    } catch (...) {
+        return GE_ERR_DSL;
+    }
 }

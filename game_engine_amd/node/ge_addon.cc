@@ -27,6 +27,8 @@ namespace {
     } while (0)
 
 napi_value throw_status(napi_env env, int st, const char *what, const char *detail = nullptr) {
+    bool pending = false;
+    if (napi_is_exception_pending(env, &pending) == napi_ok && pending) return nullptr;   // e.g. GE_BUSY from batch_arg
     std::string msg = std::string(what) + ": " + ge_strerror(st);
     if (detail && *detail) msg += std::string(" (") + detail + ")";
     char code[16];
@@ -64,7 +66,18 @@ bool get_prop_u64(napi_env env, napi_value obj, const char *name, uint64_t *out,
     return get_u64(env, v, out);
 }
 
-void finalize_batch(napi_env, void *data, void *) { ge_batch_destroy(static_cast<ge_batch *>(data)); }
+// What a batch External holds.  The C handle is not thread-safe (ge_step.h), so while an async step owns
+// it on a libuv worker (`busy`) every other entry point refuses it instead of racing, and the worker keeps
+// a reference on the External so that the garbage collector cannot finalize it mid-step.
+struct BatchBox {
+    ge_batch *b = nullptr;
+    bool busy = false;
+};
+void finalize_batch(napi_env, void *data, void *) {
+    BatchBox *box = static_cast<BatchBox *>(data);
+    if (box->b) ge_batch_destroy(box->b);
+    delete box;
+}
 void finalize_table(napi_env, void *data, void *) { free(data); }
 
 // compileTable(dslJson: string, rounds?: number): External<ge_game_table>
@@ -160,37 +173,58 @@ napi_value CreateBatch(napi_env env, napi_callback_info info) {
     ge_batch *b = nullptr;
     int st = ge_batch_create(&d, &b);
     if (st != GE_OK) return throw_status(env, st, "createBatch");
+    BatchBox *box = new BatchBox();
+    box->b = b;
     napi_value ext;
-    NAPI_OK(napi_create_external(env, b, finalize_batch, nullptr, &ext));
+    if (napi_create_external(env, box, finalize_batch, nullptr, &ext) != napi_ok) {
+        ge_batch_destroy(b);
+        delete box;
+        napi_throw_error(env, "GE_NAPI", "napi_create_external failed");
+        return nullptr;
+    }
     return ext;
 }
 
+BatchBox *box_arg(napi_env env, napi_value v) {
+    BatchBox *box = nullptr;
+    if (napi_get_value_external(env, v, reinterpret_cast<void **>(&box)) != napi_ok) return nullptr;
+    return box;
+}
+
+// the handle of a batch that is alive and not owned by an async step; throws and returns null otherwise
 ge_batch *batch_arg(napi_env env, napi_value v) {
-    ge_batch *b = nullptr;
-    if (napi_get_value_external(env, v, reinterpret_cast<void **>(&b)) != napi_ok) return nullptr;
-    return b;
+    BatchBox *box = box_arg(env, v);
+    if (!box || !box->b) return nullptr;
+    if (box->busy) {
+        napi_throw_error(env, "GE_BUSY", "an async step() of this batch is in flight: await it first (a ge_batch handle is not thread-safe)");
+        return nullptr;
+    }
+    return box->b;
 }
 
 struct StepWork {
     napi_async_work work;
     napi_deferred deferred;
-    ge_batch *batch;
+    napi_ref keep;            // the External: alive until the worker is done
+    BatchBox *box;
     uint32_t turns;
     int status;
 };
 
 void step_execute(napi_env, void *data) {
     StepWork *w = static_cast<StepWork *>(data);
-    w->status = ge_batch_step(w->batch, w->turns, nullptr);
-    if (w->status == GE_OK) w->status = ge_batch_sync(w->batch);
+    w->status = ge_batch_step(w->box->b, w->turns, nullptr);
+    if (w->status == GE_OK) w->status = ge_batch_sync(w->box->b);
 }
 
 void step_complete(napi_env env, napi_status, void *data) {
     StepWork *w = static_cast<StepWork *>(data);
+    w->box->busy = false;
+    ge_batch *const batch_of_w = w->box->b;
     napi_value v;
     if (w->status == GE_OK) {
         uint64_t turn = 0;
-        ge_batch_turn(w->batch, &turn);
+        ge_batch_turn(batch_of_w, &turn);
         napi_create_double(env, (double)turn, &v);
         napi_resolve_deferred(env, w->deferred, v);
     } else {
@@ -200,6 +234,7 @@ void step_complete(napi_env env, napi_status, void *data) {
         napi_reject_deferred(env, w->deferred, v);
     }
     napi_delete_async_work(env, w->work);
+    napi_delete_reference(env, w->keep);          // last: from here on the External may be collected
     delete w;
 }
 
@@ -212,12 +247,24 @@ napi_value Step(napi_env env, napi_callback_info info) {
     uint64_t turns = 1;
     if (!b || (argc > 1 && !get_u64(env, argv[1], &turns))) return throw_status(env, GE_ERR_ARG, "step");
     StepWork *w = new StepWork();
-    w->batch = b; w->turns = (uint32_t)turns; w->status = GE_OK;
+    w->box = box_arg(env, argv[0]); w->turns = (uint32_t)turns; w->status = GE_OK;
     napi_value promise, name;
-    NAPI_OK(napi_create_promise(env, &w->deferred, &promise));
-    NAPI_OK(napi_create_string_utf8(env, "ge_batch_step", NAPI_AUTO_LENGTH, &name));
-    NAPI_OK(napi_create_async_work(env, nullptr, name, step_execute, step_complete, w, &w->work));
-    NAPI_OK(napi_queue_async_work(env, w->work));
+    if (napi_create_reference(env, argv[0], 1, &w->keep) != napi_ok) { delete w; return throw_status(env, GE_ERR_ARG, "step"); }
+    if (napi_create_promise(env, &w->deferred, &promise) != napi_ok ||
+        napi_create_string_utf8(env, "ge_batch_step", NAPI_AUTO_LENGTH, &name) != napi_ok ||
+        napi_create_async_work(env, nullptr, name, step_execute, step_complete, w, &w->work) != napi_ok) {
+        napi_delete_reference(env, w->keep);
+        delete w;
+        return throw_status(env, GE_ERR_ARG, "step");
+    }
+    w->box->busy = true;
+    if (napi_queue_async_work(env, w->work) != napi_ok) {
+        w->box->busy = false;
+        napi_delete_async_work(env, w->work);
+        napi_delete_reference(env, w->keep);
+        delete w;
+        return throw_status(env, GE_ERR_ARG, "step");
+    }
     return promise;
 }
 
@@ -267,6 +314,76 @@ napi_value InjectAction(napi_env env, napi_callback_info info) {
         return throw_status(env, GE_ERR_ARG, "injectAction");
     int st = ge_batch_inject_action(b, room, (uint32_t)player, (uint32_t)choice);
     if (st != GE_OK) return throw_status(env, st, "injectAction");
+    return nullptr;
+}
+
+// injectActions(batch, rooms: BigUint64Array, playerIds: Uint32Array, choices: Uint32Array): Int32Array of per-action status
+napi_value InjectActions(napi_env env, napi_callback_info info) {
+    size_t argc = 4;
+    napi_value argv[4];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    ge_batch *b = argc >= 1 ? batch_arg(env, argv[0]) : nullptr;
+    if (!b || argc < 4) return throw_status(env, GE_ERR_ARG, "injectActions");
+    napi_typedarray_type tt[3];
+    size_t len[3];
+    void *data[3];
+    for (int k = 0; k < 3; k++) {
+        napi_value ab;
+        size_t off;
+        if (napi_get_typedarray_info(env, argv[1 + k], &tt[k], &len[k], &data[k], &ab, &off) != napi_ok)
+            return throw_status(env, GE_ERR_ARG, "injectActions", "typed arrays expected");
+    }
+    if (tt[0] != napi_biguint64_array || tt[1] != napi_uint32_array || tt[2] != napi_uint32_array || len[0] != len[1] || len[1] != len[2])
+        return throw_status(env, GE_ERR_ARG, "injectActions", "BigUint64Array, Uint32Array, Uint32Array of equal length");
+    void *st_data = nullptr;
+    napi_value st_buf, st_arr;
+    NAPI_OK(napi_create_arraybuffer(env, len[0] * sizeof(int32_t), &st_data, &st_buf));
+    ge_batch_inject_actions(b, len[0], static_cast<const uint64_t *>(data[0]), static_cast<const uint32_t *>(data[1]),
+                            static_cast<const uint32_t *>(data[2]), static_cast<int32_t *>(st_data));
+    NAPI_OK(napi_create_typedarray(env, napi_int32_array, len[0], st_buf, 0, &st_arr));
+    return st_arr;
+}
+
+// setTurn(batch, turn): restores a checkpoint's turn counter (the RNG is keyed by it)
+napi_value SetTurn(napi_env env, napi_callback_info info) {
+    size_t argc = 2;
+    napi_value argv[2];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    ge_batch *b = argc >= 1 ? batch_arg(env, argv[0]) : nullptr;
+    uint64_t turn = 0;
+    if (!b || argc < 2 || !get_u64(env, argv[1], &turn)) return throw_status(env, GE_ERR_ARG, "setTurn");
+    int st = ge_batch_set_turn(b, turn);
+    if (st != GE_OK) return throw_status(env, st, "setTurn");
+    return nullptr;
+}
+
+// writeRooms(batch, first, buffer: ArrayBuffer of ge_room_view): checkpoint restore
+napi_value WriteRooms(napi_env env, napi_callback_info info) {
+    size_t argc = 3;
+    napi_value argv[3];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    ge_batch *b = argc >= 1 ? batch_arg(env, argv[0]) : nullptr;
+    uint64_t first = 0;
+    void *data = nullptr;
+    size_t bytes = 0;
+    if (!b || argc < 3 || !get_u64(env, argv[1], &first) || napi_get_arraybuffer_info(env, argv[2], &data, &bytes) != napi_ok ||
+        bytes % sizeof(ge_room_view) != 0)
+        return throw_status(env, GE_ERR_ARG, "writeRooms");
+    int st = ge_batch_write_rooms(b, first, bytes / sizeof(ge_room_view), static_cast<const ge_room_view *>(data));
+    if (st != GE_OK) return throw_status(env, st, "writeRooms");
+    return nullptr;
+}
+
+// destroyBatch(batch): releases the device memory now instead of at garbage collection
+napi_value DestroyBatch(napi_env env, napi_callback_info info) {
+    size_t argc = 1;
+    napi_value argv[1];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    BatchBox *box = argc >= 1 ? box_arg(env, argv[0]) : nullptr;
+    if (!box) return throw_status(env, GE_ERR_ARG, "destroyBatch");
+    if (box->busy) { napi_throw_error(env, "GE_BUSY", "destroyBatch while an async step() is in flight"); return nullptr; }
+    if (box->b) ge_batch_destroy(box->b);
+    box->b = nullptr;
     return nullptr;
 }
 
@@ -342,6 +459,10 @@ napi_value Init(napi_env env, napi_value exports) {
         {"stepSync", nullptr, StepSync, nullptr, nullptr, nullptr, napi_default, nullptr},
         {"readRooms", nullptr, ReadRooms, nullptr, nullptr, nullptr, napi_default, nullptr},
         {"injectAction", nullptr, InjectAction, nullptr, nullptr, nullptr, napi_default, nullptr},
+        {"injectActions", nullptr, InjectActions, nullptr, nullptr, nullptr, napi_default, nullptr},
+        {"setTurn", nullptr, SetTurn, nullptr, nullptr, nullptr, napi_default, nullptr},
+        {"writeRooms", nullptr, WriteRooms, nullptr, nullptr, nullptr, napi_default, nullptr},
+        {"destroyBatch", nullptr, DestroyBatch, nullptr, nullptr, nullptr, napi_default, nullptr},
         {"readEvents", nullptr, ReadEvents, nullptr, nullptr, nullptr, napi_default, nullptr},
         {"summary", nullptr, Summary, nullptr, nullptr, nullptr, napi_default, nullptr},
         {"reset", nullptr, Reset, nullptr, nullptr, nullptr, napi_default, nullptr},

@@ -46,10 +46,19 @@ export interface BatchOptions {
 export class RoomBatch {
   constructor(opts: BatchOptions);
   readonly nRooms: number;
+  /** Async steps of one batch are chained; a synchronous call made while one is in flight throws GE_BUSY. */
   step(nTurns?: number): Promise<number>;
+  whenIdle<T>(fn: () => T): Promise<T>;
   stepSync(nTurns?: number): number;
   reset(): void;
+  /** Checkpoint = readRoomsRaw + the turn; restore = writeRoomsRaw + setTurn into a fresh batch. */
+  readRoomsRaw(first: number, count: number): ArrayBuffer;
+  writeRoomsRaw(first: number, buffer: ArrayBuffer): void;
+  setTurn(turn: number | bigint): void;
+  close(): void;
   injectAction(room: number, playerId: number, choice: number): void;
+  /** One kernel for many host-driven players' actions; per-action status, 0 = applied. */
+  injectActions(rooms: ArrayLike<number | bigint>, playerIds: ArrayLike<number>, choices: ArrayLike<number>): Int32Array;
   readRoom(room: number): RoomState;
   readRooms(first: number, count: number): RoomState[];
   readEvents(first: number, count: number): TurnEvent[][];
@@ -63,6 +72,7 @@ export class ShardedBatch {
   readonly shards: RoomBatch[];
   step(nTurns?: number): Promise<bigint | number>;
   reset(): void;
+  close(): void;
   readRoom(room: number): RoomState;
   injectAction(room: number, playerId: number, choice: number): void;
   summary(): Summary;

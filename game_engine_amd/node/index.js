@@ -200,13 +200,37 @@ class RoomBatch {
       segments: segments.map((s) => ({ table: s.table.handle, nPlayers: s.nPlayers, nRooms: s.nRooms, humanMask: s.humanMask || 0 })),
     });
     this.nRooms = segments.reduce((a, s) => a + s.nRooms, 0);
+    this._tail = Promise.resolve();     // async steps of one handle run strictly one after the other
   }
-  /** Advance every room by nTurns turns; resolves with the batch's turn counter. */
-  step(nTurns = 1) { return addon.step(this.handle, nTurns); }
+  /** Advance every room by nTurns turns; resolves with the batch's turn counter.  The C handle is not
+   * thread-safe: async steps of one batch are chained, and any synchronous call (readRoom, injectAction,
+   * summary ...) made while one is in flight throws GE_BUSY instead of racing with the worker thread —
+   * `await` the step, or queue the call with `whenIdle`. */
+  step(nTurns = 1) {
+    const p = this._tail.then(() => addon.step(this.handle, nTurns));
+    this._tail = p.catch(() => {});
+    return p;
+  }
+  /** Runs fn() once every step queued so far has finished (and before any queued later). */
+  whenIdle(fn) {
+    const p = this._tail.then(fn);
+    this._tail = p.catch(() => {});
+    return p;
+  }
   stepSync(nTurns = 1) { return addon.stepSync(this.handle, nTurns); }
   reset() { addon.reset(this.handle); }
+  /** Restore a checkpoint: room records (readRoomsRaw's ArrayBuffer) and the turn they were taken at. */
+  writeRoomsRaw(first, buffer) { addon.writeRooms(this.handle, first, buffer); }
+  readRoomsRaw(first, count) { return addon.readRooms(this.handle, first, count); }
+  setTurn(turn) { addon.setTurn(this.handle, turn); }
+  /** Releases the device memory now (otherwise at garbage collection). */
+  close() { if (this.handle) { addon.destroyBatch(this.handle); this.handle = null; } }
   /** Log an action of a host-driven (human) player in the room's current phase (segment.humanMask). */
   injectAction(room, playerId, choice) { addon.injectAction(this.handle, room, playerId, choice); }
+  /** Many at once (one kernel): rooms[], playerIds[], choices[] -> Int32Array of per-action status (0 = applied). */
+  injectActions(rooms, playerIds, choices) {
+    return addon.injectActions(this.handle, BigUint64Array.from(rooms, (r) => BigInt(r)), Uint32Array.from(playerIds), Uint32Array.from(choices));
+  }
   tableOf(room) {
     let base = 0;
     for (const s of this.segments) { if (room < base + s.nRooms) return s.table; base += s.nRooms; }
@@ -268,6 +292,7 @@ class ShardedBatch {
   }
   async step(nTurns = 1) { return (await Promise.all(this.shards.map((b) => b.step(nTurns))))[0]; }
   reset() { this.shards.forEach((b) => b.reset()); }
+  close() { this.shards.forEach((b) => b.close()); }
   shardOf(room) {
     if (!(room >= 0 && room < this.nRooms)) throw new RangeError(`room ${room}`);
     return [this.shards[Math.floor(room / this.roomsPerDevice)], room % this.roomsPerDevice];

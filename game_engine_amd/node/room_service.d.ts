@@ -14,8 +14,11 @@ export interface TurnResult { state: AgentStateView; toolCalls: ToolCall[]; uiCa
 export class RoomService {
   constructor(opts?: { gamesDir?: string; seed?: bigint | number; device?: number });
   createRoom(opts: { threadId: string; gameName: string; players: RoomPlayer[]; dsl?: object }): AgentStateView;
-  humanAction(threadId: string, playerId: number, choice: number): AgentStateView;
+  /** Requests of one thread are served strictly one after the other. */
+  humanAction(threadId: string, playerId: number, choice: number): Promise<AgentStateView>;
   continueRoom(threadId: string): Promise<TurnResult>;
+  /** Forget a thread and free its device memory; resolves false for an unknown thread. */
+  close(threadId: string): Promise<boolean>;
   serve(port?: number): Promise<import('http').Server>;
 }
 export function roomIndexOf(threadId: string): bigint;

@@ -39,8 +39,9 @@ class RoomService {
     const humanMask = players.reduce((m, p, i) => (p.isBot === false ? m | (1 << i) : m), 0);
     const batch = new RoomBatch({ segments: [{ table, nPlayers: players.length, nRooms: 1, humanMask }], seed: this.seed,
                                   firstRoom: roomIndexOf(threadId), device: this.device, maxFuse: 1, trace: true });
+    if (this.rooms.has(threadId)) this.close(threadId);
     const room = { batch, table, gameName, names: players.map((p, i) => p.name || `Player ${i + 1}`),
-                   state: batch.readRoom(0), phaseHistory: [], playerActions: {}, gameNotes: [] };
+                   state: batch.readRoom(0), phaseHistory: [], playerActions: {}, gameNotes: [], queue: Promise.resolve() };
     this.rooms.set(threadId, room);
     return this.agentState(room);
   }
@@ -51,18 +52,38 @@ class RoomService {
     return { gameName: room.gameName, current_phase_id: s.current_phase_id, current_phase_name: s.current_phase_name,
              player_states: ps, playerActions: room.playerActions, phase_history: room.phaseHistory, game_notes: room.gameNotes };
   }
+  /** Requests of one thread run strictly one after the other (the reference's LangGraph server queues
+   * runs per thread the same way): overlapping /continue and /action calls neither race on the batch
+   * handle nor see a half-updated log. */
+  _serial(room, fn) {
+    const p = room.queue.then(fn);
+    room.queue = p.catch(() => {});
+    return p;
+  }
+  /** Forget a thread and free its device memory (after queued requests have finished). */
+  close(threadId) {
+    const room = this.rooms.get(threadId);
+    if (!room) return Promise.resolve(false);
+    this.rooms.delete(threadId);
+    return this._serial(room, () => { room.batch.close(); return true; });
+  }
   /** A human's vote / choice (the frontend's "Player X voted ..." message, src/app/page.tsx:302-305). */
   humanAction(threadId, playerId, choice) {
     const room = this.rooms.get(threadId);
-    if (!room) throw new Error(`unknown thread ${threadId}`);
-    room.batch.injectAction(0, playerId, choice);
-    room.state = room.batch.readRoom(0);
-    return this.agentState(room);
+    if (!room) return Promise.reject(new Error(`unknown thread ${threadId}`));
+    return this._serial(room, () => {
+      room.batch.injectAction(0, playerId, choice);
+      room.state = room.batch.readRoom(0);
+      return this.agentState(room);
+    });
   }
   /** One turn (one graph run).  Returns { state, toolCalls, uiCalls }. */
-  async continueRoom(threadId) {
+  continueRoom(threadId) {
     const room = this.rooms.get(threadId);
-    if (!room) throw new Error(`unknown thread ${threadId}`);
+    if (!room) return Promise.reject(new Error(`unknown thread ${threadId}`));
+    return this._serial(room, () => this._continue(room));
+  }
+  async _continue(room) {
     const before = room.state;
     await room.batch.step(1);
     const after = room.batch.readRoom(0);
@@ -94,7 +115,8 @@ class RoomService {
           let out;
           if (req.method === 'POST' && req.url === '/rooms') out = this.createRoom(msg);
           else if (req.method === 'POST' && req.url === '/continue') out = await this.continueRoom(msg.threadId);
-          else if (req.method === 'POST' && req.url === '/action') out = this.humanAction(msg.threadId, msg.playerId, msg.choice);
+          else if (req.method === 'POST' && req.url === '/action') out = await this.humanAction(msg.threadId, msg.playerId, msg.choice);
+          else if (req.method === 'POST' && req.url === '/close') out = { closed: await this.close(msg.threadId) };
           else { res.writeHead(404); res.end(); return; }
           res.writeHead(200, { 'content-type': 'application/json' });
           res.end(JSON.stringify(out));

@@ -52,8 +52,40 @@ if (deviceCount() === 0) {
     before = after;
   }
   const big = new RoomBatch({ segments: [{ table, nPlayers: golden.n_players, nRooms: 10000 }], seed: 7n });
-  await big.step(64);
+  { // the handle is not thread-safe: a synchronous call while the async step owns it throws GE_BUSY
+    const p = big.step(64);
+    try { big.summary(); out.busy = 'not refused'; } catch (e) { out.busy = e.code; }
+    await p;
+  }
   const s = big.summary();
+  { // checkpoint (raw room views + turn) restored into a FRESH batch continues bit-identically; close() frees
+    const mk = () => new RoomBatch({ segments: [{ table, nPlayers: golden.n_players, nRooms: 500 }], seed: 3n, firstRoom: 40n, restart: true });
+    const a = mk(), b = mk();
+    await a.step(29);
+    b.writeRoomsRaw(0, a.readRoomsRaw(0, 500));
+    b.setTurn(29);
+    await Promise.all([a.step(35), b.step(35)]);
+    out.restoreEqual = Buffer.from(a.readRoomsRaw(0, 500)).equals(Buffer.from(b.readRoomsRaw(0, 500)));
+    a.close(); b.close();
+    try { a.readRoom(0); out.closed = 'still readable'; } catch (e) { out.closed = 'refused'; }
+  }
+  { // batched injection of host-driven players' actions: per-action status, same effect as one by one
+    const mk = () => new RoomBatch({ segments: [{ table, nPlayers: golden.n_players, nRooms: 64, humanMask: 1 }], seed: 13n, maxFuse: 1 });
+    const a = mk(), b = mk();
+    let applied = 0, same = true;
+    for (let t = 0; t < 40; t++) {
+      const rooms = Array.from({ length: 64 }, (_, r) => r), pl = rooms.map(() => 1), ch = rooms.map((r) => 1 + ((r + t) % 3));
+      const st = a.injectActions(rooms, pl, ch);
+      rooms.forEach((r, k) => {
+        let ok = true;
+        try { b.injectAction(r, 1, ch[k]); } catch (e) { ok = false; }
+        if (ok !== (st[k] === 0)) same = false;
+        applied += ok ? 1 : 0;
+      });
+      a.stepSync(1); b.stepSync(1);
+    }
+    out.injectBatch = { same, applied, equal: Buffer.from(a.readRoomsRaw(0, 64)).equals(Buffer.from(b.readRoomsRaw(0, 64))) };
+  }
   { // three shards (all on device 0 here) == one batch of the same rooms: per room and in the summary
     const { ShardedBatch } = require('./index.js');
     const seg = [{ table, nPlayers: golden.n_players, nRooms: 3000 }];

@@ -29,8 +29,22 @@ function post(port, path, obj) {
   }
   notes = last.state.game_notes.length;
   acts = Object.values(last.state.playerActions).reduce((a, r) => a + Object.keys(r.actions).length, 0);
+  // overlapping requests on ONE thread (two /continue and an /action in flight together): they must be
+  // served one after the other — no GE_BUSY, no duplicated log entries — and /close frees the room
+  const seats = players.map((p, i) => Object.assign({}, p, i === 0 ? { isBot: false } : {}));
+  await post(port, '/rooms', { threadId: 'room-h', gameName: 'werewolf-(mafia)', players: seats, dsl });
+  for (let t = 0; t < 6; t++) await post(port, '/continue', { threadId: 'room-h' });
+  const burst = await Promise.all([post(port, '/continue', { threadId: 'room-h' }), post(port, '/action', { threadId: 'room-h', playerId: 1, choice: 2 }),
+                                   post(port, '/continue', { threadId: 'room-h' }), post(port, '/continue', { threadId: 'room-h' })]);
+  const hist = burst[3].state.phase_history.length;
+  const ids = Object.values(burst[3].state.playerActions).map((r) => Object.keys(r.actions));
+  const idsOk = ids.every((k) => k.every((id, j) => id === String(j + 1)));
+  const busy = burst.some((r) => r && r.error && /busy/i.test(r.error));
+  const closed = await post(port, '/close', { threadId: 'room-h' });
+  const after = await post(port, '/continue', { threadId: 'room-h' });
   server.close();
   console.log(JSON.stringify({ room: roomIndexOf('room-abc').toString(), phases, notes, acts, ui,
+                               burst: { hist, idsOk, busy, closed: closed.closed, afterClose: after.error || null, rooms: svc.rooms.size },
                                name1: last.state.player_states['1'].name, finalPhase: last.state.current_phase_name,
                                alive: Object.values(last.state.player_states).map((p) => p.is_alive ? 1 : 0) }));
 })().catch((e) => { console.error(e); process.exit(1); });

@@ -191,6 +191,10 @@ class RoomBatch:
         _check(self._lib.ge_batch_turn(self._h, C.byref(t)))
         return t.value
 
+    def set_turn(self, turn: int):
+        """Restore the turn counter of a checkpoint (the RNG and end_turn are keyed by it)."""
+        _check(self._lib.ge_batch_set_turn(self._h, turn), "ge_batch_set_turn")
+
     def set_timing(self, on: bool):
         _check(self._lib.ge_batch_set_timing(self._h, int(on)))
 
@@ -213,6 +217,19 @@ class RoomBatch:
     def inject_action(self, room: int, player_id: int, choice: int):
         """Log an action of a host-driven (human) player in the room's current phase."""
         _check(self._lib.ge_batch_inject_action(self._h, room, player_id, choice), "ge_batch_inject_action")
+
+    def inject_actions(self, rooms, player_ids, choices) -> np.ndarray:
+        """Log many host-driven players' actions at once (one kernel).  Returns the per-action status
+        (0 = applied, negative ge_status = refused and nothing changed for that action)."""
+        rooms = np.ascontiguousarray(rooms, dtype=np.uint64)
+        player_ids = np.ascontiguousarray(player_ids, dtype=np.uint32)
+        choices = np.ascontiguousarray(choices, dtype=np.uint32)
+        if not (len(rooms) == len(player_ids) == len(choices)):
+            raise GeError(-1, "inject_actions: arrays differ in length")
+        status = np.zeros(len(rooms), dtype=np.int32)
+        self._lib.ge_batch_inject_actions(self._h, len(rooms), rooms.ctypes.data, player_ids.ctypes.data,
+                                          choices.ctypes.data, status.ctypes.data)
+        return status
 
     def read_events(self, first: int = 0, count: Optional[int] = None) -> np.ndarray:
         """[count, n_turns] events of the most recent step() call (batch created with trace=True)."""

@@ -13,8 +13,12 @@
  *     nothing throws or aborts across this boundary; HIP errors map to GE_ERR_HIP.
  *   - the caller owns every host buffer it passes; the library owns device memory behind
  *     the opaque ge_batch handle.
- *   - a handle is not thread-safe: one handle per host thread / GPU.
+ *   - a handle is not thread-safe: one handle per host thread / GPU.  Every call leaves the
+ *     calling thread's current HIP device as it found it.
  *   - ge_batch_step is asynchronous on the given stream; read / summary / sync synchronise.
+ *     Consecutive ge_batch_step calls may name different streams: the library orders each call
+ *     behind the previous one with an event, and every synchronising call waits for the stream
+ *     of the most recent step (which, by that ordering, is behind all earlier ones).
  *   - there is NO CPU fallback: without a HIP device ge_batch_create fails with GE_ERR_NO_DEVICE.
  */
 #ifndef GE_STEP_H
@@ -27,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GE_ABI_VERSION 1
+#define GE_ABI_VERSION 2
 #define GE_MAX_PHASES 32
 #define GE_MAX_PLAYERS 12
 #define GE_MAX_SEGMENTS 4
@@ -191,8 +195,15 @@ int ge_batch_create(const ge_batch_desc *desc, ge_batch **out);
  * `hip_stream` is a hipStream_t (NULL = the default stream).  Asynchronous. */
 int ge_batch_step(ge_batch *b, uint32_t n_turns, void *hip_stream);
 
-/* Back to the initial state and turn 0 (same seed, same rooms).  Synchronises. */
+/* Back to the initial state and turn 0 (same seed, same rooms): a device-side fill of every room
+ * record with the DSL's template state.  Synchronises. */
 int ge_batch_reset(ge_batch *b);
+
+/* Sets the turn counter (0 .. 2^32-1).  The RNG is keyed by (global room, turn) and end_turn and
+ * the event trace are turn-based, so a checkpoint is (room records, turn): restore = create the
+ * batch, ge_batch_write_rooms (or a copy into ge_batch_state), ge_batch_set_turn.  What the
+ * reference's LangGraph checkpointer keeps per thread besides the state (the run counter).  Synchronises. */
+int ge_batch_set_turn(ge_batch *b, uint64_t turn);
 
 int ge_batch_sync(ge_batch *b);
 int ge_batch_turn(const ge_batch *b, uint64_t *turn);
@@ -212,6 +223,15 @@ int ge_batch_write_rooms(ge_batch *b, uint64_t first, uint64_t count, const ge_r
  * (werewolf) or a statement number (two-truths); GE_ERR_ARG if the player is not a target of the
  * current phase, has already acted, or the choice is out of range.  Synchronises. */
 int ge_batch_inject_action(ge_batch *b, uint64_t room, uint32_t player_id, uint32_t choice);
+
+/* The same for n actions at once (a batch of rooms with human seats): one kernel, one thread per
+ * distinct room, which applies that room's actions in input order.  rooms[k] / player_ids[k] /
+ * choices[k] describe action k; status[k] (status may be NULL) receives GE_OK or the reason it was
+ * refused (GE_ERR_ARG as for ge_batch_inject_action, GE_ERR_RANGE for a room outside the batch).  A refused
+ * action changes nothing; the others are applied.  Returns GE_OK if every action was applied, else the
+ * status of the first refused one.  Synchronises. */
+int ge_batch_inject_actions(ge_batch *b, uint64_t n, const uint64_t *rooms, const uint32_t *player_ids,
+                            const uint32_t *choices, int32_t *status);
 
 /* GE_FLAG_TRACE: events of the most recent ge_batch_step call, dst[(room - first) * *n_turns + t].
  * cap_bytes >= count * n_turns * sizeof(ge_turn_event).  Synchronises. */

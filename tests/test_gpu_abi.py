@@ -1,0 +1,133 @@
+"""C-ABI behaviour beyond plain stepping (-m gpu): turn restore, stream changes, device-side reset,
+batched injection of host-driven players' actions, graph cache eviction."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_dsl
+from game_engine_amd import GameTable, GeError, RoomBatch
+from oracle.oracle import Oracle
+from parity_util import assert_views_equal, oracle_rooms_as_views
+
+pytestmark = pytest.mark.gpu
+
+
+def _hip():
+    return C.CDLL("libamdhip64.so")
+
+
+def test_set_turn_restores_raw_state_checkpoint(dsl_ww):
+    """Checkpoint = D2H copy of ge_batch_state + the turn; restore into a fresh batch by copying it
+    back and ge_batch_set_turn: bit-identical continuation, with and without the hipGraph path."""
+    tb = GameTable(dsl_ww)
+    for fuse in (64, 1):
+        with RoomBatch([(tb, 8, 5000)], seed=9, first_room=77, max_fuse=fuse, restart=True) as a:
+            a.step(37)
+            a.sync()
+            ptr, nbytes, _ = a.state(0)
+            ck = np.empty(nbytes, dtype=np.uint8)
+            assert _hip().hipMemcpy(C.c_void_p(ck.ctypes.data), C.c_void_p(ptr), C.c_size_t(nbytes), 2) == 0     # D2H
+            a.step(50)
+            end = a.read_rooms().tobytes()
+        with RoomBatch([(tb, 8, 5000)], seed=9, first_room=77, max_fuse=fuse, restart=True) as b:
+            ptr, nbytes, _ = b.state(0)
+            assert _hip().hipMemcpy(C.c_void_p(ptr), C.c_void_p(ck.ctypes.data), C.c_size_t(nbytes), 1) == 0      # H2D
+            b.set_turn(37)
+            b.step(50)
+            assert b.turn == 87 and b.read_rooms().tobytes() == end
+    with RoomBatch([(tb, 8, 10)], seed=1) as b:
+        with pytest.raises(GeError) as e:
+            b.set_turn(1 << 32)
+        assert e.value.status == -6
+
+
+def test_steps_on_alternating_streams_are_ordered(dsl_ww):
+    """Consecutive ge_batch_step calls on different streams: the library orders them with an event, and
+    reads wait for all of it."""
+    tb = GameTable(dsl_ww)
+    with RoomBatch([(tb, 8, 200000)], seed=4, max_fuse=8, restart=True) as a:
+        a.step(96)
+        want = a.read_rooms().tobytes()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    with RoomBatch([(tb, 8, 200000)], seed=4, max_fuse=8, restart=True) as b:
+        for k in range(12):
+            b.step(8, (s1, s2)[k % 2].cuda_stream)
+        assert b.read_rooms().tobytes() == want
+
+
+def test_reset_is_a_device_fill_back_to_the_template(dsl_ww, dsl_tt):
+    for dsl, n in ((dsl_ww, 12), (dsl_tt, 4)):
+        tb = GameTable(dsl)
+        with RoomBatch([(tb, n, 70001)], seed=2) as b:
+            fresh = b.read_rooms().tobytes()
+            b.step(40)
+            first = b.read_rooms().tobytes()
+            assert first != fresh
+            b.reset()
+            assert b.turn == 0 and b.read_rooms().tobytes() == fresh
+            b.step(40)
+            assert b.read_rooms().tobytes() == first
+
+
+def test_current_device_is_left_alone(dsl_ww):
+    before = torch.cuda.current_device()
+    with RoomBatch([(GameTable(dsl_ww), 8, 100)], seed=2, device=0) as b:
+        b.step(3)
+        b.summary()
+    assert torch.cuda.current_device() == before
+
+
+def test_graph_cache_eviction_while_running(dsl_ww):
+    """More distinct n_turns than the graph cache holds, back to back without synchronising: an evicted
+    executable must not be destroyed while it may still run."""
+    tb = GameTable(dsl_ww)
+    seq = [4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 4, 14, 5]
+    with RoomBatch([(tb, 8, 300000)], seed=6, max_fuse=1, restart=True) as b:
+        for k in seq:
+            b.step(k)
+        got = b.read_rooms().tobytes()
+    with RoomBatch([(tb, 8, 300000)], seed=6, max_fuse=64, restart=True) as a:
+        a.step(sum(seq))
+        assert a.read_rooms().tobytes() == got
+
+
+@pytest.mark.parametrize("game,n,mask", [("werewolf-(mafia)", 8, 0b101), ("werewolf-(mafia)", 12, 0b100000000001),
+                                         ("two-truths-and-a-lie", 4, 0b11), ("two-truths-and-a-lie", 9, 0b100000001)])
+def test_batched_injection_equals_oracle(game, n, mask):
+    """ge_batch_inject_actions: thousands of host-driven players' actions per call (several per room,
+    valid and invalid mixed, rooms in random order) against the oracle applying them one by one."""
+    dsl = load_dsl(game)
+    orc = Oracle(dsl, n)
+    R, seed, first = 20000, 33, 1 << 20
+    rng = np.random.default_rng(n * 7 + mask)
+    rooms = orc.init_rooms(R)
+    humans = [i + 1 for i in range(n) if (mask >> i) & 1]
+    applied = refused = 0
+    with RoomBatch([(GameTable(dsl), n, R, mask)], seed=seed, first_room=first, max_fuse=1) as b:
+        for t in range(60):
+            k = 6000
+            rr = rng.integers(0, R, size=k).astype(np.uint64)
+            pl = rng.choice(humans, size=k).astype(np.uint32)
+            ch = rng.integers(0, n + 2, size=k).astype(np.uint32)
+            if t % 7 == 0:
+                rr[:3] = [R, R + 5, 1 << 40]                  # outside the batch
+            want = np.array([0 if (r < R and orc.inject(rooms, int(r), int(p), int(c))) else (-6 if r >= R else -1)
+                             for r, p, c in zip(rr, pl, ch)], dtype=np.int32)
+            got = b.inject_actions(rr, pl, ch)
+            assert got.tolist() == want.tolist(), f"{game} turn {t}"
+            applied += int((got == 0).sum()); refused += int((got != 0).sum())
+            b.step(1)
+            orc.run(rooms, seed, first, t, 1, threads=0, human_mask=mask)
+            assert_views_equal(b.read_rooms(), oracle_rooms_as_views(orc, rooms), f"{game} turn {t}")
+        # return value = status of the first refused action in input order; NULL status is allowed
+        lib, h = b._lib, b._h
+        r3 = (C.c_uint64 * 3)(0, R + 1, 1)
+        p3 = (C.c_uint32 * 3)(99, 1, 99)
+        c3 = (C.c_uint32 * 3)(1, 1, 1)
+        assert lib.ge_batch_inject_actions(h, 3, r3, p3, c3, None) == -1
+        assert lib.ge_batch_inject_actions(h, 2, C.byref(r3, 8), C.byref(p3, 4), C.byref(c3, 4), None) == -6
+        assert lib.ge_batch_inject_actions(h, 0, None, None, None, None) == 0
+        assert lib.ge_batch_inject_actions(h, 1, None, p3, c3, None) == -1
+    assert applied > 1000 and refused > 1000

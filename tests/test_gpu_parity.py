@@ -270,7 +270,9 @@ def test_shard_invariance(dsl_ww):
 
 
 def test_write_read_roundtrip_and_restore(dsl_ww, dsl_tt):
-    """Checkpoint/restore through canonical views: restore mid-game, continue, same end state."""
+    """Checkpoint/restore through canonical views INTO A FRESH BATCH: a checkpoint is (room records,
+    turn); ge_batch_set_turn restores the counter the RNG is keyed by.  Same end state as the
+    uninterrupted run."""
     for dsl, n in ((dsl_ww, 12), (dsl_ww, 6), (dsl_tt, 4), (dsl_tt, 8), (dsl_tt, 11)):
         tb = GameTable(dsl)
         with RoomBatch([(tb, n, 999)], seed=3, first_room=50) as a:
@@ -279,8 +281,9 @@ def test_write_read_roundtrip_and_restore(dsl_ww, dsl_tt):
             a.step(41)
             end = a.read_rooms()
         with RoomBatch([(tb, n, 999)], seed=3, first_room=50) as b:
-            b.step(23)                                   # only to advance the turn counter
             b.write_rooms(0, np.ascontiguousarray(mid[::-1])[::-1].copy())
+            b.set_turn(23)
+            assert b.turn == 23
             assert b.read_rooms().tobytes() == mid.tobytes()
             b.step(41)
             assert b.read_rooms().tobytes() == end.tobytes()

@@ -74,6 +74,9 @@ def test_node_host_matches_golden(dsl, gold):
     g = json.load(open(os.path.join(GOLD, gold)))
     assert r["devices"] >= 1 and r["checked"] == sum(len(c["turns"]) for c in g["cases"])
     assert r["turn"] == 64 and r["finished"] > 0 and isinstance(r["sample"], str)
+    # handle safety, checkpoint restore with setTurn, close(), batched injection (ge_addon.cc / index.js)
+    assert r["busy"] == "GE_BUSY" and r["restoreEqual"] is True and r["closed"] == "refused"
+    assert r["injectBatch"]["same"] and r["injectBatch"]["equal"] and r["injectBatch"]["applied"] > 30
     # ShardedBatch (one Node process, several devices): shard-count invariance per room and in the summary
     assert r["shardRooms"] == 9000 and r["shardSummaryEqual"] and r["shardRoomsEqual"]
     # the JS host renders the same backend tool calls as the Python host for the same traced room
@@ -112,3 +115,7 @@ def test_single_room_service_over_http():
     assert r["phases"] == phases and r["alive"] == alive and phases[-1] == 99
     assert r["name1"] == "Bot 1" and r["finalPhase"].startswith("Game Over")
     assert r["notes"] > 10 and r["acts"] > 10 and r["ui"] > 100
+    # overlapping /continue + /action on one thread are serialised; /close frees the room
+    bt = r["burst"]
+    assert bt["hist"] == 9 and bt["idsOk"] and not bt["busy"]
+    assert bt["closed"] is True and "unknown thread" in bt["afterClose"] and bt["rooms"] == 1
