@@ -26,6 +26,14 @@ constexpr uint32_t GOLDEN = 0x9E3779B9u;
 #ifndef GE_DPP_SCAN
 #define GE_DPP_SCAN 1
 #endif
+// A/B switches (tools/ab.sh): GE_SHADOW = action-independent work placed in the shadows of the action queue's two
+// LDS round trips; GE_ORD = queue slots find their player through the ord8 table (werewolf N <= 8)
+#ifndef GE_SHADOW
+#define GE_SHADOW 1
+#endif
+#ifndef GE_ORD
+#define GE_ORD 1
+#endif
 
 // ---- POLICY.md §RNG: stateless 32-bit counter hash
 GE_HD uint32_t mix32(uint32_t x) {
@@ -254,19 +262,21 @@ __device__ __forceinline__ void deal_roles(Deal &d, uint32_t dk, uint32_t game, 
 // stalls on every branch instruction and every dependent LDS access, so that build is branch-lean
 // and computes; the other build (many wavefronts, VALU-bound) prefers LDS tables and skip-branches.
 template <int NB, bool QUEUE, bool LOWOCC>
-__device__ __forceinline__ void ww_turn(WWR<NB> &s, DevRow &row, const DevRow *rows, void *wave_lds, const uint8_t *nth8, bool valid, uint32_t n,
-                                        uint32_t nw, uint32_t phase0_idx, uint32_t rkey, uint32_t turn,
+__device__ __forceinline__ void ww_turn(WWR<NB> &s, DevRow &row, const DevRow *rows, void *wave_lds, const uint8_t *nth8, const uint32_t *ord8, bool valid, uint32_t n,
+                                        uint32_t nw, uint32_t phase0_idx, uint32_t rkey, uint32_t turn, uint32_t &tk_io,
                                         bool trace, uint32_t human, Deal &deal, uint32_t &ev_newly, uint64_t &ev_choice) {
     // human: players the host drives (never acted for here)
     // ev_*: this turn's logged actions (who acted, what they chose) for the optional event trace
     // `row` is the table row of s.phase, kept in registers across turns: LDS is read only on a transition
+    // tk_io: in = turn_key(rkey, turn), out = the next turn's key
     using nib_t = typename WWR<NB>::nib_t;
     using R = WWR<NB>;
+    constexpr bool ORD = GE_ORD && NB <= 8;                    // queue slots find their player through the ord8 table
     auto *lw = static_cast<typename WaveLdsOf<LOWOCC>::type *>(wave_lds);
     const uint32_t ALL = (1u << n) - 1u;
     const uint32_t comp = row.r0 & 3u, act = (row.r0 >> 2) & 7u, p_eff = (row.r0 >> 5) & 7u;
     const uint32_t nterms = (row.r0 >> 8) & 7u;
-    const uint32_t tk = turn_key(rkey, turn);
+    const uint32_t tk = tk_io;
     const uint32_t alive = s.template get<F_ALIVE>(), team_w = s.template get<F_TEAM_W>(), r_det = s.template get<F_DET>();
 
     // ---- who must act: target_players.condition AND alive, all players at once.
@@ -301,6 +311,37 @@ __device__ __forceinline__ void ww_turn(WWR<NB> &s, DevRow &row, const DevRow *r
         T = X & alive & (comp == COMP_ACTION ? ALL : 0u);
     }
 
+    // ---- PhaseNode, the part that does not depend on this turn's actions (nobody dies before the Referee):
+    // phase-0 guard, resolver bitset, first matching branch.  With the action queue it runs in the shadow
+    // of the queue's first LDS round trip (a lone wavefront has nothing else to cover it with).
+    bool pre_open = false;
+    uint32_t qe_cand = 0;
+    auto phase_precompute = [&]() {
+        const bool guard = s.phase == phase0_idx && !(s.flags & FLAG_PHASE0_DONE);
+        pre_open = !guard;
+        const uint32_t w = popc(alive & team_w), g = popc(alive & s.template get<F_TEAM_V>());
+        const uint32_t prev_eff = (s.flags >> 1) & 7u;
+        const uint32_t C = 1u | ((w == 0u) << RES_WOLVES_ZERO) | ((w >= g) << RES_WOLVES_GE_VILLAGERS) |
+                           ((prev_eff == EFF_DAY_RESOLVE) << RES_FOLLOWS_DAY) |
+                           ((prev_eff == EFF_NIGHT_RESOLVE) << RES_FOLLOWS_NIGHT) | (1u << RES_OTHERWISE);
+        // first branch (DSL order) whose resolver holds: row.r2 has one byte per branch with the bit of
+        // its resolver set (0 for absent branches), so the lowest non-zero byte of r2 & (C in every byte) wins
+        const uint32_t hit = row.r2 & __builtin_amdgcn_perm(C, C, 0u);   // C (< 256) in every byte
+        const uint32_t sh = ctz(hit) & 24u;
+        qe_cand = hit != 0u ? ((row.r3 >> sh) & 255u) : s.phase;         // next row index | its entry effect << 5
+    };
+    // the role-assignment values of the prepared deal (what `assign` writes), also shadow work
+    R dealt;
+    auto deal_precompute = [&]() {
+#pragma unroll
+        for (int k = 0; k < R::NW; k++) dealt.W[k] = 0;
+        const uint32_t special = ALL & ~deal.rem;
+        dealt.template set<F_VIL>(deal.rem); dealt.template set<F_WOLF>(deal.wolves); dealt.template set<F_DOC>(deal.doc); dealt.template set<F_DET>(deal.det);
+        dealt.template set<F_TEAM_W>(deal.wolves); dealt.template set<F_TEAM_V>(ALL & ~deal.wolves);
+        dealt.template set<F_SECRET>(special); dealt.template set<F_ELIG>(special);
+    };
+    uint32_t tk_next = 0;
+
     // ---- BotBehaviorNode: every due bot acts with probability 3/4, one action per visit
     uint32_t newly = 0, new_det_v = 0, new_det_w = 0;
     const bool night = act >= ACT_WOLF_TARGET && act <= ACT_DETECTIVE;
@@ -310,6 +351,9 @@ __device__ __forceinline__ void ww_turn(WWR<NB> &s, DevRow &row, const DevRow *r
         const uint32_t kw_alive = s.det_w & alive;
         const uint32_t lo_kw = kw_alive & (0u - kw_alive);       // lowest known living werewolf
         if (!QUEUE) {
+            phase_precompute();
+            deal_precompute();
+            tk_next = turn_key(rkey, turn + 1u);
             while (todo) {
                 const uint32_t i = ctz(todo);
                 todo &= todo - 1u;
@@ -329,14 +373,20 @@ __device__ __forceinline__ void ww_turn(WWR<NB> &s, DevRow &row, const DevRow *r
         } else {
             const uint32_t lane = __lane_id();
             const uint32_t cnt = popc(todo);
+            // NB <= 8: the room's slot -> player map (nibble r = its r-th due bot) from the ord8 table; the read is
+            // in flight during the scan, and a slot then needs a shift instead of an n-th-set-bit search
+            uint32_t ord = 0;
+            if (ORD) ord = ord8[todo & 0xFFu];
             uint32_t off, total;
             wave_excl_scan(cnt, off, total);
             if (LOWOCC || total != 0u) {                        // wave-uniform; LOWOCC: some room almost always has a due bot
                 // per-room context of an action; `ky`: what the acting role knows (the Detective's memory
                 // at night, who the Detective is by day - ww_choose reads only one of the two per kind)
                 const uint32_t ky = night ? known : r_det;
-                const uint4 ctx = make_uint4(alive | (team_w << 16) | (act << 28), ky | (lo_kw << 16), todo | (off << 16) | (lane << 26), tk);
-                lw->res[lane] = make_uint4(0u, 0u, 0u, 0u);
+                const uint4 ctx = ORD ? make_uint4(alive | (team_w << 16) | (act << 28), ky | (lo_kw << 8) | (off << 16) | (lane << 26), ord, tk)
+                                      : make_uint4(alive | (team_w << 16) | (act << 28), ky | (lo_kw << 16), todo | (off << 16) | (lane << 26), tk);
+                if (NB <= 8) *reinterpret_cast<uint2 *>(&lw->res[lane]) = make_uint2(0u, 0u);     // only x, y come back
+                else lw->res[lane] = make_uint4(0u, 0u, 0u, 0u);
                 // Queue slot -> owning room.  A room with cnt due bots owns slots [off, off + cnt); it writes
                 // NB slots from `off` on, highest first (immediate offsets, no per-slot address or
                 // predicate).  The surplus writes land in the ranges of the rooms after it and are
@@ -365,39 +415,69 @@ __device__ __forceinline__ void ww_turn(WWR<NB> &s, DevRow &row, const DevRow *r
                     }
                 }
                 wave_sync();
-                for (uint32_t base = 0; base < total; base += 64u) {
+                // slot k -> the owning room's context (slots past `total` hold stale entries: computed like the
+                // others, result dropped).  The first round's read is issued BEFORE the shadow work below.
+                auto fetch = [&](uint32_t k) -> uint4 {
+                    if (LOWOCC) return reinterpret_cast<WaveLdsLow *>(lw)->slot[k];
+                    auto *hi = reinterpret_cast<WaveLds *>(lw);
+                    return hi->ctx[hi->queue[k] & 63u];
+                };
+                uint4 c4 = fetch(lane);
+                if (GE_SHADOW) {
+                    phase_precompute();
+                    asm volatile("" : "+v"(qe_cand));              // stays here: not sunk below the loop
+                }
+                // at least one round (total == 0: every slot is stale and dropped): the loop is left BEFORE the next
+                // round's read is issued, so nothing of the queue is in flight behind it
+                for (uint32_t base = 0;; base += 64u) {
                     const uint32_t k = base + lane;
-                    // slots past `total` hold stale entries: computed like the others, result dropped
-                    uint4 c4;
-                    if (LOWOCC) c4 = reinterpret_cast<WaveLdsLow *>(lw)->slot[k];
-                    else { auto *hi = reinterpret_cast<WaveLds *>(lw); c4 = hi->ctx[hi->queue[k] & 63u]; }
-                    const uint32_t L = c4.z >> 26;
-                    const uint32_t due = c4.z & 0xFFFFu, rank = (k - ((c4.z >> 16) & 0x3FFu)) & 15u;   // this slot = the rank-th due bot of room L
-                    const uint32_t i = (LOWOCC ? nth_set_bit<NB>(due | (1u << 31), rank) : nth_set_bit_lds<NB>(nth8, due, rank)) & 15u;
+                    uint32_t L, i, know, lokw;
+                    if (ORD) {
+                        L = c4.y >> 26;
+                        const uint32_t rank = (k - ((c4.y >> 16) & 0x3FFu)) & 7u;       // this slot = the rank-th due bot of room L
+                        i = (c4.z >> (4u * rank)) & 7u;
+                        know = c4.y & 0xFFu; lokw = (c4.y >> 8) & 0xFFu;
+                    } else {
+                        L = c4.z >> 26;
+                        const uint32_t due = c4.z & 0xFFFFu, rank = (k - ((c4.z >> 16) & 0x3FFu)) & 15u;
+                        i = (LOWOCC ? nth_set_bit<NB>(due | (1u << 31), rank) : nth_set_bit_lds<NB>(nth8, due, rank)) & 15u;
+                        know = c4.y & 0xFFFFu; lokw = c4.y >> 16;
+                    }
                     const uint32_t d = draw(c4.w, i);
                     const bool go = k < total && (d & 3u) != 0u;
                     if (LOWOCC) {
                         // the choice is computed for every slot and only the result is predicated: a
                         // conditional block would split the slot read in two dependent LDS round trips
-                        const uint32_t know = c4.y & 0xFFFFu;
                         const uint32_t c = ww_choose<NB, false>(c4.x >> 28, i, d, c4.x & 0xFFFFu, (c4.x >> 16) & 0xFFFu,
-                                                                know, c4.y >> 16, know, nth8);
+                                                                know, lokw, know, nth8);
                         if (go) {
                             uint32_t *r = reinterpret_cast<uint32_t *>(&lw->res[L]);
                             atomicOr(r, 1u << i);
                             atomicOr(r + 1 + (i >> 3), c << (4u * (i & 7u)));
                         }
                     } else if (go) {
-                        const uint32_t know = c4.y & 0xFFFFu;
                         const uint32_t c = ww_choose<NB, true>(c4.x >> 28, i, d, c4.x & 0xFFFFu, (c4.x >> 16) & 0xFFFu,
-                                                               know, c4.y >> 16, know, nth8);
+                                                               know, lokw, know, nth8);
                         uint32_t *r = reinterpret_cast<uint32_t *>(&lw->res[L]);
                         atomicOr(r, 1u << i);
                         atomicOr(r + 1 + (i >> 3), c << (4u * (i & 7u)));
                     }
+                    if (base + 64u >= total) break;                // wave-uniform
+                    c4 = fetch(k + 64u);
                 }
                 wave_sync();
-                const uint4 r = lw->res[lane];
+                const uint4 r = NB <= 8 ? make_uint4(reinterpret_cast<const uint2 *>(&lw->res[lane])->x, reinterpret_cast<const uint2 *>(&lw->res[lane])->y, 0u, 0u)
+                                        : lw->res[lane];
+                if (GE_SHADOW) {                                   // shadow of the result read
+                    tk_next = turn_key(rkey, turn + 1u);
+                    deal_precompute();
+                    asm volatile("" : "+v"(tk_next));
+#pragma unroll
+                    for (int k = 0; k < R::NW; k++) asm volatile("" : "+v"(dealt.W[k]));
+                    // keeps the slot registers reserved up to here: reusing them for the work above would make the
+                    // compiler wait for the queue's LDS traffic first (a read into them may be in flight)
+                    asm volatile("" :: "v"(c4.x), "v"(c4.y), "v"(c4.z), "v"(c4.w));
+                }
                 newly = r.x;
                 const nib_t got = NB > 8 ? (nib_t)(((uint64_t)r.z << 32) | r.y) : (nib_t)r.y;
                 const nib_t m15 = nib_nonzero(got);              // c >= 1, so a nibble is set iff that player acted
@@ -410,9 +490,15 @@ __device__ __forceinline__ void ww_turn(WWR<NB> &s, DevRow &row, const DevRow *r
                     new_det_w = tb & team_w;
                     new_det_v = tb & ~team_w;
                 }
+                if (!GE_SHADOW) { phase_precompute(); tk_next = turn_key(rkey, turn + 1u); deal_precompute(); }
+            } else {
+                phase_precompute();
+                deal_precompute();
+                tk_next = turn_key(rkey, turn + 1u);
             }
         }
     }
+    tk_io = tk_next;
     s.acted |= newly;
     s.template set<F_SUB>(night ? newly : 0u);                 // night_action_submitted
     ev_newly = newly;
@@ -424,23 +510,11 @@ __device__ __forceinline__ void ww_turn(WWR<NB> &s, DevRow &row, const DevRow *r
         ev_choice = (uint64_t)s.choice & nib_fill(m);
     }
 
-    // ---- PhaseNode: phase-0 guard (v2:1025-1052): first turn only records phase 0, Referee skipped
-    const bool guard = s.phase == phase0_idx && !(s.flags & FLAG_PHASE0_DONE);
+    // ---- PhaseNode: phase-0 guard (v2:1025-1052): first turn only records phase 0, Referee skipped;
+    // completion: every target player has acted in this visit
     s.flags |= FLAG_PHASE0_DONE;                               // set by the guard turn; already set afterwards
-    uint32_t qe = s.phase;                                     // next row index | its entry effect << 5
-    {   // evaluated for every lane, selected at the end (one branch less than a guarded block)
-        const bool open = !guard && (comp != COMP_ACTION || (T & ~s.acted) == 0u);
-        const uint32_t w = popc(alive & team_w), g = popc(alive & s.template get<F_TEAM_V>());
-        const uint32_t prev_eff = (s.flags >> 1) & 7u;
-        const uint32_t C = 1u | ((w == 0u) << RES_WOLVES_ZERO) | ((w >= g) << RES_WOLVES_GE_VILLAGERS) |
-                           ((prev_eff == EFF_DAY_RESOLVE) << RES_FOLLOWS_DAY) |
-                           ((prev_eff == EFF_NIGHT_RESOLVE) << RES_FOLLOWS_NIGHT) | (1u << RES_OTHERWISE);
-        // first branch (DSL order) whose resolver holds: row.r2 has one byte per branch with the bit of
-        // its resolver set (0 for absent branches), so the lowest non-zero byte of r2 & (C in every byte) wins
-        const uint32_t hit = row.r2 & __builtin_amdgcn_perm(C, C, 0u);   // C (< 256) in every byte
-        const uint32_t sh = ctz(hit) & 24u;
-        qe = (open && hit != 0u) ? ((row.r3 >> sh) & 255u) : qe;
-    }
+    const bool open = pre_open && (comp != COMP_ACTION || (T & ~s.acted) == 0u);
+    const uint32_t qe = open ? qe_cand : s.phase;
     const uint32_t q = qe & 31u;
     {   // investigated_alignments[c] = team(c): an assignment, so a stale entry is replaced
         // (the guard turn has no actions: both masks are 0)
@@ -467,25 +541,27 @@ __device__ __forceinline__ void ww_turn(WWR<NB> &s, DevRow &row, const DevRow *r
     // role assignment: the deal of this game was normally prepared ahead (run loop, every 8th turn, for
     // all lanes of the wavefront at once); fall back to dealing here if it was not
     const bool is_assign = eff == EFF_ASSIGN_ROLES;
-    if (is_assign && !(deal.valid && deal.game == s.games)) deal_roles<NB, LOWOCC>(deal, deal_key(rkey, s.games), s.games, n, nw, nth8);
-    auto assign = [&](WWR<NB> &t) {
-        const uint32_t special = ALL & ~deal.rem;
-        t.template put<F_VIL>(deal.rem); t.template put<F_WOLF>(deal.wolves); t.template put<F_DOC>(deal.doc); t.template put<F_DET>(deal.det);
-        t.template put<F_TEAM_W>(deal.wolves); t.template put<F_TEAM_V>(ALL & ~deal.wolves);
-        t.template put<F_SECRET>(special); t.template put<F_ELIG>(special);
-    };
+    if (is_assign && !(deal.valid && deal.game == s.games)) {
+        deal_roles<NB, LOWOCC>(deal, deal_key(rkey, s.games), s.games, n, nw, nth8);
+        deal_precompute();
+    }
+    // the fields a deal replaces, as masks over the packed predicate words
+    R dmask;
+#pragma unroll
+    for (int k = 0; k < R::NW; k++) dmask.W[k] = 0;
+    dmask.template set<F_VIL>(R::FM); dmask.template set<F_WOLF>(R::FM); dmask.template set<F_DOC>(R::FM); dmask.template set<F_DET>(R::FM);
+    dmask.template set<F_TEAM_W>(R::FM); dmask.template set<F_TEAM_V>(R::FM); dmask.template set<F_SECRET>(R::FM); dmask.template set<F_ELIG>(R::FM);
     if (LOWOCC) {
         // lone wavefront: every divergent block costs an exec-mask sequence and a branch bubble, and both
         // effects are entered by some room of the wavefront on most turns anyway - so both are evaluated
         // for every lane and applied by selects
-        WWR<NB> t = s;
-        assign(t);
 #pragma unroll
-        for (int k = 0; k < R::NW; k++) s.W[k] = is_assign ? t.W[k] : s.W[k];
+        for (int k = 0; k < R::NW; k++) s.W[k] = is_assign ? ((s.W[k] & ~dmask.W[k]) | dealt.W[k]) : s.W[k];
         deal.valid = is_assign ? 0u : deal.valid;
         resolve(eff == EFF_NIGHT_RESOLVE || eff == EFF_DAY_RESOLVE, eff == EFF_DAY_RESOLVE);
     } else if (is_assign) {
-        assign(s);
+#pragma unroll
+        for (int k = 0; k < R::NW; k++) s.W[k] = (s.W[k] & ~dmask.W[k]) | dealt.W[k];
         deal.valid = 0u;
     } else if (eff == EFF_NIGHT_RESOLVE || eff == EFF_DAY_RESOLVE) {
         resolve(true, eff == EFF_DAY_RESOLVE);

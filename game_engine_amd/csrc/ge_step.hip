@@ -20,6 +20,10 @@ using namespace ge;
 
 namespace {
 
+// LDS of a step block: [phase rows][ord8 table][nth8 table, table builds only][one WaveLds per wavefront]
+constexpr uint32_t LDS_ROWS = sizeof(DevRow) * GE_MAX_PHASES;
+constexpr uint32_t LDS_ORD8 = 1024;
+
 // A/B switch for the bot-action step: wave-level work queue in LDS (true) or per-lane loop (false).
 // Measured on MI355X (steady state, K=64): 1 048 576 Werewolf x8 rooms 1.19e11 vs 6.2e10 steps/s,
 // 2 097 152 x12 9.4e10 vs 3.7e10, 65 536 x8 4.4e10 vs 3.6e10 (profiles/r01_queue_ab.txt).
@@ -93,8 +97,12 @@ __device__ __forceinline__ void store_event(uint32_t *trace, uint64_t rooms_padd
     ((__attribute__((address_space(1))) u32x4 *)(uintptr_t)trace)[(uint64_t)t * rooms_padded + room] = v;
 }
 
-__device__ __forceinline__ void load_rows(DevRow *rows, const DevTable *tables, uint32_t table_idx, uint8_t *nth8) {
+__device__ __forceinline__ void load_rows(DevRow *rows, const DevTable *tables, uint32_t table_idx, uint8_t *nth8, uint32_t *ord8 = nullptr) {
     if (threadIdx.x < GE_MAX_PHASES) rows[threadIdx.x] = tables[table_idx].rows[threadIdx.x];
+    if (ord8) {                                                // 1 KB: one 16-B element per thread of a 64-room block
+        const u32x4 *src = reinterpret_cast<const u32x4 *>(tables[table_idx].ord8);
+        for (uint32_t i = threadIdx.x; i < 64u; i += blockDim.x) reinterpret_cast<u32x4 *>(ord8)[i] = src[i];
+    }
     if (nth8) {                                                // 2 KB, 16 B per thread and pass
         const u32x4 *src = reinterpret_cast<const u32x4 *>(tables[table_idx].nth8);
         for (uint32_t i = threadIdx.x; i < 128u; i += blockDim.x) reinterpret_cast<u32x4 *>(nth8)[i] = src[i];
@@ -113,7 +121,9 @@ __device__ __forceinline__ void run_ww(const SegDev *__restrict__ sgp, const Ste
     const uint64_t room = valid ? room_in : 0;
     uint32_t w[L::WORDS];
     load_words<L::WORDS>(sg.base, sg.rooms_padded, room, w);      // in flight while the block fills its LDS tables
-    load_rows(rows, tables, sg.table_idx, LOWOCC ? nullptr : nth8);
+    // the slot -> player table of the action queue sits right behind the phase rows (step_lds_bytes)
+    uint32_t *ord8 = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(rows) + LDS_ROWS);
+    load_rows(rows, tables, sg.table_idx, LOWOCC ? nullptr : nth8, (GE_ORD && NB <= 8) ? ord8 : nullptr);
     WWR<NB> s;
     {
         WW<NB> u;
@@ -140,6 +150,7 @@ __device__ __forceinline__ void run_ww(const SegDev *__restrict__ sgp, const Ste
     // 8th turn all lanes without a prepared deal get their next one together (a game is longer than 8 turns).
     Deal deal = {0u, 0u, 0u, 0u, 0u, 0u};
     const bool ahead = a.n_turns >= 16u;                      // not worth it for short launches
+    uint32_t tk = turn_key(rk, turn0);                        // this turn's key; ww_turn leaves the next turn's (computed in an LDS wait shadow)
     for (uint32_t t = 0; t < a.n_turns; t++) {
         if (ahead && (t & 7u) == 0u && !deal.valid) {
             // this game already has roles: prepare the next game's
@@ -158,7 +169,7 @@ __device__ __forceinline__ void run_ww(const SegDev *__restrict__ sgp, const Ste
         const uint32_t p = s.phase;
         uint32_t ev_newly = 0;
         uint64_t ev_choice = 0;
-        ww_turn<NB, GE_WAVE_QUEUE, LOWOCC>(s, row, rows, lw, nth8, valid, sg.n_players, sg.nw, sg.phase0_idx, rk, turn0 + t,
+        ww_turn<NB, GE_WAVE_QUEUE, LOWOCC>(s, row, rows, lw, nth8, ord8, valid, sg.n_players, sg.nw, sg.phase0_idx, rk, turn0 + t, tk,
                                    a.trace != 0u, sg.human_mask, deal, ev_newly, ev_choice);
         if (a.trace && valid) store_event(sg.trace, sg.rooms_padded, t, room, turn0 + t, p, s.phase, restarted, ev_newly, ev_choice);
     }
@@ -237,15 +248,14 @@ __device__ __forceinline__ void run_kind(const SegDev *__restrict__ sg, const St
     else run_tt<12, LOWOCC>(sg, a, rows, lw, nth8, tables, room);
 }
 
-// LDS of a step block, sized at launch (a 64-room block must not pay for four wavefronts' queues, or
-// LDS, not registers, caps the wavefronts per CU): [phase rows][nth8 table, table builds only][one WaveLds per wavefront]
-constexpr uint32_t LDS_ROWS = sizeof(DevRow) * GE_MAX_PHASES;
+// LDS of a step block is sized at launch (a 64-room block must not pay for four wavefronts' queues, or
+// LDS, not registers, caps the wavefronts per CU)
 constexpr uint32_t LDS_NTH8 = 2048;
-static_assert(sizeof(WaveLds) % 16 == 0 && sizeof(WaveLdsLow) % 16 == 0 && LDS_ROWS % 16 == 0, "LDS sections stay 16-byte aligned");
+static_assert(sizeof(WaveLds) % 16 == 0 && sizeof(WaveLdsLow) % 16 == 0 && LDS_ROWS % 16 == 0 && LDS_ORD8 % 16 == 0, "LDS sections stay 16-byte aligned");
 
 inline uint32_t step_lds_bytes(bool queue, bool lowocc, uint32_t block_threads) {
     if (!queue) return LDS_ROWS;                              // Two-Truths N <= 4: phase rows only
-    return LDS_ROWS + (lowocc ? 0u : LDS_NTH8) + (uint32_t)(lowocc ? sizeof(WaveLdsLow) : sizeof(WaveLds)) * (block_threads / 64u);
+    return LDS_ROWS + LDS_ORD8 + (lowocc ? 0u : LDS_NTH8) + (uint32_t)(lowocc ? sizeof(WaveLdsLow) : sizeof(WaveLds)) * (block_threads / 64u);
 }
 
 extern __shared__ __align__(16) unsigned char ge_lds[];
@@ -257,8 +267,8 @@ __global__ void __launch_bounds__(256) ge_step_kernel(const StepArgs a, const Se
                                                       const DevTable *__restrict__ tables) {
     constexpr bool WWK = KIND == K_WW8 || KIND == K_WW12 || tt_uses_queue(KIND == K_TT4 ? 4 : KIND == K_TT8 ? 8 : 12, LOWOCC);   // uses the action queue
     DevRow *rows = reinterpret_cast<DevRow *>(ge_lds);
-    uint8_t *nth8 = ge_lds + LDS_ROWS;
-    auto *wl = reinterpret_cast<typename WaveLdsOf<LOWOCC>::type *>(ge_lds + LDS_ROWS + (LOWOCC ? 0u : LDS_NTH8));
+    uint8_t *nth8 = ge_lds + LDS_ROWS + LDS_ORD8;
+    auto *wl = reinterpret_cast<typename WaveLdsOf<LOWOCC>::type *>(ge_lds + LDS_ROWS + LDS_ORD8 + (LOWOCC ? 0u : LDS_NTH8));
     const uint64_t room = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     run_kind<KIND, LOWOCC>(segs, a, rows, WWK ? &wl[threadIdx.x >> 6] : nullptr, nth8, tables, room);
 }
@@ -268,8 +278,8 @@ template <bool LOWOCC>
 __global__ void __launch_bounds__(256) ge_step_kernel_mixed(const StepArgs a, const SegDev *__restrict__ segs,
                                                             const DevTable *__restrict__ tables) {
     DevRow *rows = reinterpret_cast<DevRow *>(ge_lds);
-    uint8_t *nth8 = ge_lds + LDS_ROWS;
-    auto *wl = reinterpret_cast<typename WaveLdsOf<LOWOCC>::type *>(ge_lds + LDS_ROWS + (LOWOCC ? 0u : LDS_NTH8));
+    uint8_t *nth8 = ge_lds + LDS_ROWS + LDS_ORD8;
+    auto *wl = reinterpret_cast<typename WaveLdsOf<LOWOCC>::type *>(ge_lds + LDS_ROWS + LDS_ORD8 + (LOWOCC ? 0u : LDS_NTH8));
     uint32_t si = 0;
     for (uint32_t k = 1; k < a.n_seg; k++)
         if (blockIdx.x >= a.block_begin[k]) si = k;

@@ -53,9 +53,14 @@ if (deviceCount() === 0) {
   }
   const big = new RoomBatch({ segments: [{ table, nPlayers: golden.n_players, nRooms: 10000 }], seed: 7n });
   { // the handle is not thread-safe: a synchronous call while the async step owns it throws GE_BUSY
-    const p = big.step(64);
-    try { big.summary(); out.busy = 'not refused'; } catch (e) { out.busy = e.code; }
+    const { addon } = require('./index.js');
+    const p = addon.step(big.handle, 64);                      // the raw binding: RoomBatch.step() would queue instead
+    try { addon.summary(big.handle); out.busy = 'not refused'; } catch (e) { out.busy = e.code; }
     await p;
+    // through the host class, calls queue up behind the step instead of being refused
+    const q = big.step(1);
+    out.queued = Number((await big.whenIdle(() => big.summary())).turn);
+    await q;
   }
   const s = big.summary();
   { // checkpoint (raw room views + turn) restored into a FRESH batch continues bit-identically; close() frees

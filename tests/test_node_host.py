@@ -73,7 +73,7 @@ def test_node_host_matches_golden(dsl, gold):
     r = _run(os.path.join(GOLD, "dsl", dsl), os.path.join(GOLD, gold))
     g = json.load(open(os.path.join(GOLD, gold)))
     assert r["devices"] >= 1 and r["checked"] == sum(len(c["turns"]) for c in g["cases"])
-    assert r["turn"] == 64 and r["finished"] > 0 and isinstance(r["sample"], str)
+    assert r["turn"] == 65 and r["queued"] == 65 and r["finished"] > 0 and isinstance(r["sample"], str)
     # handle safety, checkpoint restore with setTurn, close(), batched injection (ge_addon.cc / index.js)
     assert r["busy"] == "GE_BUSY" and r["restoreEqual"] is True and r["closed"] == "refused"
     assert r["injectBatch"]["same"] and r["injectBatch"]["equal"] and r["injectBatch"]["applied"] > 30
