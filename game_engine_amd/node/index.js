@@ -151,17 +151,39 @@ function actionText(act, player, c) {
   return `voted that statement ${c} is the lie`;
 }
 
+// add_game_note's categories and their marks (agent/tools/backend_tools.py:175-187; unknown type -> the EVENT mark)
+const NOTE_EMOJI = { CRITICAL: '\u{1F534}', VOTING_STATUS: '⚠️', DECISION: '\u{1F3AF}', BOT_REMINDER: '\u{1F916}', UI_FILTER: '\u{1F6AB}',
+                     PHASE_STATUS: '⏳', NEXT_PHASE: '\u{1F52E}', GAME_STATUS: '\u{1F3C6}', PHASE_SUGGESTION: '\u{1F4A1}',
+                     BRANCH_RECOMMENDATION: '\u{1F500}', EVENT: '\u{1F4DD}' };
+/** What _execute_add_game_note appends (bt:188-198). */
+function formatNote(noteType, content) {
+  const prefix = `${NOTE_EMOJI[noteType] || NOTE_EMOJI.EVENT} ${noteType}:`;
+  return content.startsWith(prefix) ? content : `${prefix} ${content}`;
+}
+
+function plurality(votes, n) {
+  let best = 0, bestC = 0;
+  for (let k = 1; k <= n; k++) {
+    const c = votes.filter((v) => v === k).length;
+    if (c > bestC) { best = k; bestC = c; }
+  }
+  return best;
+}
+
 /**
  * One stepped turn of one room as the reference's backend tool calls
  * (agent/tools/backend_tools.py:10-157), in node order: update_player_actions* ->
  * set_next_phase -> update_player_state* -> add_game_note*.  Same rendering as the Python host
  * (game_engine_amd/toolcalls.py); applying the calls to the reference's dict state reproduces
- * the GPU state.  `before`/`after`: RoomState; `event`: from RoomBatch.readEvents().
+ * the GPU state, and the notes are the fixed policy's (pinned by tests/golden/strings_*.json).
+ * `before`/`after`: RoomState; `event`: from RoomBatch.readEvents().
  */
 function turnToolCalls(table, before, after, event) {
   const calls = [];
   const ids = Object.keys(after.player_states).sort((a, b) => Number(a) - Number(b));
+  const n = ids.length;
   const from = table.info.phases.find((x) => x.id === event.from_phase_id);
+  const to = table.info.phases.find((x) => x.id === event.to_phase_id);
   ids.forEach((pid, i) => {
     if ((event.acted_now >> i) & 1) {
       const c = event.choice[i];
@@ -186,9 +208,73 @@ function turnToolCalls(table, before, after, event) {
       }
     }
   });
-  if (moved) calls.push({ name: 'add_game_note', args: { note_type: 'PHASE_STATUS', content: `[t=${event.turn}] phase ${event.from_phase_id} -> ${event.to_phase_id}` } });
-  deaths.forEach(([pid, role]) => calls.push({ name: 'add_game_note', args: { note_type: 'CRITICAL', content: `Player ${pid} (${role}) eliminated - marked is_alive=false` } }));
+  if (!moved) return calls;
+  const note = (kind, text) => calls.push({ name: 'add_game_note', args: { note_type: kind, content: text } });
+  note('PHASE_STATUS', `[t=${event.turn}] phase ${event.from_phase_id} -> ${event.to_phase_id}`);
+  const A = ids.map((pid) => after.player_states[pid]), B = ids.map((pid) => before.player_states[pid]);
+  if (to.effect === 1) {                                          // GE_EFF_ASSIGN_ROLES
+    note('NEXT_PHASE', 'Roles assigned: ' + A.map((p, i) => `Player${i + 1}=${p.role}`).join(', '));
+  } else if (to.effect === 3 || to.effect === 4) {               // NIGHT_RESOLVE / DAY_RESOLVE
+    const how = to.effect === 3 ? 'overnight by the werewolves' : 'by day vote';
+    deaths.forEach(([pid, role]) => note('CRITICAL', `Player ${pid} (${role}) eliminated ${how} - marked is_alive=false`));
+    if (to.effect === 3 && !deaths.length) {
+      const roles = table.info.roleNames;                        // class 2 = Werewolf, 3 = Doctor
+      const victim = plurality(A.filter((p, i) => B[i].is_alive && B[i].role === roles[2]).map((p) => p.selected_target_id), n);
+      let protect = 0;
+      A.forEach((p, i) => { if (B[i].is_alive && B[i].role === roles[3]) protect = p.selected_target_id; });
+      note('DECISION', `Werewolves targeted Player ${victim}, Doctor protected Player ${protect} - no elimination`);
+    }
+  } else if (to.effect === 5) {                                   // TT_ROUND_START
+    const sp = A.findIndex((p) => p.is_speaker);
+    note('DECISION', `Selected Player ${sp + 1} as next speaker (turn_order)`);
+  } else if (to.effect === 7) {                                   // TT_SCORE
+    if (B.some((p) => p.is_speaker)) note('SCORE_UPDATE', 'Total scores - ' + A.map((p, i) => `Player ${i + 1}: ${p.total_score}`).join(', '));
+  }
   return calls;
+}
+
+/**
+ * The log-shaped parts of one room's AgentState that the packed state does not carry - playerActions
+ * (bt:285-344), game_notes (bt:163-202), phase_history (v2:1207-1215), the Two-Truths `statements` texts
+ * and the players' names - kept by folding each turn's tool calls as the reference's `_execute_*` would.
+ */
+class RoomLog {
+  constructor(table, names, gameName = '') {
+    this.table = table; this.names = names.slice(); this.gameName = gameName;
+    this.playerActions = {}; this.gameNotes = []; this.phaseHistory = []; this.statements = {};
+  }
+  /** Apply one turn's calls; `after`: the RoomState after the turn. */
+  fold(calls, after, now = Date.now()) {
+    for (const c of calls) {
+      const a = c.args;
+      if (c.name === 'update_player_actions') {
+        const pid = a.player_id;
+        const rec = this.playerActions[pid] || (this.playerActions[pid] = { name: this.names[Number(pid) - 1], actions: {} });
+        const id = String(Object.values(rec.actions).reduce((m, x) => Math.max(m, Number(x.id)), 0) + 1);   // per-player sequence, bt:323-332
+        rec.name = this.names[Number(pid) - 1];
+        rec.actions[id] = { action: a.actions, timestamp: now, phase: a.phase, id };
+      } else if (c.name === 'add_game_note') {
+        this.gameNotes.push(formatNote(a.note_type, a.content));
+      } else if (c.name === 'update_player_state' && a.state_name === 'statements') {
+        this.statements[a.player_id] = Object.assign({}, a.state_value);
+      }
+    }
+    this.phaseHistory.push({ phase_id: after.current_phase_id, phase_name: after.current_phase_name, timestamp: new Date(now).toISOString() });   // every turn, v2:1207-1215
+  }
+  /** AgentState of the room (v2:97-117), player_states in the reference's key order. */
+  agentState(room) {
+    const ps = {};
+    Object.keys(room.player_states).forEach((pid, i) => {
+      const out = { name: this.names[i] };
+      for (const [k, v] of Object.entries(room.player_states[pid])) {
+        out[k] = v;
+        if (k === 'is_speaker') out.statements = Object.assign({}, this.statements[pid] || {});
+      }
+      ps[pid] = out;
+    });
+    return { gameName: this.gameName, current_phase_id: room.current_phase_id, current_phase_name: room.current_phase_name,
+             player_states: ps, playerActions: this.playerActions, phase_history: this.phaseHistory, game_notes: this.gameNotes };
+  }
 }
 
 class RoomBatch {
@@ -314,5 +400,5 @@ class ShardedBatch {
 
 const { compileCriteria, audienceGroups, uiToolCalls } = require('./ui_script.js');
 
-module.exports = { GameTable, RoomBatch, ShardedBatch, loadDslByGamename, findGameFile, initializePlayers, turnToolCalls, compileCriteria, audienceGroups, uiToolCalls,
+module.exports = { GameTable, RoomBatch, ShardedBatch, RoomLog, formatNote, loadDslByGamename, findGameFile, initializePlayers, turnToolCalls, compileCriteria, audienceGroups, uiToolCalls,
                    deviceCount: addon.deviceCount, addon };

@@ -13,7 +13,7 @@
  * LangGraphAgent (route.ts:30-39); `serve()` exposes the same over plain HTTP for a quick try.
  */
 const http = require('http');
-const { GameTable, RoomBatch, loadDslByGamename, turnToolCalls, uiToolCalls } = require('./index.js');
+const { GameTable, RoomBatch, RoomLog, loadDslByGamename, turnToolCalls, uiToolCalls } = require('./index.js');
 
 /** stable 48-bit room index from a thread id (the RNG is keyed by it) */
 function roomIndexOf(threadId) {
@@ -34,24 +34,19 @@ class RoomService {
   }
   /** roomSession.players as the lobby builds it (src/app/game-library/[game]/room/page.tsx:261-369). */
   /** players[i].isBot === false marks a human seat: the bot policy never acts for it (humanAction does). */
-  createRoom({ threadId, gameName, players, dsl }) {
+  createRoom({ threadId, gameName, players, dsl, roomIndex }) {
     const table = this.table(gameName, dsl);
     const humanMask = players.reduce((m, p, i) => (p.isBot === false ? m | (1 << i) : m), 0);
     const batch = new RoomBatch({ segments: [{ table, nPlayers: players.length, nRooms: 1, humanMask }], seed: this.seed,
-                                  firstRoom: roomIndexOf(threadId), device: this.device, maxFuse: 1, trace: true });
+                                  firstRoom: roomIndex === undefined ? roomIndexOf(threadId) : BigInt(roomIndex),   // the RNG is keyed by it
+                                  device: this.device, maxFuse: 1, trace: true });
     if (this.rooms.has(threadId)) this.close(threadId);
-    const room = { batch, table, gameName, names: players.map((p, i) => p.name || `Player ${i + 1}`),
-                   state: batch.readRoom(0), phaseHistory: [], playerActions: {}, gameNotes: [], queue: Promise.resolve() };
+    const names = players.map((p, i) => p.name || `Player ${i + 1}`);
+    const room = { batch, table, gameName, names, state: batch.readRoom(0), log: new RoomLog(table, names, gameName), queue: Promise.resolve() };
     this.rooms.set(threadId, room);
     return this.agentState(room);
   }
-  agentState(room) {
-    const s = room.state;
-    const ps = {};
-    Object.keys(s.player_states).forEach((pid, i) => { ps[pid] = { name: room.names[i], ...s.player_states[pid] }; });
-    return { gameName: room.gameName, current_phase_id: s.current_phase_id, current_phase_name: s.current_phase_name,
-             player_states: ps, playerActions: room.playerActions, phase_history: room.phaseHistory, game_notes: room.gameNotes };
-  }
+  agentState(room) { return room.log.agentState(room.state); }
   /** Requests of one thread run strictly one after the other (the reference's LangGraph server queues
    * runs per thread the same way): overlapping /continue and /action calls neither race on the batch
    * handle nor see a half-updated log. */
@@ -90,17 +85,8 @@ class RoomService {
     const event = room.batch.readEvents(0, 1)[0][0];
     const toolCalls = turnToolCalls(room.table, before, after, event);
     // fold the calls into the log-shaped parts of AgentState the packed state does not carry
-    for (const c of toolCalls) {
-      if (c.name === 'update_player_actions') {                     // backend_tools.py:285-344
-        const pid = c.args.player_id;
-        const rec = room.playerActions[pid] || (room.playerActions[pid] = { name: room.names[Number(pid) - 1], actions: {} });
-        const id = String(Object.keys(rec.actions).length + 1);
-        rec.actions[id] = { action: c.args.actions, timestamp: Date.now(), phase: c.args.phase, id };
-      } else if (c.name === 'add_game_note') {                      // backend_tools.py:163-202
-        room.gameNotes.push(`${c.args.note_type === 'CRITICAL' ? '🔴' : '⏳'} ${c.args.note_type}: ${c.args.content}`);
-      }
-    }
-    room.phaseHistory.push({ phase_id: after.current_phase_id, phase_name: after.current_phase_name });   // v2:1207-1215
+    // (playerActions / game_notes / phase_history, as backend_tools.py:163-202, 285-344 would)
+    room.log.fold(toolCalls, after);
     room.state = after;
     const state = this.agentState(room);
     return { state, toolCalls, uiCalls: uiToolCalls(room.table.dsl, after) };

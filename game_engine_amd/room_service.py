@@ -11,11 +11,10 @@ are folded from those calls exactly as the reference's `_execute_*` functions wo
 """
 from __future__ import annotations
 
-import time
 from typing import Any, Dict, List, Optional
 
 from .stepper import GameTable, RoomBatch, load_dsl_by_gamename, view_to_agent_state
-from .toolcalls import turn_tool_calls
+from .toolcalls import RoomLog, turn_tool_calls
 from .ui_script import ui_tool_calls
 
 
@@ -40,26 +39,26 @@ class RoomService:
             self._tables[game_name] = GameTable(dsl if dsl else load_dsl_by_gamename(game_name, self.games_dir))
         return self._tables[game_name]
 
-    def create_room(self, thread_id: str, game_name: str, players: List[Dict[str, Any]], dsl: Optional[dict] = None) -> Dict[str, Any]:
+    def create_room(self, thread_id: str, game_name: str, players: List[Dict[str, Any]], dsl: Optional[dict] = None,
+                    room_index: Optional[int] = None) -> Dict[str, Any]:
         """players: roomSession.players as the lobby builds it; `isBot: False` marks a human seat, which
-        the bot policy never acts for (bot_behavior_system_prompt.txt:3) — use human_action for it."""
+        the bot policy never acts for (bot_behavior_system_prompt.txt:3) — use human_action for it.
+        room_index: the global room index the RNG is keyed by (default: derived from the thread id)."""
         tb = self.table(game_name, dsl)
         human_mask = sum(1 << i for i, p in enumerate(players) if p.get("isBot") is False)
-        batch = RoomBatch([(tb, len(players), 1, human_mask)], seed=self.seed, first_room=room_index_of(thread_id),
+        batch = RoomBatch([(tb, len(players), 1, human_mask)], seed=self.seed,
+                          first_room=room_index_of(thread_id) if room_index is None else room_index,
                           device=self.device, max_fuse=1, trace=True)
-        room = {"batch": batch, "table": tb, "gameName": game_name,
-                "names": [p.get("name") or f"Player {i + 1}" for i, p in enumerate(players)],
-                "view": batch.read_rooms(0, 1)[0], "phase_history": [], "playerActions": {}, "game_notes": []}
+        if thread_id in self._rooms:
+            self.close(thread_id)
+        names = [p.get("name") or f"Player {i + 1}" for i, p in enumerate(players)]
+        room = {"batch": batch, "table": tb, "gameName": game_name, "names": names,
+                "view": batch.read_rooms(0, 1)[0], "log": RoomLog(tb, names, game_name)}
         self._rooms[thread_id] = room
         return self._agent_state(room)
 
     def _agent_state(self, room: Dict[str, Any]) -> Dict[str, Any]:
-        s = view_to_agent_state(room["table"], room["view"])
-        for i, pid in enumerate(sorted(s["player_states"], key=int)):
-            s["player_states"][pid] = {"name": room["names"][i], **s["player_states"][pid]}
-        s.update(gameName=room["gameName"], playerActions=room["playerActions"], phase_history=room["phase_history"],
-                 game_notes=room["game_notes"])
-        return s
+        return room["log"].agent_state(room["view"])
 
     def human_action(self, thread_id: str, player_id: int, choice: int) -> Dict[str, Any]:
         """A human's vote / choice (logged by process_human_action_if_needed, agent/tools/utils.py:310-358)."""
@@ -76,19 +75,9 @@ class RoomService:
         after = batch.read_rooms(0, 1)[0]
         event = batch.read_events(0, 1)[0][0]
         calls = turn_tool_calls(room["table"], before, after, event)
-        for c in calls:
-            if c["name"] == "update_player_actions":                                   # bt:285-344
-                pid = c["args"]["player_id"]
-                rec = room["playerActions"].setdefault(pid, {"name": room["names"][int(pid) - 1], "actions": {}})
-                aid = str(len(rec["actions"]) + 1)
-                rec["actions"][aid] = {"action": c["args"]["actions"], "timestamp": int(time.time() * 1000),
-                                       "phase": c["args"]["phase"], "id": aid}
-            elif c["name"] == "add_game_note":                                          # bt:163-202
-                mark = "🔴" if c["args"]["note_type"] == "CRITICAL" else "⏳"
-                room["game_notes"].append(f"{mark} {c['args']['note_type']}: {c['args']['content']}")
+        room["log"].fold(calls, after)                      # playerActions / game_notes / phase_history, as bt:163-202, 285-344 would
         room["view"] = after
         state = self._agent_state(room)
-        room["phase_history"].append({"phase_id": state["current_phase_id"], "phase_name": state["current_phase_name"]})   # v2:1207-1215
         return {"state": state, "toolCalls": calls, "uiCalls": ui_tool_calls(room["table"].dsl, state)}
 
     def close(self, thread_id: Optional[str] = None):

@@ -128,7 +128,61 @@ def human_cases():
                        "cases": cases}, f, separators=(",", ":"))
 
 
+def _strip_ts(x):
+    """Drop wall-clock fields (timestamps) - everything else of the log-shaped AgentState parts stays."""
+    if isinstance(x, dict):
+        return {k: _strip_ts(v) for k, v in x.items() if k != "timestamp"}
+    if isinstance(x, list):
+        return [_strip_ts(v) for v in x]
+    return x
+
+
+def string_cases():
+    """The STRING layer of AgentState (v2:97-117) as the reference run leaves it, turn by turn, for a few
+    rooms: playerActions (bt:285-344), game_notes (bt:163-202), phase_history (v2:1207-1215) and the full
+    player_states dicts (names, role / team strings, statements) - timestamps stripped.  What the hosts'
+    RoomService must reproduce exactly (tests/test_strings_golden.py)."""
+    for game, n, picks in (("werewolf-(mafia)", 8, [(0xC0FFEE, 0), (1, 3)]),
+                           ("werewolf-(mafia)", 12, [(0xC0FFEE, 1)]),
+                           ("two-truths-and-a-lie", 4, [(0xC0FFEE, 0), (0, 2)]),
+                           ("two-truths-and-a-lie", 6, [(1, 4)])):
+        cases = []
+        for seed, room in picks:
+            s_ = RoomSession(game, n, seed, room, "v2")
+            turns, n_notes, n_hist = [], 0, 0
+            seen_actions = {}
+            t = 0
+            while s_.end_turn < 0 or t < s_.end_turn + 3:
+                s_.step()
+                st = s_.state
+                acts = []
+                for pid in sorted(st["playerActions"], key=int):
+                    rec = st["playerActions"][pid]
+                    for aid in sorted(rec["actions"], key=int):
+                        if (pid, aid) not in seen_actions:
+                            seen_actions[(pid, aid)] = True
+                            a = rec["actions"][aid]
+                            acts.append({"player_id": pid, "name": rec["name"], "id": a["id"], "action": a["action"], "phase": a["phase"]})
+                turns.append({"current_phase_id": st["current_phase_id"], "current_phase_name": st.get("current_phase_name"),
+                              "actions_added": acts, "notes_added": list(st["game_notes"][n_notes:]),
+                              "history_added": _strip_ts(st["phase_history"][n_hist:]),
+                              "player_states": _strip_ts(st["player_states"])})
+                n_notes, n_hist = len(st["game_notes"]), len(st["phase_history"])
+                t += 1
+                assert t < 400
+            cases.append({"seed": seed, "room": room, "turns": turns,
+                          "final": {"playerActions": _strip_ts(s_.state["playerActions"]), "game_notes": s_.state["game_notes"],
+                                    "phase_history": _strip_ts(s_.state["phase_history"])}})
+            print("strings", game, n, hex(seed), room, "turns", len(turns), file=sys.stderr)
+        name = f"strings_{game.split('-(')[0].replace('-', '_')}_n{n}.json"
+        with open(os.path.join(GOLD, name), "w", encoding="utf-8") as f:
+            json.dump({"game": game, "n_players": n, "rounds": 1,
+                       "source": "reference game_agent_v2 nodes + backend_tools plumbing under FixedPolicy; timestamps stripped",
+                       "cases": cases}, f, ensure_ascii=False, separators=(",", ":"))
+
+
 if __name__ == "__main__":
     main()
     restart_cases()
     human_cases()
+    string_cases()
