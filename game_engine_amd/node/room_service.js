@@ -73,12 +73,13 @@ class RoomService {
     });
   }
   /** One turn (one graph run).  Returns { state, toolCalls, uiCalls }. */
-  continueRoom(threadId) {
+  /** items: the frontend's canvas items (AgentState.items) when the caller has them (clearCanvas exemptList). */
+  continueRoom(threadId, items) {
     const room = this.rooms.get(threadId);
     if (!room) return Promise.reject(new Error(`unknown thread ${threadId}`));
-    return this._serial(room, () => this._continue(room));
+    return this._serial(room, () => this._continue(room, items));
   }
-  async _continue(room) {
+  async _continue(room, items) {
     const before = room.state;
     await room.batch.step(1);
     const after = room.batch.readRoom(0);
@@ -89,7 +90,8 @@ class RoomService {
     room.log.fold(toolCalls, after);
     room.state = after;
     const state = this.agentState(room);
-    return { state, toolCalls, uiCalls: uiToolCalls(room.table.dsl, after) };
+    const deaths = toolCalls.filter((c) => c.name === 'update_player_state' && c.args.state_name === 'is_alive' && c.args.state_value === false).map((c) => c.args.player_id);
+    return { state, toolCalls, uiCalls: uiToolCalls(room.table.dsl, state, { table: room.table, turn: event.turn, deaths, items }) };
   }
   serve(port = 8124) {
     const server = http.createServer((req, res) => {
@@ -100,7 +102,7 @@ class RoomService {
           const msg = body ? JSON.parse(body) : {};
           let out;
           if (req.method === 'POST' && req.url === '/rooms') out = this.createRoom(msg);
-          else if (req.method === 'POST' && req.url === '/continue') out = await this.continueRoom(msg.threadId);
+          else if (req.method === 'POST' && req.url === '/continue') out = await this.continueRoom(msg.threadId, msg.items);
           else if (req.method === 'POST' && req.url === '/action') out = await this.humanAction(msg.threadId, msg.playerId, msg.choice);
           else if (req.method === 'POST' && req.url === '/close') out = { closed: await this.close(msg.threadId) };
           else { res.writeHead(404); res.end(); return; }

@@ -67,8 +67,10 @@ class RoomService:
         room["view"] = room["batch"].read_rooms(0, 1)[0]
         return self._agent_state(room)
 
-    def continue_room(self, thread_id: str) -> Dict[str, Any]:
-        """One turn (one graph run): {"state": AgentState, "toolCalls": [...], "uiCalls": [...]}."""
+    def continue_room(self, thread_id: str, items: Optional[List[Dict[str, Any]]] = None) -> Dict[str, Any]:
+        """One turn (one graph run): {"state": AgentState, "toolCalls": [...], "uiCalls": [...]}.
+        items: the frontend's canvas items (AgentState.items, [{id, type, ...}]) when the caller has them:
+        clearCanvas then names the ids to keep (exemptList)."""
         room = self._rooms[thread_id]
         batch, before = room["batch"], room["view"]
         batch.step(1)
@@ -78,7 +80,10 @@ class RoomService:
         room["log"].fold(calls, after)                      # playerActions / game_notes / phase_history, as bt:163-202, 285-344 would
         room["view"] = after
         state = self._agent_state(room)
-        return {"state": state, "toolCalls": calls, "uiCalls": ui_tool_calls(room["table"].dsl, state)}
+        deaths = [c["args"]["player_id"] for c in calls if c["name"] == "update_player_state"
+                  and c["args"]["state_name"] == "is_alive" and c["args"]["state_value"] is False]
+        ui = ui_tool_calls(room["table"].dsl, state, room["table"], turn=int(event["turn"]), deaths=deaths, items=items)
+        return {"state": state, "toolCalls": calls, "uiCalls": ui}
 
     def close(self, thread_id: Optional[str] = None):
         for tid in ([thread_id] if thread_id else list(self._rooms)):
