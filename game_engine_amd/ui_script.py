@@ -15,7 +15,7 @@ deterministically from the DSL and a room's `player_states`:
 
 Every call carries the parameters its frontend handler requires (game_engine_amd/frontend_tools.json:
 the parameter lists of page.tsx's useCopilotAction blocks, extracted by
-oracle/refharness/extract_frontend_tools.py - e.g. createVotingPanel{name, votingId, options[], position}
+tools/extract_frontend_tools.py - e.g. createVotingPanel{name, votingId, options[], position}
 page.tsx:1146-1157, markPlayerDead{playerId, playerName} :1256-1262, clearCanvas{exemptList?} :2418-2426)
 and nothing a handler does not declare.  The argument VALUES are this build's deterministic script (the
 reference leaves them to the LLM): item names from the phase, a fixed grid plan for positions, options and

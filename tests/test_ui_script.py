@@ -57,7 +57,10 @@ def test_frontend_tool_table_is_the_reference_surface():
     assert [p[0] for p in tools["clearCanvas"]] == ["exemptList"] and req("clearCanvas") == []  # page.tsx:2418-2426
     assert FRONTEND_TOOLS <= set(tools)
     if os.path.exists("/root/reference/src/app/page.tsx"):
-        from oracle.refharness import extract_frontend_tools as ex
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("extract_frontend_tools", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "extract_frontend_tools.py"))
+        ex = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(ex)
         page = open("/root/reference/src/app/page.tsx", encoding="utf-8").read()
         assert ex.extract(page) == tools
 

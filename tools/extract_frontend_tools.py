@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Extracts the frontend tool-call surface from the reference's page component into a constant table.
 
-    python -m oracle.refharness.extract_frontend_tools      (build container only: reads /root/reference)
+    python tools/extract_frontend_tools.py      (build container only: reads /root/reference)
 
 Writes game_engine_amd/frontend_tools.json: {tool: [[param, type, required], ...]} for every
 `useCopilotAction({ name, parameters: [...] })` of src/app/page.tsx (handlers :371-386, :892-2500;
@@ -14,7 +14,7 @@ import re
 import sys
 
 REF = os.environ.get("GE_REFERENCE", "/root/reference")
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "game_engine_amd", "frontend_tools.json")
 
 
