@@ -257,7 +257,7 @@ def main():
     unfused = None
     if rank == 0 and world == 1 and not args.no_unfused:
         b1 = RoomBatch(segments, seed=SEED, device=device_index, max_fuse=1, restart=True)
-        b1.step(PREROLL_TURNS, stream); b1.sync()
+        b1.step(PREROLL_TURNS, stream); b1.step(256, stream); b1.sync()     # pre-roll; the second call builds the 256-launch graph
         # wall clock first, without per-launch events (they serialise the launches; here the 256
         # launches of a step() call are replayed from a hipGraph), then the kernel time per launch
         t1 = time.perf_counter()

@@ -34,6 +34,32 @@ constexpr uint32_t GOLDEN = 0x9E3779B9u;
 #ifndef GE_ORD
 #define GE_ORD 1
 #endif
+// diagnostic build (-DGE_STAMPS=1, tools/stamps.py): s_memtime stamps at points of the werewolf turn where no LDS
+// operation is outstanding anyway, accumulated per wavefront; never in the product build
+#ifndef GE_STAMPS
+#define GE_STAMPS 0
+#endif
+// branch diet of the lone-wavefront build, A/B on MI355X at 65 536 rooms (gpurun_out/abn_branch.txt, us/turn at fuse 64):
+// none 1.442; GE_TPL_TRACE (turn loop compiled per trace setting: two always-taken wave-uniform branches less) 1.420;
+// GE_GO_BRANCHLESS (every queue slot ORs a result, zeros if it does not act) 1.468 - worse, the extra LDS atomics cost
+// more than the branch; GE_UNLIKELY (fallback role deal hinted out of line) 1.446; GE_UNROLL2 (two turns per trip) 1.439
+#ifndef GE_TPL_TRACE
+#define GE_TPL_TRACE 1
+#endif
+#ifndef GE_GO_BRANCHLESS
+#define GE_GO_BRANCHLESS 0
+#endif
+#ifndef GE_UNLIKELY
+#define GE_UNLIKELY 0
+#endif
+#ifndef GE_UNROLL2
+#define GE_UNROLL2 0
+#endif
+// role deals are prepared ahead every GE_DEAL_PERIOD-th turn (a power of two; a game is longer, and a room whose deal
+// is not ready when it needs one deals on the spot)
+#ifndef GE_DEAL_PERIOD
+#define GE_DEAL_PERIOD 16
+#endif
 
 // ---- POLICY.md §RNG: stateless 32-bit counter hash
 GE_HD uint32_t mix32(uint32_t x) {
@@ -210,6 +236,12 @@ __device__ __forceinline__ void wave_excl_scan(uint32_t cnt, uint32_t &off, uint
     }
 }
 
+struct Stamps {
+    unsigned long long last, acc[4];
+    __device__ __forceinline__ void start() { last = __builtin_amdgcn_s_memtime(); acc[0] = acc[1] = acc[2] = acc[3] = 0; }
+    __device__ __forceinline__ void mark(int k) { const unsigned long long now = __builtin_amdgcn_s_memtime(); acc[k] += now - last; last = now; }
+};
+
 // candidate choice of one bot action (POLICY.md §3); shared by the per-lane loop and the queue
 template <int NB, bool TABLE>
 __device__ __forceinline__ uint32_t ww_choose(uint32_t act, uint32_t i, uint32_t d, uint32_t alive, uint32_t team_w,
@@ -264,11 +296,13 @@ __device__ __forceinline__ void deal_roles(Deal &d, uint32_t dk, uint32_t game, 
 template <int NB, bool QUEUE, bool LOWOCC>
 __device__ __forceinline__ void ww_turn(WWR<NB> &s, DevRow &row, const DevRow *rows, void *wave_lds, const uint8_t *nth8, const uint32_t *ord8, bool valid, uint32_t n,
                                         uint32_t nw, uint32_t phase0_idx, uint32_t rkey, uint32_t turn, uint32_t &tk_io,
-                                        bool trace, uint32_t human, Deal &deal, uint32_t &ev_newly, uint64_t &ev_choice) {
+                                        bool trace, uint32_t human, Deal &deal, bool deal_now, uint32_t &ev_newly, uint64_t &ev_choice, Stamps *stamps = nullptr) {
     // human: players the host drives (never acted for here)
     // ev_*: this turn's logged actions (who acted, what they chose) for the optional event trace
     // `row` is the table row of s.phase, kept in registers across turns: LDS is read only on a transition
     // tk_io: in = turn_key(rkey, turn), out = the next turn's key
+    // deal_now (wave-uniform, every GE_DEAL_PERIOD-th turn of a long launch): lanes without a prepared role deal
+    // compute their next one - in the shadow of the queue's result round trip
     using nib_t = typename WWR<NB>::nib_t;
     using R = WWR<NB>;
     constexpr bool ORD = GE_ORD && NB <= 8;                    // queue slots find their player through the ord8 table
@@ -310,6 +344,7 @@ __device__ __forceinline__ void ww_turn(WWR<NB> &s, DevRow &row, const DevRow *r
         }
         T = X & alive & (comp == COMP_ACTION ? ALL : 0u);
     }
+    if (GE_STAMPS && stamps) { asm volatile("" :: "v"(T)); stamps->mark(0); }        // [end of previous turn .. row in registers]
 
     // ---- PhaseNode, the part that does not depend on this turn's actions (nobody dies before the Referee):
     // phase-0 guard, resolver bitset, first matching branch.  With the action queue it runs in the shadow
@@ -333,6 +368,12 @@ __device__ __forceinline__ void ww_turn(WWR<NB> &s, DevRow &row, const DevRow *r
     // the role-assignment values of the prepared deal (what `assign` writes), also shadow work
     R dealt;
     auto deal_precompute = [&]() {
+        if (deal_now && !deal.valid) {
+            // this game already has roles: prepare the next game's
+            const bool has_roles = (NB <= 8 ? s.W[2] : (s.W[R::NW - 2] | s.W[R::NW - 1])) != 0u;
+            const uint32_t g = has_roles ? (s.games < 0xFFFFu ? s.games + 1u : s.games) : s.games;
+            deal_roles<NB, LOWOCC>(deal, deal_key(rkey, g), g, n, nw, nth8);
+        }
 #pragma unroll
         for (int k = 0; k < R::NW; k++) dealt.W[k] = 0;
         const uint32_t special = ALL & ~deal.rem;
@@ -431,6 +472,7 @@ __device__ __forceinline__ void ww_turn(WWR<NB> &s, DevRow &row, const DevRow *r
                 // round's read is issued, so nothing of the queue is in flight behind it
                 for (uint32_t base = 0;; base += 64u) {
                     const uint32_t k = base + lane;
+                    if (GE_STAMPS && stamps && base == 0u) { asm volatile("" :: "v"(c4.x)); stamps->mark(1); }   // [.. first slot in registers]
                     uint32_t L, i, know, lokw;
                     if (ORD) {
                         L = c4.y >> 26;
@@ -450,7 +492,12 @@ __device__ __forceinline__ void ww_turn(WWR<NB> &s, DevRow &row, const DevRow *r
                         // conditional block would split the slot read in two dependent LDS round trips
                         const uint32_t c = ww_choose<NB, false>(c4.x >> 28, i, d, c4.x & 0xFFFFu, (c4.x >> 16) & 0xFFFu,
                                                                 know, lokw, know, nth8);
-                        if (go) {
+                        if (GE_GO_BRANCHLESS) {
+                            // every slot ORs into its room's result (L is a lane index even for a stale slot), zeros if it does not act
+                            uint32_t *r = reinterpret_cast<uint32_t *>(&lw->res[L]);
+                            atomicOr(r, go ? (1u << i) : 0u);
+                            atomicOr(r + 1 + (i >> 3), go ? (c << (4u * (i & 7u))) : 0u);
+                        } else if (go) {
                             uint32_t *r = reinterpret_cast<uint32_t *>(&lw->res[L]);
                             atomicOr(r, 1u << i);
                             atomicOr(r + 1 + (i >> 3), c << (4u * (i & 7u)));
@@ -479,6 +526,7 @@ __device__ __forceinline__ void ww_turn(WWR<NB> &s, DevRow &row, const DevRow *r
                     asm volatile("" :: "v"(c4.x), "v"(c4.y), "v"(c4.z), "v"(c4.w));
                 }
                 newly = r.x;
+                if (GE_STAMPS && stamps) { asm volatile("" :: "v"(newly)); stamps->mark(2); }                 // [.. results in registers]
                 const nib_t got = NB > 8 ? (nib_t)(((uint64_t)r.z << 32) | r.y) : (nib_t)r.y;
                 const nib_t m15 = nib_nonzero(got);              // c >= 1, so a nibble is set iff that player acted
                 s.choice = (s.choice & ~m15) | got;
@@ -541,7 +589,7 @@ __device__ __forceinline__ void ww_turn(WWR<NB> &s, DevRow &row, const DevRow *r
     // role assignment: the deal of this game was normally prepared ahead (run loop, every 8th turn, for
     // all lanes of the wavefront at once); fall back to dealing here if it was not
     const bool is_assign = eff == EFF_ASSIGN_ROLES;
-    if (is_assign && !(deal.valid && deal.game == s.games)) {
+    if (GE_UNLIKELY ? __builtin_expect(is_assign && !(deal.valid && deal.game == s.games), 0) : (is_assign && !(deal.valid && deal.game == s.games))) {
         deal_roles<NB, LOWOCC>(deal, deal_key(rkey, s.games), s.games, n, nw, nth8);
         deal_precompute();
     }

@@ -6,10 +6,12 @@
 // ge_layout.h for the HBM layout, ge_device.h for the turn itself.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
 #include <new>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/ge_step.h"
@@ -48,6 +50,7 @@ struct SegDev {
 
 struct StepArgs {
     const uint32_t *turn_dev;  // launches replayed from a hipGraph: turn0 is relative to this device word (else null)
+    unsigned long long *stamps; // GE_STAMPS diagnostic build: 4 segment sums + wave-turn count (else null)
     uint32_t n_seg, turn0, n_turns, seed_key, block_threads, restart, trace, lowocc;
     uint32_t block_begin[GE_MAX_SEGMENTS];
 };
@@ -147,31 +150,48 @@ __device__ __forceinline__ void run_ww(const SegDev *__restrict__ sgp, const Ste
     // Role deals are keyed by (room, game index), so they can be prepared before the turn that applies
     // them.  Entering the role-assignment phase is rare per room (once a game) but in a wavefront of 64
     // rooms some room does it on ~80 % of the turns; instead of running the deal for that one lane, every
-    // 8th turn all lanes without a prepared deal get their next one together (a game is longer than 8 turns).
+    // GE_DEAL_PERIOD-th turn all lanes without a prepared deal get their next one together (ww_turn, in an
+    // LDS wait shadow; a game is longer than the period).
     Deal deal = {0u, 0u, 0u, 0u, 0u, 0u};
     const bool ahead = a.n_turns >= 16u;                      // not worth it for short launches
     uint32_t tk = turn_key(rk, turn0);                        // this turn's key; ww_turn leaves the next turn's (computed in an LDS wait shadow)
-    for (uint32_t t = 0; t < a.n_turns; t++) {
-        if (ahead && (t & 7u) == 0u && !deal.valid) {
-            // this game already has roles: prepare the next game's
-            const bool dealt = (NB <= 8 ? s.W[2] : (s.W[WWR<NB>::NW - 2] | s.W[WWR<NB>::NW - 1])) != 0u;
-            const uint32_t g = dealt ? (s.games < 0xFFFFu ? s.games + 1u : s.games) : s.games;
-            deal_roles<NB, LOWOCC>(deal, deal_key(rk, g), g, sg.n_players, sg.nw, nth8);
+    Stamps stamps;
+    if (GE_STAMPS) stamps.start();
+    // the turn loop, compiled once per trace setting: the event-trace branches (two per turn, both wave-uniform and
+    // almost always taken) cost a lone wavefront an instruction-fetch bubble each
+    auto turns = [&](auto trace_c) {
+        constexpr bool KNOWN = decltype(trace_c)::value != 2;
+        const bool trace = KNOWN ? decltype(trace_c)::value == 1 : a.trace != 0u;
+#if GE_UNROLL2
+#pragma unroll 2
+#endif
+        for (uint32_t t = 0; t < a.n_turns; t++) {
+            uint32_t restarted = 0;
+            if (a.restart && ((row.r0 >> 11) & 7u) == 0u) {      // recycle a finished room
+                const uint32_t g = s.games;
+                s = s0;
+                s.games = g < 0xFFFFu ? g + 1u : g;
+                row = row0;
+                restarted = 1;
+            }
+            const uint32_t p = s.phase;
+            uint32_t ev_newly = 0;
+            uint64_t ev_choice = 0;
+            ww_turn<NB, GE_WAVE_QUEUE, LOWOCC>(s, row, rows, lw, nth8, ord8, valid, sg.n_players, sg.nw, sg.phase0_idx, rk, turn0 + t, tk,
+                                       trace, sg.human_mask, deal, ahead && (t & (GE_DEAL_PERIOD - 1u)) == 0u, ev_newly, ev_choice,
+                                       (GE_STAMPS && a.stamps) ? &stamps : nullptr);
+            if (trace && valid) store_event(sg.trace, sg.rooms_padded, t, room, turn0 + t, p, s.phase, restarted, ev_newly, ev_choice);
         }
-        uint32_t restarted = 0;
-        if (a.restart && ((row.r0 >> 11) & 7u) == 0u) {      // recycle a finished room
-            const uint32_t g = s.games;
-            s = s0;
-            s.games = g < 0xFFFFu ? g + 1u : g;
-            row = row0;
-            restarted = 1;
-        }
-        const uint32_t p = s.phase;
-        uint32_t ev_newly = 0;
-        uint64_t ev_choice = 0;
-        ww_turn<NB, GE_WAVE_QUEUE, LOWOCC>(s, row, rows, lw, nth8, ord8, valid, sg.n_players, sg.nw, sg.phase0_idx, rk, turn0 + t, tk,
-                                   a.trace != 0u, sg.human_mask, deal, ev_newly, ev_choice);
-        if (a.trace && valid) store_event(sg.trace, sg.rooms_padded, t, room, turn0 + t, p, s.phase, restarted, ev_newly, ev_choice);
+    };
+    if (GE_TPL_TRACE && LOWOCC) {                             // (two copies of the loop cost the large-batch build registers)
+        if (a.trace) turns(std::integral_constant<int, 1>{}); else turns(std::integral_constant<int, 0>{});
+    } else {
+        turns(std::integral_constant<int, 2>{});
+    }
+    if (GE_STAMPS && a.stamps && (threadIdx.x & 63u) == 0u) {
+        stamps.mark(3);
+        for (int k = 0; k < 4; k++) atomicAdd(a.stamps + k, stamps.acc[k]);
+        atomicAdd(a.stamps + 4, (unsigned long long)a.n_turns);
     }
     if (!valid) return;
     WW<NB> u;
@@ -735,6 +755,7 @@ struct ge_batch {
     hipStream_t last_stream = nullptr;
     bool pending = false;             // work was queued on last_stream since the last synchronisation
     hipEvent_t order_ev = nullptr;    // orders a step on a new stream behind the previous stream's work
+    unsigned long long *stamps_dev = nullptr;   // GE_STAMPS diagnostic build only
     void *inj_buf = nullptr;          // device scratch of ge_batch_inject_actions
     size_t inj_cap = 0;
     // hipGraph replay of launch-bound step sequences (many short launches per ge_batch_step call)
@@ -767,6 +788,7 @@ static int fill_args(const ge_batch *b, StepArgs &a, uint32_t turn0, uint32_t n_
         return e ? strtoull(e, nullptr, 10) : (uint64_t)(1024u * 64u * 3u / 2u);
     }();
     a.lowocc = b->n_rooms < low_rooms ? 1u : 0u;
+    a.stamps = b->stamps_dev;
     return GE_OK;
 }
 
@@ -934,6 +956,12 @@ static int create_impl(const ge_batch_desc *desc, ge_batch **out) {
         } while (0);
     }
     if (st != GE_OK) { ge_batch_destroy(b); return st; }
+#if GE_STAMPS
+    if (getenv("GE_STAMPS_OUT")) {
+        DeviceGuard dg(b->device);
+        if (hipMalloc(reinterpret_cast<void **>(&b->stamps_dev), 64) == hipSuccess) (void)hipMemset(b->stamps_dev, 0, 64);
+    }
+#endif
     st = ge_batch_reset(b);
     if (st != GE_OK) { ge_batch_destroy(b); return st; }
     *out = b;
@@ -1348,6 +1376,18 @@ void ge_batch_destroy(ge_batch *b) {
     {
         DeviceGuard dg(b->device);
         (void)hipStreamSynchronize(b->last_stream);               // nothing of this batch may still be running
+#if GE_STAMPS
+        if (b->stamps_dev) {
+            unsigned long long h[8] = {0};
+            (void)hipMemcpy(h, b->stamps_dev, 64, hipMemcpyDeviceToHost);
+            if (FILE *f = fopen(getenv("GE_STAMPS_OUT"), "a")) {
+                fprintf(f, "{\"rooms\": %llu, \"wave_turns\": %llu, \"seg\": [%llu, %llu, %llu, %llu]}\n",
+                        (unsigned long long)b->n_rooms, h[4], h[0], h[1], h[2], h[3]);
+                fclose(f);
+            }
+            (void)hipFree(b->stamps_dev);
+        }
+#endif
         for (auto &ev : b->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
         if (b->order_ev) (void)hipEventDestroy(b->order_ev);
         for (auto &g : b->graphs) (void)hipGraphExecDestroy(g.second);

@@ -84,8 +84,14 @@ TEAM_NONE, TEAM_VILLAGERS, TEAM_WEREWOLVES = 0, 1, 2
 TEAM_NAMES = {TEAM_NONE: "", TEAM_VILLAGERS: "villagers", TEAM_WEREWOLVES: "werewolves"}
 
 MAX_TERMS = 4
+MAX_CLAUSES = 4
 MAX_BRANCHES = 4
 MAX_PHASES = 32
+
+# numeric player fields a condition may compare (index = ge_step.h GE_NUM_*; value = largest the record holds)
+WW_NUM = {"selected_target_id": (0, 15)}
+TT_NUM = {"lie_index": (1, 3), "vote_choice": (2, 3), "total_score": (3, 255), "rounds_as_speaker": (4, 15)}
+WAIT_FOR = ("single_player_choice", "all_players_action", "multiple_players_action")
 
 
 class DslError(ValueError):
@@ -98,6 +104,20 @@ class Term:
     value: Any            # True / "str" / number
     negate: bool
     base: int = -1        # base-mask index in the pack (filled by compile)
+
+
+@dataclass
+class Literal:
+    """One literal of the clause form of a condition (dsl_phases_generation_prompt.txt:120-132 grammar):
+    base: the player has ANY of the base predicates `bases` (== / != / in [...] over booleans and enums);
+    num:  lo <= player.<field> <= hi (==, !=, <, <=, >, >=, in [...] over a declared `num` field)."""
+    kind: str             # "base" | "num"
+    negate: bool
+    bases: Tuple[int, ...] = ()
+    field: str = ""
+    num: int = 0          # numeric field index (WW_NUM / TT_NUM)
+    lo: int = 0
+    hi: int = 0
 
 
 @dataclass
@@ -114,7 +134,9 @@ class Phase:
     idx: int
     name: str
     completion: int
-    terms: List[Term] = field(default_factory=list)
+    terms: List[Term] = field(default_factory=list)      # the plain conjunction, when the condition is one
+    clauses: List[List[Literal]] = field(default_factory=list)   # always: OR of AND-clauses
+    generic: bool = False                                # True: only the clause form describes the condition
     act: int = ACT_NONE
     effect: int = EFF_NONE
     branches: List[Branch] = field(default_factory=list)
@@ -145,10 +167,8 @@ _TERM_RE = re.compile(
 
 
 def parse_condition(cond: Optional[str]) -> List[Term]:
-    """`player.f == v and player.g == w` -> terms (ww:247,279,310,390; tt phases 2,3,5).
-
-    Only the conjunctive form the shipped phases use is accepted for phase targets;
-    anything else is a DslError rather than a guess."""
+    """`player.f == v and player.g == w` -> terms (ww:247,279,310,390; tt phases 2,3,5): the plain
+    conjunctive form.  Raises DslError for anything else (parse_clauses reads the full grammar)."""
     if not cond:
         return []
     terms: List[Term] = []
@@ -169,6 +189,112 @@ def parse_condition(cond: Optional[str]) -> List[Term]:
     if len(terms) > MAX_TERMS:
         raise DslError("too many condition terms")
     return terms
+
+
+_GTERM_RE = re.compile(r"^\s*player\.(\w+)\s*(==|!=|<=|>=|<|>|not\s+in|in)\s*(.+?)\s*$", re.I | re.S)
+
+
+def _atom(text: str):
+    t = text.strip()
+    if t.lower() in ("true", "false"):
+        return t.lower() == "true"
+    if len(t) >= 2 and t[0] == t[-1] and t[0] in "'\"":
+        return t[1:-1]
+    if re.fullmatch(r"-?\d+", t):
+        return int(t)
+    raise DslError(f"unsupported literal: {text!r}")
+
+
+def parse_clauses(pack: int, cond: Optional[str]) -> List[List[Literal]]:
+    """The condition grammar the DSL generator is told to use (dsl_phases_generation_prompt.txt:120-132):
+    terms `player.<field> <op> <value>` with == != < <= > >= `in [...]` `not in [...]`, joined by `and`,
+    alternatives joined by `or` (`and` binds tighter; no parentheses).  Result: OR of AND-clauses of
+    Literals.  Anything outside the grammar or the rule pack is a DslError, never a guess."""
+    if not cond or not cond.strip():
+        return []
+    base = WW_BASE if pack == PACK_WEREWOLF else TT_BASE
+    nums = WW_NUM if pack == PACK_WEREWOLF else TT_NUM
+    flat = " ".join(cond.split())
+    if "(" in flat.replace("[", "").replace("]", "") and re.search(r"\((?![^\[]*\])", flat):
+        raise DslError(f"unsupported condition (parentheses): {cond!r}")
+    clauses: List[List[Literal]] = []
+    for alt in re.split(r"\s+or\s+", flat, flags=re.I):
+        # one alternative = AND of terms; a term may itself be a small OR (numeric `in` over a non-contiguous
+        # list), which is distributed into several clauses
+        partial: List[List[Literal]] = [[]]
+        for part in re.split(r"\s+and\s+", alt, flags=re.I):
+            m = _GTERM_RE.match(part)
+            if not m:
+                raise DslError(f"unsupported condition term: {part!r}")
+            fld, op, rhs = m.group(1), " ".join(m.group(2).lower().split()), m.group(3)
+            if op in ("in", "not in"):
+                inner = rhs.strip()
+                if not (inner.startswith("[") and inner.endswith("]")):
+                    raise DslError(f"unsupported list literal: {rhs!r}")
+                vals = [_atom(x) for x in inner[1:-1].split(",") if x.strip()]
+                if not vals:
+                    raise DslError(f"empty list in: {part!r}")
+            else:
+                vals = [_atom(rhs)]
+            neg = op in ("!=", "not in")
+            options: List[Literal]
+            if fld in nums and all(isinstance(v, int) and not isinstance(v, bool) for v in vals):
+                idx, top = nums[fld]
+                if op in ("==", "!=", "in", "not in"):
+                    ks = sorted({v for v in vals})
+                    runs: List[List[int]] = []
+                    for k in ks:                                # contiguous runs of the value list
+                        if runs and k == runs[-1][1] + 1:
+                            runs[-1][1] = k
+                        else:
+                            runs.append([k, k])
+                    if neg and len(runs) > 1:
+                        raise DslError(f"unsupported: 'not in' over a non-contiguous list: {part!r}")
+                    options = [Literal("num", neg, field=fld, num=idx, lo=lo, hi=hi) for lo, hi in runs]
+                else:
+                    k = vals[0]
+                    lo, hi = {"<": (0, k - 1), "<=": (0, k), ">": (k + 1, top), ">=": (k, top)}[op]
+                    options = [Literal("num", False, field=fld, num=idx, lo=lo, hi=hi)]
+                for o in options:                                  # clip to what the record can hold; lo > hi = never
+                    o.lo, o.hi = max(o.lo, 0), min(o.hi, top)
+                    if o.lo > o.hi:
+                        o.lo, o.hi = 1, 0
+            else:
+                if op not in ("==", "!=", "in", "not in"):
+                    raise DslError(f"unsupported comparison on a non-numeric field: {part!r}")
+                bases, flips = [], set()
+                for v in vals:
+                    if isinstance(v, bool) or (isinstance(v, int) and v in (0, 1) and (fld, True) in base):
+                        key, flip = (fld, True), (not bool(v))
+                    elif isinstance(v, str) and fld == "role" and pack == PACK_WEREWOLF:
+                        key, flip = ("role", _role_class(v)), False
+                    elif isinstance(v, str):
+                        key, flip = (fld, v), False
+                    else:
+                        raise DslError(f"unsupported value in: {part!r}")
+                    if key not in base:
+                        raise DslError(f"condition field {fld!r} not in rule pack: {part!r}")
+                    bases.append(base[key])
+                    flips.add(flip)
+                if len(flips) > 1:
+                    raise DslError(f"unsupported: a boolean list with both values: {part!r}")
+                options = [Literal("base", neg != flips.pop(), bases=tuple(sorted(set(bases))), field=fld)]
+            partial = [c + [o] for c in partial for o in options]
+            if len(partial) > MAX_CLAUSES:
+                raise DslError("too many condition alternatives")
+        clauses += partial
+    if len(clauses) > MAX_CLAUSES:
+        raise DslError("too many condition alternatives")
+    if any(len(c) > MAX_TERMS for c in clauses):
+        raise DslError("too many condition terms")
+    return clauses
+
+
+def plain_terms(clauses: List[List[Literal]]) -> Optional[List[Tuple[int, bool]]]:
+    """[(base, negate)] when the clause form is one conjunction of single base predicates, else None."""
+    if len(clauses) != 1 or any(l.kind != "base" or len(l.bases) != 1 for l in clauses[0]):
+        return None
+    return [(l.bases[0], l.negate) for l in clauses[0]]
 
 
 def _role_class(name: str) -> int:
@@ -249,18 +375,17 @@ def compile_dsl(dsl: dict, rounds: int = 1) -> Table:
         p = Phase(id=pid, idx=i, name=ph.get("name", f"Phase {pid}"), completion=comp, tools=tools)
         text = (p.name + " " + (ph.get("description") or "")).lower()
         if comp == COMP_ACTION:
-            p.terms = parse_condition(((cc.get("target_players") or {}).get("condition")))
-            for t in p.terms:
-                key = None
-                if t.field == "role" and pack == PACK_WEREWOLF:
-                    key = ("role", _role_class(str(t.value)))
-                elif isinstance(t.value, str):
-                    key = (t.field, t.value)
-                else:
-                    key = (t.field, True)
-                if key not in base:
-                    raise DslError(f"phase {pid}: condition field {t.field!r} not in rule pack")
-                t.base = base[key]
+            wf = cc.get("wait_for")
+            if wf is not None and wf not in WAIT_FOR:
+                raise DslError(f"phase {pid}: unknown wait_for {wf!r}")
+            try:
+                p.clauses = parse_clauses(pack, (cc.get("target_players") or {}).get("condition"))
+            except DslError as e:
+                raise DslError(f"phase {pid}: {e}") from None
+            plain = plain_terms(p.clauses) if p.clauses else []
+            p.generic = plain is None
+            if plain is not None:
+                p.terms = [Term(l.field, True, l.negate, base=l.bases[0]) for l in (p.clauses[0] if p.clauses else [])]
             p.act = _classify_action(pack, p, text)
         p.effect = _classify_effect(pack, p, text)
         nxt = ph.get("next_phase")
@@ -288,7 +413,16 @@ def compile_dsl(dsl: dict, rounds: int = 1) -> Table:
 
 
 def _classify_action(pack: int, p: Phase, text: str) -> int:
-    bases = {(t.base, t.negate) for t in p.terms}
+    """The action kind of a player_action phase, from its condition: every alternative (clause) is
+    classified on its own and all must agree."""
+    kinds = {_classify_clause(pack, p, c) for c in (p.clauses or [[]])}
+    if len(kinds) != 1:
+        raise DslError(f"phase {p.id}: the condition's alternatives describe different player actions")
+    return kinds.pop()
+
+
+def _classify_clause(pack: int, p: Phase, clause: List[Literal]) -> int:
+    bases = {(l.bases[0], l.negate) for l in clause if l.kind == "base" and len(l.bases) == 1}
     if pack == PACK_WEREWOLF:
         if (WW_BASE[("role", ROLE_WEREWOLF)], False) in bases:
             return ACT_WOLF_TARGET
@@ -305,7 +439,7 @@ def _classify_action(pack: int, p: Phase, text: str) -> int:
             if "createTextInputPanel" in p.tools or "statement" in p.name.lower():
                 return ACT_TT_STATEMENTS
             return ACT_TT_LIE
-    raise DslError(f"phase {p.id}: cannot classify player action {[(t.field, t.value) for t in p.terms]}")
+    raise DslError(f"phase {p.id}: cannot classify player action {[(l.field, l.bases, l.lo, l.hi) for l in clause]}")
 
 
 def _classify_effect(pack: int, p: Phase, text: str) -> int:
