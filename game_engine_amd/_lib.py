@@ -12,11 +12,18 @@ GE_MAX_PHASES, GE_MAX_SEGMENTS, GE_NAME_LEN = 32, 4, 64
 GE_ABI_VERSION = 2
 
 
+class Literal(C.Structure):
+    _fields_ = [("kind", C.c_uint8), ("neg", C.c_uint8), ("num_field", C.c_uint8), ("pad", C.c_uint8),
+                ("bases", C.c_uint16), ("lo", C.c_uint8), ("hi", C.c_uint8)]
+
+
 class PhaseRow(C.Structure):
     _fields_ = [("phase_id", C.c_int32), ("completion", C.c_uint8), ("act", C.c_uint8),
                 ("effect", C.c_uint8), ("n_terms", C.c_uint8), ("term_base", C.c_uint8 * 4),
                 ("term_neg", C.c_uint8 * 4), ("n_branches", C.c_uint8), ("br_res", C.c_uint8 * 4),
-                ("br_target", C.c_uint8 * 4), ("pad", C.c_uint8 * 3), ("name", C.c_char * GE_NAME_LEN)]
+                ("br_target", C.c_uint8 * 4), ("pad", C.c_uint8 * 3), ("name", C.c_char * GE_NAME_LEN),
+                ("generic", C.c_uint8), ("n_clauses", C.c_uint8), ("clause_len", C.c_uint8 * 4), ("pad2", C.c_uint8 * 2),
+                ("clause", (Literal * 4) * 4)]
 
 
 class Table(C.Structure):

@@ -289,12 +289,84 @@ __device__ __forceinline__ void deal_roles(Deal &d, uint32_t dk, uint32_t game, 
     d.wolves = wolves; d.doc = doc; d.det = det; d.rem = rem; d.game = game; d.valid = 1u;
 }
 
+// ------------------------------------------------------------------ generic target conditions
+// The slow path of `target_players.condition`: an OR of AND-clauses of literals (ge_layout.h DevCond), for DSLs that use
+// the rest of the grammar (or, in [..], numeric comparisons).  Only the GENERIC kernel builds contain it, and only
+// the lanes whose current row is flagged ROW_GENERIC run it; the shipped games never do.
+template <int NB> __device__ __forceinline__ uint32_t ww_base_mask(const WWR<NB> &s, uint32_t set) {
+    uint32_t m = 0;
+    m |= (set >> F_ALIVE) & 1u ? s.template get<F_ALIVE>() : 0u;       m |= (set >> F_CAN_VOTE) & 1u ? s.template get<F_CAN_VOTE>() : 0u;
+    m |= (set >> F_REVEALED) & 1u ? s.template get<F_REVEALED>() : 0u; m |= (set >> F_SECRET) & 1u ? s.template get<F_SECRET>() : 0u;
+    m |= (set >> F_ELIG) & 1u ? s.template get<F_ELIG>() : 0u;         m |= (set >> F_SUB) & 1u ? s.template get<F_SUB>() : 0u;
+    m |= (set >> F_TEAM_V) & 1u ? s.template get<F_TEAM_V>() : 0u;     m |= (set >> F_TEAM_W) & 1u ? s.template get<F_TEAM_W>() : 0u;
+    m |= (set >> F_VIL) & 1u ? s.template get<F_VIL>() : 0u;           m |= (set >> F_WOLF) & 1u ? s.template get<F_WOLF>() : 0u;
+    m |= (set >> F_DOC) & 1u ? s.template get<F_DOC>() : 0u;           m |= (set >> F_DET) & 1u ? s.template get<F_DET>() : 0u;
+    return m;
+}
+
+// players whose small-integer field (FB bits per player in `arr`) lies in [lo, hi]
+template <int NB, int FB, typename arr_t> __device__ __forceinline__ uint32_t range_mask(arr_t arr, uint32_t lo, uint32_t hi) {
+    uint32_t m = 0;
+#pragma unroll
+    for (int i = 0; i < NB; i++) {
+        const uint32_t v = (uint32_t)(arr >> (FB * i)) & ((1u << FB) - 1u);
+        m |= (v >= lo && v <= hi ? 1u : 0u) << i;
+    }
+    return m;
+}
+
+template <typename LITMASK> __device__ __forceinline__ uint32_t eval_clauses(const DevCond &c, uint32_t all, LITMASK lit_mask) {
+    const uint32_t ncl = c.meta & 7u;
+    uint32_t T = ncl ? 0u : all;                              // no condition: everybody
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t len = (c.meta >> (4 + 4 * k)) & 7u;
+        uint32_t m = all;
+#pragma unroll
+        for (int l = 0; l < 4; l++) {
+            const uint32_t w = c.lit[k][l];
+            const uint32_t x = lit_mask(w) ^ ((w >> 30) & 1u ? all : 0u);
+            m &= (uint32_t)l < len ? x : all;
+        }
+        T |= (uint32_t)k < ncl ? m : 0u;
+    }
+    return T & all;
+}
+
+template <int NB> __device__ __forceinline__ uint32_t ww_cond_generic(const WWR<NB> &s, const DevCond &c, uint32_t all) {
+    return eval_clauses(c, all, [&](uint32_t w) -> uint32_t {
+        if (((w >> 28) & 3u) == 1u) return ww_base_mask<NB>(s, w & 0xFFFFu);
+        return range_mask<NB, 4>(s.sel, w & 0xFFu, (w >> 8) & 0xFFu);        // GE_NUM_SELECTED_TARGET is the pack's only numeric field
+    });
+}
+
+template <int NB> __device__ __forceinline__ uint32_t tt_cond_generic(const TT<NB> &s, const DevCond &c, uint32_t all) {
+    return eval_clauses(c, all, [&](uint32_t w) -> uint32_t {
+        if (((w >> 28) & 3u) == 1u) {
+            const uint32_t set = w & 0xFFFFu;
+            return ((set & 1u) ? s.speaker : 0u) | ((set & 2u) ? s.submitted : 0u) | ((set & 4u) ? s.revealed : 0u) |
+                   ((set & 8u) ? s.can_vote : 0u) | ((set & 16u) ? s.has_voted : 0u);
+        }
+        const uint32_t lo = w & 0xFFu, hi = (w >> 8) & 0xFFu, f = (w >> 16) & 7u;
+        if (f == 1u) return range_mask<NB, 2>(s.lie, lo, hi);                   // GE_NUM_LIE_INDEX
+        if (f == 2u) return range_mask<NB, 2>(s.vote, lo, hi);                  // GE_NUM_VOTE_CHOICE
+        if (f == 4u) return range_mask<NB, 4>(s.rounds, lo, hi);                // GE_NUM_ROUNDS_AS_SPEAKER
+        uint32_t m = 0;                                                         // GE_NUM_TOTAL_SCORE: a byte per player
+#pragma unroll
+        for (int i = 0; i < NB; i++) {
+            const uint32_t v = (s.score[i / 4] >> (8 * (i % 4))) & 255u;
+            m |= (v >= lo && v <= hi ? 1u : 0u) << i;
+        }
+        return m;
+    });
+}
+
 // ------------------------------------------------------------------ werewolf
 // LOWOCC: the launch has fewer than ~3 wavefronts per SIMD (e.g. 65 536 rooms): a lone wavefront
 // stalls on every branch instruction and every dependent LDS access, so that build is branch-lean
 // and computes; the other build (many wavefronts, VALU-bound) prefers LDS tables and skip-branches.
-template <int NB, bool QUEUE, bool LOWOCC>
-__device__ __forceinline__ void ww_turn(WWR<NB> &s, DevRow &row, const DevRow *rows, void *wave_lds, const uint8_t *nth8, const uint32_t *ord8, bool valid, uint32_t n,
+template <int NB, bool QUEUE, bool LOWOCC, bool GENERIC = false>
+__device__ __forceinline__ void ww_turn(WWR<NB> &s, DevRow &row, const DevRow *rows, const DevCond *conds, void *wave_lds, const uint8_t *nth8, const uint32_t *ord8, bool valid, uint32_t n,
                                         uint32_t nw, uint32_t phase0_idx, uint32_t rkey, uint32_t turn, uint32_t &tk_io,
                                         bool trace, uint32_t human, Deal &deal, bool deal_now, uint32_t &ev_newly, uint64_t &ev_choice, Stamps *stamps = nullptr) {
     // human: players the host drives (never acted for here)
@@ -344,6 +416,8 @@ __device__ __forceinline__ void ww_turn(WWR<NB> &s, DevRow &row, const DevRow *r
         }
         T = X & alive & (comp == COMP_ACTION ? ALL : 0u);
     }
+    if (GENERIC && (row.r0 & ROW_GENERIC) && comp == COMP_ACTION)        // or / in [..] / numeric comparisons: the clause form
+        T = ww_cond_generic<NB>(s, conds[s.phase], ALL) & alive;
     if (GE_STAMPS && stamps) { asm volatile("" :: "v"(T)); stamps->mark(0); }        // [end of previous turn .. row in registers]
 
     // ---- PhaseNode, the part that does not depend on this turn's actions (nobody dies before the Referee):
@@ -645,8 +719,8 @@ __device__ __forceinline__ uint32_t even_bits(uint32_t x) {
 
 // QUEUE: bot actions through the wavefront work queue (see ww_turn) - pays from 8 players on, where the
 // first turn of a vote has 7-11 due bots in some room of every wavefront; TABLE: n-th-set-bit from LDS
-template <int NB, bool QUEUE, bool TABLE>
-__device__ __forceinline__ void tt_turn(TT<NB> &s, uint32_t &done, DevRow &row, const DevRow *rows, void *wave_lds, const uint8_t *nth8,
+template <int NB, bool QUEUE, bool TABLE, bool GENERIC = false>
+__device__ __forceinline__ void tt_turn(TT<NB> &s, uint32_t &done, DevRow &row, const DevRow *rows, const DevCond *conds, void *wave_lds, const uint8_t *nth8,
                                         bool valid, uint32_t n, uint32_t rounds,
                                         uint32_t phase0_idx, uint32_t rkey, uint32_t turn,
                                         bool trace, uint32_t human, uint32_t &ev_newly, uint64_t &ev_choice) {
@@ -676,6 +750,8 @@ __device__ __forceinline__ void tt_turn(TT<NB> &s, uint32_t &done, DevRow &row, 
         }
         T = X & ALL;
     }
+    if (GENERIC && (row.r0 & ROW_GENERIC) && comp == COMP_ACTION)        // the clause form (see ww_turn)
+        T = tt_cond_generic<NB>(s, conds[s.phase], ALL);
 
     uint32_t newly = 0;
     {

@@ -238,13 +238,22 @@ template <> struct TTLayout<12> {
 //       0xFF bytes (selector 0x0D) in the others, so the AND of the three permutes is the term.
 //       N<=8: 4 terms x 1 byte, pair (W2:W2) in r5;  N<=12: terms 0..1 x 2 bytes.
 //   r7: XOR mask of the negated terms (same byte positions)
+//   r0 bit 21: the target condition is generic (or / in [..] / numeric): the row's DevCond describes it, r1/r4..r7 do not
 struct DevRow { uint32_t r0, r1, r2, r3, r4, r5, r6, r7; };
+constexpr uint32_t ROW_GENERIC = 1u << 21;
+
+// A target condition in clause form (include/ge_step.h ge_literal), for the rows whose condition is not a plain
+// conjunction of base predicates.  lit[c][l]: bits 0..15 = base-predicate bit set, or lo | hi << 8 of a numeric
+// range; 16..18 = numeric field (GE_NUM_*); 28..29 = kind (1 base set, 2 numeric); 30 = negated.
+// meta: n_clauses [2:0], length of clause c [4 + 4c +: 3].
+struct DevCond { uint32_t lit[4][4]; uint32_t meta, pad[3]; };
 
 struct DevTable {
     DevRow rows[32];
     int32_t n_phases, rounds, n_players, pad;
     uint8_t nth8[2048];      // n-th-set-bit table (ge_device.h), copied to LDS by the large-batch build
     uint32_t ord8[256];      // ord8[mask] = the positions of the set bits of an 8-bit mask, ascending, one nibble each
+    DevCond conds[32];       // clause form of the generic rows (read from global memory by the generic kernel builds only)
 };
 
 // plane geometry of a segment

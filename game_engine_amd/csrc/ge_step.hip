@@ -113,7 +113,7 @@ __device__ __forceinline__ void load_rows(DevRow *rows, const DevTable *tables, 
     __syncthreads();
 }
 
-template <int NB, bool LOWOCC>
+template <int NB, bool LOWOCC, bool GENERIC>
 __device__ __forceinline__ void run_ww(const SegDev *__restrict__ sgp, const StepArgs &a, DevRow *rows, void *lw,
                                        uint8_t *nth8, const DevTable *__restrict__ tables, uint64_t room_in) {
     const SegDev &sg = *sgp;
@@ -177,7 +177,7 @@ __device__ __forceinline__ void run_ww(const SegDev *__restrict__ sgp, const Ste
             const uint32_t p = s.phase;
             uint32_t ev_newly = 0;
             uint64_t ev_choice = 0;
-            ww_turn<NB, GE_WAVE_QUEUE, LOWOCC>(s, row, rows, lw, nth8, ord8, valid, sg.n_players, sg.nw, sg.phase0_idx, rk, turn0 + t, tk,
+            ww_turn<NB, GE_WAVE_QUEUE, LOWOCC, GENERIC>(s, row, rows, tables[sg.table_idx].conds, lw, nth8, ord8, valid, sg.n_players, sg.nw, sg.phase0_idx, rk, turn0 + t, tk,
                                        trace, sg.human_mask, deal, ahead && (t & (GE_DEAL_PERIOD - 1u)) == 0u, ev_newly, ev_choice,
                                        (GE_STAMPS && a.stamps) ? &stamps : nullptr);
             if (trace && valid) store_event(sg.trace, sg.rooms_padded, t, room, turn0 + t, p, s.phase, restarted, ev_newly, ev_choice);
@@ -208,7 +208,7 @@ __device__ __forceinline__ void run_ww(const SegDev *__restrict__ sgp, const Ste
 #endif
 constexpr bool tt_uses_queue(int nb, bool lowocc) { return !lowocc || nb >= GE_TT_LOW_QUEUE_MIN; }
 
-template <int NB, bool LOWOCC>
+template <int NB, bool LOWOCC, bool GENERIC>
 __device__ __forceinline__ void run_tt(const SegDev *__restrict__ sgp, const StepArgs &a, DevRow *rows, void *lw, uint8_t *nth8,
                                        const DevTable *__restrict__ tables, uint64_t room_in) {
     constexpr bool QUEUE = tt_uses_queue(NB, LOWOCC);
@@ -245,7 +245,7 @@ __device__ __forceinline__ void run_tt(const SegDev *__restrict__ sgp, const Ste
         const uint32_t p = s.phase;
         uint32_t ev_newly = 0;
         uint64_t ev_choice = 0;
-        tt_turn<NB, QUEUE, !LOWOCC>(s, done, row, rows, lw, nth8, valid, sg.n_players, sg.rounds, sg.phase0_idx, rk, turn0 + t, a.trace != 0u, sg.human_mask, ev_newly, ev_choice);
+        tt_turn<NB, QUEUE, !LOWOCC, GENERIC>(s, done, row, rows, tables[sg.table_idx].conds, lw, nth8, valid, sg.n_players, sg.rounds, sg.phase0_idx, rk, turn0 + t, a.trace != 0u, sg.human_mask, ev_newly, ev_choice);
         if (a.trace && valid) store_event(sg.trace, sg.rooms_padded, t, room, turn0 + t, p, s.phase, restarted, ev_newly, ev_choice);
     }
     if (!valid) return;
@@ -258,14 +258,14 @@ __device__ __forceinline__ void run_tt(const SegDev *__restrict__ sgp, const Ste
 // Two-Truths batch diverges per block, never inside a wavefront.  Segment descriptors live in
 // device memory and are read with a block-uniform index (scalar loads): indexing the kernel
 // arguments dynamically would push them through scratch.
-template <int KIND, bool LOWOCC>
+template <int KIND, bool LOWOCC, bool GENERIC>
 __device__ __forceinline__ void run_kind(const SegDev *__restrict__ sg, const StepArgs &a, DevRow *rows, void *lw,
                                          uint8_t *nth8, const DevTable *__restrict__ tables, uint64_t room) {
-    if (KIND == K_WW8) run_ww<8, LOWOCC>(sg, a, rows, lw, nth8, tables, room);
-    else if (KIND == K_WW12) run_ww<12, LOWOCC>(sg, a, rows, lw, nth8, tables, room);
-    else if (KIND == K_TT4) run_tt<4, LOWOCC>(sg, a, rows, lw, nth8, tables, room);
-    else if (KIND == K_TT8) run_tt<8, LOWOCC>(sg, a, rows, lw, nth8, tables, room);
-    else run_tt<12, LOWOCC>(sg, a, rows, lw, nth8, tables, room);
+    if (KIND == K_WW8) run_ww<8, LOWOCC, GENERIC>(sg, a, rows, lw, nth8, tables, room);
+    else if (KIND == K_WW12) run_ww<12, LOWOCC, GENERIC>(sg, a, rows, lw, nth8, tables, room);
+    else if (KIND == K_TT4) run_tt<4, LOWOCC, GENERIC>(sg, a, rows, lw, nth8, tables, room);
+    else if (KIND == K_TT8) run_tt<8, LOWOCC, GENERIC>(sg, a, rows, lw, nth8, tables, room);
+    else run_tt<12, LOWOCC, GENERIC>(sg, a, rows, lw, nth8, tables, room);
 }
 
 // LDS of a step block is sized at launch (a 64-room block must not pay for four wavefronts' queues, or
@@ -282,7 +282,9 @@ extern __shared__ __align__(16) unsigned char ge_lds[];
 
 // single-kind batch (the benchmark configurations): one instantiation per record layout, so each
 // gets its own register allocation
-template <int KIND, bool LOWOCC>
+// GENERIC: some row of the table has a generic target condition (DevCond); those builds exist for the large-batch
+// form only and serve every batch size of such a table
+template <int KIND, bool LOWOCC, bool GENERIC = false>
 __global__ void __launch_bounds__(256) ge_step_kernel(const StepArgs a, const SegDev *__restrict__ segs,
                                                       const DevTable *__restrict__ tables) {
     constexpr bool WWK = KIND == K_WW8 || KIND == K_WW12 || tt_uses_queue(KIND == K_TT4 ? 4 : KIND == K_TT8 ? 8 : 12, LOWOCC);   // uses the action queue
@@ -290,11 +292,11 @@ __global__ void __launch_bounds__(256) ge_step_kernel(const StepArgs a, const Se
     uint8_t *nth8 = ge_lds + LDS_ROWS + LDS_ORD8;
     auto *wl = reinterpret_cast<typename WaveLdsOf<LOWOCC>::type *>(ge_lds + LDS_ROWS + LDS_ORD8 + (LOWOCC ? 0u : LDS_NTH8));
     const uint64_t room = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    run_kind<KIND, LOWOCC>(segs, a, rows, WWK ? &wl[threadIdx.x >> 6] : nullptr, nth8, tables, room);
+    run_kind<KIND, LOWOCC, GENERIC>(segs, a, rows, WWK ? &wl[threadIdx.x >> 6] : nullptr, nth8, tables, room);
 }
 
 // mixed batch: several segments (games / player counts) in one launch
-template <bool LOWOCC>
+template <bool LOWOCC, bool GENERIC = false>
 __global__ void __launch_bounds__(256) ge_step_kernel_mixed(const StepArgs a, const SegDev *__restrict__ segs,
                                                             const DevTable *__restrict__ tables) {
     DevRow *rows = reinterpret_cast<DevRow *>(ge_lds);
@@ -308,11 +310,11 @@ __global__ void __launch_bounds__(256) ge_step_kernel_mixed(const StepArgs a, co
     const uint64_t room = (uint64_t)(blockIdx.x - a.block_begin[si]) * blockDim.x + threadIdx.x;
     void *lw = &wl[threadIdx.x >> 6];
     switch (sg->kind) {
-    case K_WW8: run_kind<K_WW8, LOWOCC>(sg, a, rows, lw, nth8, tables, room); break;
-    case K_WW12: run_kind<K_WW12, LOWOCC>(sg, a, rows, lw, nth8, tables, room); break;
-    case K_TT4: run_kind<K_TT4, LOWOCC>(sg, a, rows, lw, nth8, tables, room); break;
-    case K_TT8: run_kind<K_TT8, LOWOCC>(sg, a, rows, lw, nth8, tables, room); break;
-    default: run_kind<K_TT12, LOWOCC>(sg, a, rows, lw, nth8, tables, room); break;
+    case K_WW8: run_kind<K_WW8, LOWOCC, GENERIC>(sg, a, rows, lw, nth8, tables, room); break;
+    case K_WW12: run_kind<K_WW12, LOWOCC, GENERIC>(sg, a, rows, lw, nth8, tables, room); break;
+    case K_TT4: run_kind<K_TT4, LOWOCC, GENERIC>(sg, a, rows, lw, nth8, tables, room); break;
+    case K_TT8: run_kind<K_TT8, LOWOCC, GENERIC>(sg, a, rows, lw, nth8, tables, room); break;
+    default: run_kind<K_TT12, LOWOCC, GENERIC>(sg, a, rows, lw, nth8, tables, room); break;
     }
 }
 
@@ -464,13 +466,42 @@ __device__ __forceinline__ void row_term(const DevRow &row, uint32_t j, uint32_t
     neg = (row.r0 >> (16u + j)) & 1u;
 }
 
-template <int NB> __device__ int inject_ww(WW<NB> &s, const DevRow &row, uint32_t n, uint32_t player, uint32_t choice) {
+// the clause form of a condition for ONE player of an unpacked record (host-driven players' actions)
+template <typename BASE, typename NUM>
+__device__ __forceinline__ bool clauses_hold(const DevCond &c, BASE base_true, NUM num_value) {
+    const uint32_t ncl = c.meta & 7u;
+    if (ncl == 0u) return true;
+    for (uint32_t k = 0; k < ncl; k++) {
+        const uint32_t len = (c.meta >> (4 + 4 * k)) & 7u;
+        bool all = true;
+        for (uint32_t l = 0; l < len && all; l++) {
+            const uint32_t w = c.lit[k][l];
+            bool ok = false;
+            if (((w >> 28) & 3u) == 1u) {
+                for (uint32_t b = 0; b < 16u; b++)
+                    if (((w >> b) & 1u) && base_true(b)) ok = true;
+            } else {
+                const uint32_t v = num_value((w >> 16) & 7u);
+                ok = v >= (w & 0xFFu) && v <= ((w >> 8) & 0xFFu);
+            }
+            all = ok != (((w >> 30) & 1u) != 0u);
+        }
+        if (all) return true;
+    }
+    return false;
+}
+
+template <int NB> __device__ int inject_ww(WW<NB> &s, const DevRow &row, const DevCond &cond, uint32_t n, uint32_t player, uint32_t choice) {
     using nib_t = typename WW<NB>::nib_t;
     if (player < 1 || player > n) return GE_ERR_ARG;
     if ((row.r0 & 3u) != COMP_ACTION) return GE_ERR_ARG;
     const uint32_t bit = 1u << (player - 1u);
     if (!(s.alive & bit)) return GE_ERR_ARG;
-    const uint32_t nt = (row.r0 >> 8) & 7u;
+    if (row.r0 & ROW_GENERIC) {
+        if (!clauses_hold(cond, [&](uint32_t b) { return ww_base<NB>(s, b, bit); },
+                          [&](uint32_t) { return (uint32_t)(s.sel >> (4u * (player - 1u))) & 15u; })) return GE_ERR_ARG;
+    }
+    const uint32_t nt = (row.r0 & ROW_GENERIC) ? 0u : (row.r0 >> 8) & 7u;
     for (uint32_t j = 0; j < nt; j++) {
         uint32_t base; bool neg;
         row_term(row, j, NB <= 8 ? 4u : 2u, base, neg);
@@ -492,11 +523,21 @@ template <int NB> __device__ int inject_ww(WW<NB> &s, const DevRow &row, uint32_
     return GE_OK;
 }
 
-template <int NB> __device__ int inject_tt(TT<NB> &s, const DevRow &row, uint32_t n, uint32_t player, uint32_t choice) {
+template <int NB> __device__ int inject_tt(TT<NB> &s, const DevRow &row, const DevCond &cond, uint32_t n, uint32_t player, uint32_t choice) {
     if (player < 1 || player > n) return GE_ERR_ARG;
     if ((row.r0 & 3u) != COMP_ACTION) return GE_ERR_ARG;
     const uint32_t bit = 1u << (player - 1u);
-    const uint32_t nt = (row.r0 >> 8) & 7u;
+    if (row.r0 & ROW_GENERIC) {
+        const uint32_t i = player - 1u;
+        if (!clauses_hold(cond, [&](uint32_t b) { return tt_base<NB>(s, b, bit); },
+                          [&](uint32_t f) -> uint32_t {
+                              if (f == 1u) return (s.lie >> (2u * i)) & 3u;
+                              if (f == 2u) return (s.vote >> (2u * i)) & 3u;
+                              if (f == 4u) return (uint32_t)(s.rounds >> (4u * i)) & 15u;
+                              return (s.score[i / 4u] >> (8u * (i % 4u))) & 255u;
+                          })) return GE_ERR_ARG;
+    }
+    const uint32_t nt = (row.r0 & ROW_GENERIC) ? 0u : (row.r0 >> 8) & 7u;
     for (uint32_t j = 0; j < nt; j++) {
         uint32_t base; bool neg;
         row_term(row, j, 2u, base, neg);
@@ -521,7 +562,8 @@ template <int NB> __device__ void inject_group_ww(const SegDev &sg, const DevTab
     WW<NB> s;
     L::unpack(w, s);
     const DevRow row = tables[sg.table_idx].rows[s.phase];
-    for (uint32_t k = lo; k < hi; k++) a.status[k] = inject_ww<NB>(s, row, sg.n_players, a.players[k], a.choices[k]);
+    const DevCond cond = tables[sg.table_idx].conds[s.phase];
+    for (uint32_t k = lo; k < hi; k++) a.status[k] = inject_ww<NB>(s, row, cond, sg.n_players, a.players[k], a.choices[k]);
     L::pack(s, w);
     store_words<L::WORDS>(sg.base, sg.rooms_padded, room, w);
 }
@@ -532,7 +574,8 @@ template <int NB> __device__ void inject_group_tt(const SegDev &sg, const DevTab
     TT<NB> s;
     L::unpack(w, s);
     const DevRow row = tables[sg.table_idx].rows[s.phase];
-    for (uint32_t k = lo; k < hi; k++) a.status[k] = inject_tt<NB>(s, row, sg.n_players, a.players[k], a.choices[k]);
+    const DevCond cond = tables[sg.table_idx].conds[s.phase];
+    for (uint32_t k = lo; k < hi; k++) a.status[k] = inject_tt<NB>(s, row, cond, sg.n_players, a.players[k], a.choices[k]);
     L::pack(s, w);
     store_words<L::WORDS>(sg.base, sg.rooms_padded, room, w);
 }
@@ -584,7 +627,7 @@ DevRow to_dev_row(const ge_game_table &tb, const ge_phase_row &r, uint32_t kind)
     const int stride = bytes4 ? 8 : 16;
     DevRow d = {0, 0, 0, 0, 0, 0, 0, 0};
     d.r0 = (r.completion & 3u) | ((r.act & 7u) << 2) | ((r.effect & 7u) << 5) | ((r.n_terms & 7u) << 8) |
-           ((r.n_branches & 7u) << 11);
+           ((r.n_branches & 7u) << 11) | (r.generic ? ROW_GENERIC : 0u);
     for (int j = 0; j < GE_MAX_TERMS; j++) {
         if (j < r.n_terms) d.r0 |= (uint32_t)(r.term_neg[j] & 1u) << (16 + j);
         const uint32_t base = r.term_base[j];
@@ -618,6 +661,23 @@ DevRow to_dev_row(const ge_game_table &tb, const ge_phase_row &r, uint32_t kind)
         d.r4 = sel[0]; d.r5 = sel[1]; d.r6 = sel[2];
     }
     return d;
+}
+
+DevCond to_dev_cond(const ge_phase_row &r) {
+    DevCond c;
+    memset(&c, 0, sizeof c);
+    const uint32_t ncl = r.n_clauses <= GE_MAX_CLAUSES ? r.n_clauses : GE_MAX_CLAUSES;
+    c.meta = ncl;
+    for (uint32_t k = 0; k < ncl; k++) {
+        const uint32_t len = r.clause_len[k] <= GE_MAX_TERMS ? r.clause_len[k] : GE_MAX_TERMS;
+        c.meta |= len << (4 + 4 * k);
+        for (uint32_t l = 0; l < len; l++) {
+            const ge_literal &x = r.clause[k][l];
+            const uint32_t payload = x.kind == GE_LIT_NUM ? ((uint32_t)x.lo | ((uint32_t)x.hi << 8)) : x.bases;
+            c.lit[k][l] = payload | ((uint32_t)(x.num_field & 7u) << 16) | ((uint32_t)(x.kind & 3u) << 28) | (x.neg ? 1u << 30 : 0u);
+        }
+    }
+    return c;
 }
 
 int words_of(uint32_t kind) {
@@ -753,6 +813,7 @@ struct ge_batch {
     SegDev *segs_dev = nullptr;
     unsigned long long *sum_dev = nullptr;
     hipStream_t last_stream = nullptr;
+    bool generic = false;             // some phase has a generic target condition: the GENERIC kernel builds are launched
     bool pending = false;             // work was queued on last_stream since the last synchronisation
     hipEvent_t order_ev = nullptr;    // orders a step on a new stream behind the previous stream's work
     unsigned long long *stamps_dev = nullptr;   // GE_STAMPS diagnostic build only
@@ -934,7 +995,11 @@ static int create_impl(const ge_batch_desc *desc, ge_batch **out) {
                 s.dev.base = reinterpret_cast<uint32_t *>(static_cast<char *>(b->state) + reinterpret_cast<size_t>(s.dev.base));
                 DevTable &dt = host_tables[k];
                 memset(&dt, 0, sizeof dt);
-                for (int r = 0; r < s.table.n_phases; r++) dt.rows[r] = to_dev_row(s.table, s.table.rows[r], s.dev.kind);
+                for (int r = 0; r < s.table.n_phases; r++) {
+                    dt.rows[r] = to_dev_row(s.table, s.table.rows[r], s.dev.kind);
+                    dt.conds[r] = to_dev_cond(s.table.rows[r]);
+                    if (s.table.rows[r].generic) b->generic = true;
+                }
                 dt.n_phases = s.table.n_phases; dt.rounds = s.table.rounds; dt.n_players = (int32_t)s.dev.n_players;
                 fill_nth8_host(dt.nth8);
                 fill_ord8_host(dt.ord8);
@@ -991,8 +1056,17 @@ static int reset_impl(ge_batch *b) {
 static hipError_t launch_step(const ge_batch *b, const StepArgs &a, hipStream_t st) {
     const dim3 grid(b->n_blocks), block(b->block_threads);
 #define GE_LAUNCH(KERNEL, QUEUE, LOW) hipLaunchKernelGGL(KERNEL, grid, block, step_lds_bytes(QUEUE, LOW, b->block_threads), st, a, b->segs_dev, b->tables)
-    const bool low = a.lowocc != 0u;
-    if (b->segs.size() > 1) {
+    const bool low = a.lowocc != 0u && !b->generic;           // generic tables: the large-batch build serves every size
+    if (b->generic) {
+        if (b->segs.size() > 1) GE_LAUNCH((ge_step_kernel_mixed<false, true>), true, false);
+        else switch (b->segs[0].dev.kind) {
+        case K_WW8: GE_LAUNCH((ge_step_kernel<K_WW8, false, true>), true, false); break;
+        case K_WW12: GE_LAUNCH((ge_step_kernel<K_WW12, false, true>), true, false); break;
+        case K_TT4: GE_LAUNCH((ge_step_kernel<K_TT4, false, true>), true, false); break;
+        case K_TT8: GE_LAUNCH((ge_step_kernel<K_TT8, false, true>), true, false); break;
+        default: GE_LAUNCH((ge_step_kernel<K_TT12, false, true>), true, false); break;
+        }
+    } else if (b->segs.size() > 1) {
         if (low) GE_LAUNCH(ge_step_kernel_mixed<true>, true, true); else GE_LAUNCH(ge_step_kernel_mixed<false>, true, false);
     } else {
         switch (b->segs[0].dev.kind) {

@@ -12,6 +12,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <memory>
 #include <new>
 #include <string>
@@ -216,52 +217,242 @@ int base_of(int pack, const std::string &field, const std::string &sval, bool is
     return -1;
 }
 
-// `player.f == v and player.g == w`  (ww:247,279,310,390; tt phases 2,3,5)
-int parse_condition(int pack, const std::string &cond, ge_phase_row &row, std::string &why) {
-    size_t pos = 0;
-    row.n_terms = 0;
-    std::string s = cond;
-    while (pos < s.size()) {
-        size_t nxt = s.find(" and ", pos);
-        std::string part = s.substr(pos, nxt == std::string::npos ? std::string::npos : nxt - pos);
-        pos = nxt == std::string::npos ? s.size() : nxt + 5;
-        size_t a = part.find_first_not_of(" \t\n"), z = part.find_last_not_of(" \t\n");
-        if (a == std::string::npos) continue;
-        part = part.substr(a, z - a + 1);
-        if (part.compare(0, 7, "player.") != 0) { why = "unsupported condition term: " + part; return -1; }
-        size_t i = 7;
-        while (i < part.size() && (isalnum((unsigned char)part[i]) || part[i] == '_')) i++;
-        std::string field = part.substr(7, i - 7);
-        while (i < part.size() && part[i] == ' ') i++;
-        bool neg;
-        if (part.compare(i, 2, "==") == 0) neg = false;
-        else if (part.compare(i, 2, "!=") == 0) neg = true;
-        else { why = "unsupported operator in: " + part; return -1; }
-        i += 2;
-        while (i < part.size() && part[i] == ' ') i++;
-        std::string lit = part.substr(i);
-        bool is_str = false;
-        std::string sval;
-        if (lit.size() >= 2 && (lit[0] == '\'' || lit[0] == '"') && lit.back() == lit[0]) {
-            is_str = true; sval = lit.substr(1, lit.size() - 2);
-        } else {
-            std::string l = lower(lit);
-            if (l == "false") neg = !neg;
-            else if (l != "true") { why = "unsupported literal in: " + part; return -1; }
+// ---- target_players.condition: the grammar of dsl_phases_generation_prompt.txt:120-132
+//   cond   := clause { " or " clause }            (and binds tighter than or; no parentheses)
+//   clause := term { " and " term }
+//   term   := "player." field op value | "player." field ["not"] "in" "[" value {"," value} "]"
+//   op     := == != < <= > >=          value := 'str' | "str" | true | false | integer
+// compiled to an OR of AND-clauses of ge_literal.  Both shipped games only write `==` joined by `and`.
+
+struct Atom { enum { BOOL, INT, STR } type = INT; bool b = false; long num = 0; std::string str; };
+
+std::string squeeze(const std::string &s) {                    // whitespace runs -> one blank, trimmed
+    std::string o;
+    bool sp = true;
+    for (char c : s) {
+        if (c == ' ' || c == '\t' || c == '\n' || c == '\r') { if (!sp) o += ' '; sp = true; }
+        else { o += c; sp = false; }
+    }
+    while (!o.empty() && o.back() == ' ') o.pop_back();
+    return o;
+}
+
+// splits on a blank-delimited keyword outside quotes and brackets
+std::vector<std::string> split_kw(const std::string &s, const char *kw) {
+    std::vector<std::string> out;
+    const std::string pat = std::string(" ") + kw + " ";
+    std::string low = lower(s);
+    size_t start = 0;
+    char quote = 0;
+    int depth = 0;
+    for (size_t i = 0; i < s.size(); i++) {
+        const char c = s[i];
+        if (quote) { if (c == quote) quote = 0; continue; }
+        if (c == '\'' || c == '"') { quote = c; continue; }
+        if (c == '[') depth++;
+        else if (c == ']') depth--;
+        else if (depth == 0 && low.compare(i, pat.size(), pat) == 0) {
+            out.push_back(s.substr(start, i - start));
+            start = i + pat.size();
+            i = start - 1;
         }
-        int base = base_of(pack, field, sval, is_str);
-        if (base < 0) { why = "condition field not in rule pack: " + part; return -1; }
-        if (row.n_terms >= GE_MAX_TERMS) { why = "too many condition terms"; return -1; }
-        row.term_base[row.n_terms] = (uint8_t)base;
-        row.term_neg[row.n_terms] = neg ? 1 : 0;
-        row.n_terms++;
+    }
+    out.push_back(s.substr(start));
+    return out;
+}
+
+bool parse_atom(const std::string &text, Atom &a) {
+    std::string t = squeeze(text);
+    std::string l = lower(t);
+    if (l == "true" || l == "false") { a.type = Atom::BOOL; a.b = l == "true"; return true; }
+    if (t.size() >= 2 && (t[0] == '\'' || t[0] == '"') && t.back() == t[0]) { a.type = Atom::STR; a.str = t.substr(1, t.size() - 2); return true; }
+    if (!t.empty()) {
+        size_t i = t[0] == '-' ? 1 : 0;
+        bool digits = i < t.size();
+        for (size_t k = i; k < t.size(); k++) digits = digits && isdigit((unsigned char)t[k]);
+        if (digits) { a.type = Atom::INT; a.num = strtol(t.c_str(), nullptr, 10); return true; }
+    }
+    return false;
+}
+
+// numeric field of a pack: GE_NUM_* and the largest value the record holds, -1 if the pack has none of that name
+int num_field_of(int pack, const std::string &field, int &top) {
+    if (pack == GE_PACK_WEREWOLF) {
+        if (field == "selected_target_id") { top = 15; return GE_NUM_SELECTED_TARGET; }
+        return -1;
+    }
+    if (field == "lie_index") { top = 3; return GE_NUM_LIE_INDEX; }
+    if (field == "vote_choice") { top = 3; return GE_NUM_VOTE_CHOICE; }
+    if (field == "total_score") { top = 255; return GE_NUM_TOTAL_SCORE; }
+    if (field == "rounds_as_speaker") { top = 15; return GE_NUM_ROUNDS_AS_SPEAKER; }
+    return -1;
+}
+
+bool is_bool_field(int pack, const std::string &field) { return base_of(pack, field, std::string(), false) >= 0; }
+
+using Clause = std::vector<ge_literal>;
+
+// one term -> the literals it stands for (several = an OR, for a numeric `in` over a list with gaps)
+int parse_term(int pack, const std::string &part, std::vector<ge_literal> &options, std::string &why) {
+    std::string p = squeeze(part);
+    if (p.compare(0, 7, "player.") != 0) { why = "unsupported condition term: " + p; return -1; }
+    size_t i = 7;
+    while (i < p.size() && (isalnum((unsigned char)p[i]) || p[i] == '_')) i++;
+    const std::string field = p.substr(7, i - 7);
+    while (i < p.size() && p[i] == ' ') i++;
+    std::string rest = p.substr(i), lrest = lower(rest), op;
+    for (const char *cand : {"==", "!=", "<=", ">=", "<", ">", "not in ", "in "})
+        if (lrest.compare(0, strlen(cand), cand) == 0) { op = cand; break; }
+    if (field.empty() || op.empty()) { why = "unsupported condition term: " + p; return -1; }
+    std::string rhs = squeeze(rest.substr(op.size()));
+    while (!op.empty() && op.back() == ' ') op.pop_back();
+    const bool in_op = op == "in" || op == "not in";
+    std::vector<Atom> vals;
+    if (in_op) {
+        if (rhs.size() < 2 || rhs[0] != '[' || rhs.back() != ']') { why = "unsupported list literal: " + rhs; return -1; }
+        std::string inner = rhs.substr(1, rhs.size() - 2), cur;
+        char quote = 0;
+        auto flush = [&]() -> bool {
+            if (squeeze(cur).empty()) { cur.clear(); return true; }
+            Atom a;
+            if (!parse_atom(cur, a)) return false;
+            vals.push_back(a);
+            cur.clear();
+            return true;
+        };
+        for (char c : inner) {
+            if (quote) { cur += c; if (c == quote) quote = 0; continue; }
+            if (c == '\'' || c == '"') { quote = c; cur += c; continue; }
+            if (c == ',') { if (!flush()) { why = "unsupported literal in: " + p; return -1; } continue; }
+            cur += c;
+        }
+        if (!flush()) { why = "unsupported literal in: " + p; return -1; }
+        if (vals.empty()) { why = "empty list in: " + p; return -1; }
+    } else {
+        Atom a;
+        if (!parse_atom(rhs, a)) { why = "unsupported literal in: " + p; return -1; }
+        vals.push_back(a);
+    }
+    const bool neg = op == "!=" || op == "not in";
+    int top = 0;
+    const int nf = num_field_of(pack, field, top);
+    bool all_int = true;
+    for (auto &v : vals) all_int = all_int && v.type == Atom::INT;
+    if (nf >= 0 && all_int) {
+        auto clip = [&](long lo, long hi) {
+            ge_literal l;
+            memset(&l, 0, sizeof l);
+            l.kind = GE_LIT_NUM; l.num_field = (uint8_t)nf;
+            if (lo < 0) lo = 0;
+            if (hi > top) hi = top;
+            if (lo > hi) { lo = 1; hi = 0; }                          // never true
+            l.lo = (uint8_t)lo; l.hi = (uint8_t)hi;
+            return l;
+        };
+        if (op == "==" || op == "!=" || in_op) {
+            std::vector<long> ks;
+            for (auto &v : vals) ks.push_back(v.num);
+            std::sort(ks.begin(), ks.end());
+            ks.erase(std::unique(ks.begin(), ks.end()), ks.end());
+            std::vector<std::pair<long, long>> runs;                  // contiguous runs of the value list
+            for (long k : ks) {
+                if (!runs.empty() && k == runs.back().second + 1) runs.back().second = k;
+                else runs.push_back({k, k});
+            }
+            if (neg && runs.size() > 1) { why = "unsupported: 'not in' over a non-contiguous list: " + p; return -1; }
+            for (auto &r : runs) { ge_literal l = clip(r.first, r.second); l.neg = neg; options.push_back(l); }
+        } else {
+            const long k = vals[0].num;
+            if (op == "<") options.push_back(clip(0, k - 1));
+            else if (op == "<=") options.push_back(clip(0, k));
+            else if (op == ">") options.push_back(clip(k + 1, top));
+            else options.push_back(clip(k, top));
+        }
+        return 0;
+    }
+    if (!(op == "==" || op == "!=" || in_op)) { why = "unsupported comparison on a non-numeric field: " + p; return -1; }
+    ge_literal l;
+    memset(&l, 0, sizeof l);
+    l.kind = GE_LIT_BASE;
+    int flips = 0;                                                    // bit 0: some value keeps, bit 1: some value flips
+    for (auto &v : vals) {
+        int base = -1;
+        bool flip = false;
+        if (v.type == Atom::BOOL || (v.type == Atom::INT && (v.num == 0 || v.num == 1) && is_bool_field(pack, field))) {
+            base = base_of(pack, field, std::string(), false);
+            flip = v.type == Atom::BOOL ? !v.b : v.num == 0;
+        } else if (v.type == Atom::STR) {
+            base = base_of(pack, field, v.str, true);
+        } else { why = "unsupported value in: " + p; return -1; }
+        if (base < 0) { why = "condition field not in rule pack: " + p; return -1; }
+        l.bases |= (uint16_t)(1u << base);
+        flips |= flip ? 2 : 1;
+    }
+    if (flips == 3) { why = "unsupported: a boolean list with both values: " + p; return -1; }
+    l.neg = (neg != (flips == 2)) ? 1 : 0;
+    options.push_back(l);
+    return 0;
+}
+
+// the whole condition -> row.clause[][] (+ term_base / term_neg and generic = 0 when it is a plain conjunction)
+int parse_condition(int pack, const std::string &cond_in, ge_phase_row &row, std::string &why) {
+    row.n_terms = 0; row.n_clauses = 0; row.generic = 0;
+    const std::string cond = squeeze(cond_in);
+    if (cond.empty()) return 0;
+    {   // parentheses are outside the grammar (a '(' inside a quoted string is data)
+        char quote = 0;
+        for (char c : cond) {
+            if (quote) { if (c == quote) quote = 0; continue; }
+            if (c == '\'' || c == '"') quote = c;
+            else if (c == '(' || c == ')') { why = "unsupported condition (parentheses): " + cond; return -1; }
+        }
+    }
+    std::vector<Clause> clauses;
+    for (const std::string &alt : split_kw(cond, "or")) {
+        std::vector<Clause> partial(1);
+        for (const std::string &part : split_kw(alt, "and")) {
+            std::vector<ge_literal> options;
+            if (parse_term(pack, part, options, why) != 0) return -1;
+            std::vector<Clause> next;
+            for (auto &c : partial)
+                for (auto &o : options) { Clause x = c; x.push_back(o); next.push_back(x); }
+            partial.swap(next);
+            if (partial.size() > GE_MAX_CLAUSES) { why = "too many condition alternatives"; return -1; }
+        }
+        for (auto &c : partial) clauses.push_back(c);
+    }
+    if (clauses.size() > GE_MAX_CLAUSES) { why = "too many condition alternatives"; return -1; }
+    for (auto &c : clauses)
+        if (c.size() > GE_MAX_TERMS) { why = "too many condition terms"; return -1; }
+    row.n_clauses = (uint8_t)clauses.size();
+    bool plain = clauses.size() == 1;
+    for (size_t ci = 0; ci < clauses.size(); ci++) {
+        row.clause_len[ci] = (uint8_t)clauses[ci].size();
+        for (size_t li = 0; li < clauses[ci].size(); li++) {
+            const ge_literal &l = clauses[ci][li];
+            row.clause[ci][li] = l;
+            plain = plain && l.kind == GE_LIT_BASE && l.bases != 0 && (l.bases & (l.bases - 1)) == 0;
+        }
+    }
+    row.generic = plain ? 0 : 1;
+    if (plain) {
+        for (const ge_literal &l : clauses[0]) {
+            int b = 0;
+            while (!((l.bases >> b) & 1)) b++;
+            row.term_base[row.n_terms] = (uint8_t)b;
+            row.term_neg[row.n_terms] = l.neg;
+            row.n_terms++;
+        }
     }
     return 0;
 }
 
-bool term_is(const ge_phase_row &r, int base, int neg) {
-    for (int j = 0; j < r.n_terms; j++)
-        if (r.term_base[j] == base && r.term_neg[j] == neg) return true;
+// a clause holds the positive (neg = 0) / negative single-base literal `base`
+bool clause_has(const ge_phase_row &r, int c, int base, int neg) {
+    for (int j = 0; j < r.clause_len[c]; j++) {
+        const ge_literal &l = r.clause[c][j];
+        if (l.kind == GE_LIT_BASE && l.bases == (1u << base) && l.neg == neg) return true;
+    }
     return false;
 }
 
@@ -389,19 +580,33 @@ static int compile_impl(const char *dsl_json, size_t len, int rounds, ge_game_ta
         if (row.completion == GE_COMP_ACTION) {
             const JVal *tp = cc->get("target_players");
             std::string why;
+            const JVal *wf = cc->get("wait_for");
+            if (wf && !wf->is_null()) {
+                // all three kinds mean "feedback from ALL target players" (prompt :138 "Completion Logic"); anything else is an error
+                const std::string w = as_str(wf);
+                if (w != "single_player_choice" && w != "all_players_action" && w != "multiple_players_action")
+                    return err.set(where + ("unknown wait_for " + w));
+            }
             if (parse_condition(t.pack, as_str(tp ? tp->get("condition") : nullptr), row, why) != 0)
                 return err.set(where + why);
-            if (t.pack == GE_PACK_WEREWOLF) {
-                if (term_is(row, 7 + ROLE_WEREWOLF, 0)) row.act = GE_ACT_WOLF_TARGET;
-                else if (term_is(row, 7 + ROLE_DOCTOR, 0)) row.act = GE_ACT_DOCTOR_PROTECT;
-                else if (term_is(row, 7 + ROLE_DETECTIVE, 0)) row.act = GE_ACT_DETECTIVE;
-                else if (term_is(row, 1, 0)) row.act = GE_ACT_DAY_VOTE;
-            } else {
-                if (term_is(row, 0, 1)) row.act = GE_ACT_TT_VOTE;
-                else if (term_is(row, 0, 0))
-                    row.act = (has_tool("createTextInputPanel") || has(lname, "statement")) ? GE_ACT_TT_STATEMENTS : GE_ACT_TT_LIE;
+            // the action kind, from the condition: every alternative is classified on its own and all must agree
+            if (row.n_clauses == 0) return err.set(where + std::string("cannot classify the player action"));
+            for (int c = 0; c < row.n_clauses; c++) {
+                int act = GE_ACT_NONE;
+                if (t.pack == GE_PACK_WEREWOLF) {
+                    if (clause_has(row, c, 7 + ROLE_WEREWOLF, 0)) act = GE_ACT_WOLF_TARGET;
+                    else if (clause_has(row, c, 7 + ROLE_DOCTOR, 0)) act = GE_ACT_DOCTOR_PROTECT;
+                    else if (clause_has(row, c, 7 + ROLE_DETECTIVE, 0)) act = GE_ACT_DETECTIVE;
+                    else if (clause_has(row, c, 1, 0)) act = GE_ACT_DAY_VOTE;
+                } else {
+                    if (clause_has(row, c, 0, 1)) act = GE_ACT_TT_VOTE;
+                    else if (clause_has(row, c, 0, 0))
+                        act = (has_tool("createTextInputPanel") || has(lname, "statement")) ? GE_ACT_TT_STATEMENTS : GE_ACT_TT_LIE;
+                }
+                if (act == GE_ACT_NONE) return err.set(where + std::string("cannot classify the player action"));
+                if (c > 0 && act != row.act) return err.set(where + std::string("the condition's alternatives describe different player actions"));
+                row.act = (uint8_t)act;
             }
-            if (row.act == GE_ACT_NONE) return err.set(where + std::string("cannot classify the player action"));
         }
 
         if (t.pack == GE_PACK_WEREWOLF) {

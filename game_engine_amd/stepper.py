@@ -122,6 +122,10 @@ class GameTable:
             out.append({"phase_id": r.phase_id, "name": r.name.decode("utf-8", "replace"),
                         "completion": r.completion, "act": r.act, "effect": r.effect,
                         "terms": [(r.term_base[j], r.term_neg[j]) for j in range(r.n_terms)],
+                        "generic": bool(r.generic),
+                        # the condition in clause form: OR of AND-clauses of (kind, neg, bases bit set, num_field, lo, hi)
+                        "clauses": [[(l.kind, l.neg, l.bases, l.num_field, l.lo, l.hi) for l in list(r.clause[c])[: r.clause_len[c]]]
+                                    for c in range(r.n_clauses)],
                         "branches": [(r.br_res[j], r.br_target[j]) for j in range(r.n_branches)]})
         return out
 

@@ -36,6 +36,7 @@ extern "C" {
 #define GE_MAX_PLAYERS 12
 #define GE_MAX_SEGMENTS 4
 #define GE_MAX_TERMS 4
+#define GE_MAX_CLAUSES 4
 #define GE_MAX_BRANCHES 4
 #define GE_NAME_LEN 64
 
@@ -65,6 +66,27 @@ enum { GE_EFF_NONE = 0, GE_EFF_ASSIGN_ROLES, GE_EFF_NIGHT_BEGIN, GE_EFF_NIGHT_RE
 enum { GE_RES_ALWAYS = 0, GE_RES_WOLVES_ZERO, GE_RES_WOLVES_GE_VILLAGERS, GE_RES_FOLLOWS_DAY,
        GE_RES_FOLLOWS_NIGHT, GE_RES_ALL_ROUNDS_DONE, GE_RES_OTHERWISE };
 
+/* numeric player fields a target condition may compare (declared `num` fields of the rule packs:
+ * werewolf selected_target_id; two-truths lie_index, vote_choice, total_score, rounds_as_speaker) */
+enum { GE_NUM_SELECTED_TARGET = 0, GE_NUM_LIE_INDEX = 1, GE_NUM_VOTE_CHOICE = 2, GE_NUM_TOTAL_SCORE = 3,
+       GE_NUM_ROUNDS_AS_SPEAKER = 4 };
+enum { GE_LIT_NONE = 0, GE_LIT_BASE = 1, GE_LIT_NUM = 2 };
+
+/* One literal of a target condition in clause form (OR of AND-clauses).  The grammar is the one the
+ * reference's DSL generator is told to write (agent/prompt/dsl_phases_generation_prompt.txt:120-132):
+ *   player.<field> ==|!=|<|<=|>|>= <value>,  player.<field> in [..] / not in [..],  joined by and / or.
+ * GE_LIT_BASE: the player has ANY of the base predicates in the bit set `bases` (== / != / in over booleans
+ * and enums, POLICY.md §3 numbering); GE_LIT_NUM: lo <= player.<num_field> <= hi (lo > hi: never true).
+ * `neg` inverts the literal. */
+typedef struct ge_literal {
+    uint8_t kind;                         /* GE_LIT_* */
+    uint8_t neg;
+    uint8_t num_field;                    /* GE_NUM_* (GE_LIT_NUM) */
+    uint8_t pad;
+    uint16_t bases;                       /* GE_LIT_BASE: bit b = base predicate b */
+    uint8_t lo, hi;                       /* GE_LIT_NUM */
+} ge_literal;
+
 /* One DSL phase, compiled.  Replaces what the LLM reads out of dsl['phases'][id] each turn
  * (v2:1057, 1087-1103). */
 typedef struct ge_phase_row {
@@ -80,6 +102,14 @@ typedef struct ge_phase_row {
     uint8_t br_target[GE_MAX_BRANCHES];   /* dense row index of the successor */
     uint8_t pad[3];
     char name[GE_NAME_LEN];               /* phases.<id>.name, UTF-8, truncated */
+    /* target_players.condition in clause form: always filled.  `generic` = 0: the condition is the plain
+     * conjunction term_base / term_neg above (what both shipped games use; the kernels' fast path);
+     * 1: only the clause form describes it (or / in [..] with several values / numeric comparisons). */
+    uint8_t generic;
+    uint8_t n_clauses;                    /* 0: no condition (every living player) */
+    uint8_t clause_len[GE_MAX_CLAUSES];
+    uint8_t pad2[2];
+    ge_literal clause[GE_MAX_CLAUSES][GE_MAX_TERMS];
 } ge_phase_row;
 
 /* A compiled game (one YAML file).  Host-visible so callers may inspect or build one by hand. */

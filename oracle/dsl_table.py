@@ -215,7 +215,7 @@ def parse_clauses(pack: int, cond: Optional[str]) -> List[List[Literal]]:
     base = WW_BASE if pack == PACK_WEREWOLF else TT_BASE
     nums = WW_NUM if pack == PACK_WEREWOLF else TT_NUM
     flat = " ".join(cond.split())
-    if "(" in flat.replace("[", "").replace("]", "") and re.search(r"\((?![^\[]*\])", flat):
+    if re.search(r"[()]", re.sub(r"'[^']*'|\"[^\"]*\"", "", flat)):          # outside quoted strings
         raise DslError(f"unsupported condition (parentheses): {cond!r}")
     clauses: List[List[Literal]] = []
     for alt in re.split(r"\s+or\s+", flat, flags=re.I):

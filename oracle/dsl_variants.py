@@ -1,0 +1,59 @@
+"""ORACLE (test infrastructure) - variants of the two shipped game DSLs that use the rest of the condition
+grammar the reference's DSL generator is told to write (agent/prompt/dsl_phases_generation_prompt.txt:106-150):
+`in [...]`, `!=`, `<`, `<=`, `>`, `>=` over declared `num` fields, `or`, and the three `wait_for` kinds.
+The shipped games only use `==` joined by `and`; these variants are what pins the generic path: the
+reference's own nodes are run on them (oracle/refharness/make_golden.py::variant_cases -> tests/golden/
+traj_variant_*.json), and the oracle and the product are compared on them.
+
+Each variant is a function of the base DSL dict (tests/golden/dsl/<game>.json): data in, data out."""
+from __future__ import annotations
+
+import copy
+from typing import Callable, Dict, Tuple
+
+
+def _set_condition(dsl: dict, phase_id, cond: str, wait_for: str = None) -> None:
+    ph = dsl["phases"].get(phase_id) or dsl["phases"].get(str(phase_id)) or dsl["phases"][int(phase_id)]
+    cc = ph["completion_criteria"]
+    cc["target_players"]["condition"] = cond
+    if wait_for:
+        cc["wait_for"] = wait_for
+
+
+def ww_generic(base: dict) -> dict:
+    """Werewolf: role lists, !=, an `or` of two conjunctions and a numeric comparison that changes who votes by day
+    (only players whose selected_target_id is below 5: villagers hold 0, night actors whatever they picked)."""
+    d = copy.deepcopy(base)
+    for pid in (2, 10):
+        _set_condition(d, pid, "player.role in ['Werewolf'] and player.is_alive == true and player.team != 'villagers'",
+                       "all_players_action")
+    for pid in (3, 11):
+        _set_condition(d, pid, "player.role in ['Doctor', 'Medic'] and player.is_alive != false")
+    for pid in (4, 12):
+        _set_condition(d, pid, "player.role == 'Detective' and player.is_alive == true and player.selected_target_id == 0 "
+                               "or player.role == 'Detective' and player.selected_target_id > 0")
+    for pid in (7, 15):
+        _set_condition(d, pid, "player.can_vote == true and player.is_alive == true and player.selected_target_id < 5",
+                       "multiple_players_action")
+    return d
+
+
+def tt_generic(base: dict) -> dict:
+    """Two Truths: only players who are behind (score <= 1) or have already spoken vote; boolean list; not in."""
+    d = copy.deepcopy(base)
+    _set_condition(d, 2, "player.is_speaker == true and player.statements_submitted != true")
+    _set_condition(d, 3, "player.is_speaker in [true] and player.lie_index not in [1, 2, 3]", "single_player_choice")
+    _set_condition(d, 5, "player.is_speaker == false and player.total_score <= 1 "
+                         "or player.is_speaker == false and player.rounds_as_speaker >= 1", "all_players_action")
+    return d
+
+
+# name -> (base game, builder, rounds)
+VARIANTS: Dict[str, Tuple[str, Callable[[dict], dict], int]] = {
+    "ww_generic": ("werewolf-(mafia)", ww_generic, 1),
+    "tt_generic": ("two-truths-and-a-lie", tt_generic, 2),
+}
+
+
+def build(name: str, base: dict) -> dict:
+    return VARIANTS[name][1](base)

@@ -45,11 +45,22 @@ enum { T_SPEAKER, T_SUBMITTED, T_LIE, T_REVEALED, T_CAN_VOTE, T_VOTE, T_HAS_VOTE
 #define F_ACTED 9
 #define F_CHOICE 10
 
+/* one literal of a condition's clause form (oracle/dsl_table.py Literal):
+ * kind 1: the player has ANY base predicate of the bit set `bases`; kind 2: lo <= numeric field <= hi */
+typedef struct {
+    uint8_t kind, neg, num_field, pad;
+    uint16_t bases;
+    uint8_t lo, hi;
+} orc_literal;
+
 typedef struct {
     uint8_t completion, act, effect, n_terms, n_branches, pad[3];
     uint8_t term_base[4], term_neg[4];
     uint8_t br_res[4], br_target[4];
     int32_t phase_id;
+    /* target_players.condition as OR of AND-clauses (always filled; n_terms/term_* are not read) */
+    uint8_t n_clauses, clause_len[4], pad2[3];
+    orc_literal clause[4][4];
 } orc_phase;
 
 typedef struct {
@@ -114,12 +125,39 @@ static int base_true(const orc_table *tb, const orc_room *r, int i, int base) {
     }
 }
 
-/* completion_criteria.target_players.condition AND alive */
+/* a numeric player field a condition may compare (index: dsl_table.WW_NUM / TT_NUM) */
+static int num_value(const orc_table *tb, const orc_room *r, int i, int field) {
+    const uint8_t *f = r->p[i];
+    if (tb->pack == PACK_WW) return f[W_TARGET];
+    switch (field) {
+    case 1: return f[T_LIE]; case 2: return f[T_VOTE]; case 3: return f[T_SCORE]; default: return f[T_ROUNDS];
+    }
+}
+
+static int literal_true(const orc_table *tb, const orc_room *r, int i, const orc_literal *l) {
+    int ok = 0;
+    if (l->kind == 1) {
+        for (int b = 0; b < 16; b++)
+            if (((l->bases >> b) & 1) && base_true(tb, r, i, b)) ok = 1;
+    } else {
+        const int v = num_value(tb, r, i, l->num_field);
+        ok = v >= l->lo && v <= l->hi;
+    }
+    return ok != (l->neg != 0);
+}
+
+/* completion_criteria.target_players.condition AND alive; the condition is an OR of AND-clauses
+ * (an empty condition = every living player) */
 static int is_target(const orc_table *tb, const orc_phase *ph, const orc_room *r, int i) {
     if (!is_alive(tb, r, i)) return 0;
-    for (int t = 0; t < ph->n_terms; t++)
-        if ((base_true(tb, r, i, ph->term_base[t]) != 0) == (ph->term_neg[t] != 0)) return 0;
-    return 1;
+    if (ph->n_clauses == 0) return 1;
+    for (int c = 0; c < ph->n_clauses; c++) {
+        int all = 1;
+        for (int t = 0; t < ph->clause_len[c]; t++)
+            if (!literal_true(tb, r, i, &ph->clause[c][t])) { all = 0; break; }
+        if (all) return 1;
+    }
+    return 0;
 }
 
 /* most votes wins, ties -> lowest id; 0 when nobody voted */

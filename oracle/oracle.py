@@ -23,12 +23,19 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_HERE, "libge_oracle.so")
 
 
+class _Literal(C.Structure):
+    _fields_ = [("kind", C.c_uint8), ("neg", C.c_uint8), ("num_field", C.c_uint8), ("pad", C.c_uint8),
+                ("bases", C.c_uint16), ("lo", C.c_uint8), ("hi", C.c_uint8)]
+
+
 class _Phase(C.Structure):
     _fields_ = [("completion", C.c_uint8), ("act", C.c_uint8), ("effect", C.c_uint8),
                 ("n_terms", C.c_uint8), ("n_branches", C.c_uint8), ("pad", C.c_uint8 * 3),
                 ("term_base", C.c_uint8 * 4), ("term_neg", C.c_uint8 * 4),
                 ("br_res", C.c_uint8 * 4), ("br_target", C.c_uint8 * 4),
-                ("phase_id", C.c_int32)]
+                ("phase_id", C.c_int32),
+                ("n_clauses", C.c_uint8), ("clause_len", C.c_uint8 * 4), ("pad2", C.c_uint8 * 3),
+                ("clause", (_Literal * 4) * 4)]
 
 
 class _Table(C.Structure):
@@ -99,6 +106,14 @@ class Oracle:
             cp.n_terms, cp.n_branches, cp.phase_id = len(p.terms), len(p.branches), p.id
             for k, t in enumerate(p.terms):
                 cp.term_base[k], cp.term_neg[k] = t.base, int(t.negate)
+            cp.n_clauses = len(p.clauses)
+            for ci, clause in enumerate(p.clauses):
+                cp.clause_len[ci] = len(clause)
+                for li, l in enumerate(clause):
+                    cl = cp.clause[ci][li]
+                    cl.kind, cl.neg = (1 if l.kind == "base" else 2), int(l.negate)
+                    cl.num_field, cl.lo, cl.hi = l.num, l.lo, l.hi
+                    cl.bases = sum(1 << b for b in l.bases)
             for k, b in enumerate(p.branches):
                 cp.br_res[k], cp.br_target[k] = b.resolver, b.target_idx
         self.ct = ct

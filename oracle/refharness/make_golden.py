@@ -128,6 +128,35 @@ def human_cases():
                        "cases": cases}, f, separators=(",", ":"))
 
 
+def variant_cases():
+    """The reference's nodes run on VARIANTS of the shipped DSLs that use the rest of the condition grammar
+    (oracle/dsl_variants.py: in [...], !=, <, <=, >, >=, or, wait_for kinds) -> traj_variant_<name>_n<N>.json."""
+    from .. import dsl_variants
+    for name, n, rooms, turns in (("ww_generic", 8, [0, 5], 90), ("ww_generic", 11, [2], 130),
+                                  ("tt_generic", 4, [0, 3], 110), ("tt_generic", 7, [1], 200)):
+        game, builder, rounds = dsl_variants.VARIANTS[name]
+        cases = []
+        for seed in SEEDS:
+            for room in rooms:
+                a = RoomSession(game, n, seed, room, "v2", rounds, dsl_variant=builder)
+                b = RoomSession(game, n, seed, room, "v3", rounds, dsl_variant=builder)
+                traj = []
+                for t in range(turns):
+                    a.step()
+                    b.step()
+                    pa = a.project()
+                    assert pa == b.project(), (name, n, seed, room, t, "v2 != v3")
+                    traj.append(pa)
+                assert traj[-1][3] >= 0, (name, n, seed, room, "did not finish; raise turns")
+                cases.append({"seed": seed, "room": room, "turns": traj})
+                print("variant", name, n, hex(seed), room, "end_turn", traj[-1][3], file=sys.stderr)
+        with open(os.path.join(GOLD, f"traj_variant_{name}_n{n}.json"), "w") as f:
+            json.dump({"game": game, "variant": name, "n_players": n, "rounds": rounds,
+                       "source": "reference game_agent_v2 + v3 nodes under FixedPolicy on oracle/dsl_variants.py:" + name,
+                       "layout": "[phase, prev_phase, phase0_done, end_turn] + 11/player (+ det/player for werewolf)",
+                       "cases": cases}, f, separators=(",", ":"))
+
+
 def _strip_ts(x):
     """Drop wall-clock fields (timestamps) - everything else of the log-shaped AgentState parts stays."""
     if isinstance(x, dict):
@@ -186,3 +215,4 @@ if __name__ == "__main__":
     restart_cases()
     human_cases()
     string_cases()
+    variant_cases()

@@ -72,10 +72,33 @@ class RoomView:
         ok = (v == term.value) if not isinstance(term.value, bool) else (bool(v) is True)
         return ok != term.negate
 
+    def base_true(self, i: int, base: int) -> bool:
+        """Base predicate `base` of the rule pack (POLICY.md §3 numbering), read off the dict state."""
+        if self.table.pack == T.PACK_WEREWOLF:
+            for (fld, val), b in T.WW_BASE.items():
+                if b == base:
+                    if fld == "role":
+                        return self.role_class(i) == val
+                    return (self.get(i, fld) == val) if isinstance(val, str) else bool(self.get(i, fld))
+            raise AssertionError(base)
+        for (fld, _), b in T.TT_BASE.items():
+            if b == base:
+                return bool(self.get(i, fld))
+        raise AssertionError(base)
+
+    def literal_true(self, i: int, l: T.Literal) -> bool:
+        if l.kind == "base":
+            ok = any(self.base_true(i, b) for b in l.bases)
+        else:
+            ok = l.lo <= int(self.get(i, l.field) or 0) <= l.hi
+        return ok != l.negate
+
     def targets(self, ph: T.Phase) -> int:
         """completion_criteria.target_players.condition AND alive
-        (bot_behavior_system_prompt.txt:21-31: dead players never act)."""
-        return self.mask(lambda i: self.alive(i) and all(self.term_true(i, t) for t in ph.terms))
+        (bot_behavior_system_prompt.txt:21-31: dead players never act).  The condition is read in its
+        clause form: OR of AND-clauses of literals (dsl_phases_generation_prompt.txt:120-132 grammar)."""
+        return self.mask(lambda i: self.alive(i) and (not ph.clauses or any(
+            all(self.literal_true(i, l) for l in clause) for clause in ph.clauses)))
 
     def visit_actions(self, ph: T.Phase, only_turn: Optional[int] = None) -> Dict[int, Tuple[int, int]]:
         """player index -> (turn, choice) of the latest action in this visit of `ph`

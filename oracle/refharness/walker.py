@@ -88,14 +88,20 @@ class RoomSession:
     """One room (= one LangGraph thread, src/app/api/copilotkit/route.ts:24-37)."""
 
     def __init__(self, game: str, n_players: int, seed: int, room: int = 0,
-                 version: str = "v2", rounds: int = 1, turn0: int = 0, human_mask: int = 0, human_script=None, game_index: int = 0):
+                 version: str = "v2", rounds: int = 1, turn0: int = 0, human_mask: int = 0, human_script=None, game_index: int = 0,
+                 dsl_variant=None):
         from .. import dsl_table
         from .policy import FixedPolicy
         import yaml
         self.version = version
         self.mod = load_reference(version)
         with open(os.path.join(REFERENCE_ROOT, "games", f"{game}.yaml"), encoding="utf-8") as f:
-            self.table = dsl_table.compile_dsl(yaml.safe_load(f), rounds=rounds)
+            dsl = yaml.safe_load(f)
+        if dsl_variant is not None:
+            # a variant of the game's DSL (oracle/dsl_variants.py): the reference's InitialRouterNode keeps a DSL
+            # that is already in the state instead of loading the game's file (v2:254-262)
+            dsl = dsl_variant(dsl)
+        self.table = dsl_table.compile_dsl(dsl, rounds=rounds)
         human = None
         if human_script is not None:
             def human(turn, view, _s=self):          # the script sees the canonical projection, like the tests do
@@ -109,7 +115,7 @@ class RoomSession:
         self.state: Dict[str, Any] = {
             "messages": [], "gameName": game, "items": [], "tools": [],
             "current_phase_id": 0, "player_states": {}, "playerActions": {},
-            "phase_history": [], "game_notes": [], "dsl": {},
+            "phase_history": [], "game_notes": [], "dsl": (dsl if dsl_variant is not None else {}),
             "roomSession": {"players": [
                 {"name": f"Bot {i + 1}", "gamePlayerId": i + 1, "isBot": True} for i in range(n_players)]},
         }

@@ -21,6 +21,16 @@ def load_dsl(game: str) -> dict:
         return json.load(f)
 
 
+def golden_dsl(g: dict) -> dict:
+    """The DSL a golden file was produced with: the game's fixture, or a grammar variant of it
+    (oracle/dsl_variants.py; the variants are functions of the committed base DSL)."""
+    dsl = load_dsl(g["game"])
+    if g.get("variant"):
+        from oracle import dsl_variants
+        dsl = dsl_variants.build(g["variant"], dsl)
+    return dsl
+
+
 def golden_files():
     return sorted(f for f in os.listdir(GOLD) if f.startswith("traj_") and f.endswith(".json"))
 

@@ -29,7 +29,8 @@ def test_struct_sizes_match_header():
     # sizes the N-API / cgo / ctypes bindings rely on
     from game_engine_amd.stepper import ROOM_VIEW_DTYPE
     assert ROOM_VIEW_DTYPE.itemsize == 20 + 16 * 12 + 16
-    assert C.sizeof(_lib.PhaseRow) == 4 + 4 + 4 + 4 + 1 + 4 + 4 + 3 + 64
+    assert C.sizeof(_lib.Literal) == 8
+    assert C.sizeof(_lib.PhaseRow) == 4 + 4 + 4 + 4 + 1 + 4 + 4 + 3 + 64 + 8 + 4 * 4 * 8
     assert C.sizeof(_lib.Summary) == 8 * 41
 
 

@@ -6,7 +6,7 @@ Integer path: every comparison is bit-exact."""
 import numpy as np
 import pytest
 
-from conftest import golden_files, human_files, load_dsl, load_golden, restart_files
+from conftest import golden_dsl, golden_files, human_files, load_dsl, load_golden, restart_files
 from game_engine_amd import GameTable, GeError, RoomBatch
 from game_engine_amd.stepper import project_view
 from parity_util import assert_views_equal, oracle_batch, oracle_rooms_as_views
@@ -24,7 +24,7 @@ def _oracle(dsl, n, rounds=1):
 def test_golden_trajectories_turn_by_turn(name):
     """Every turn of every committed reference trajectory, one launch per turn."""
     g = load_golden(name)
-    tb = GameTable(load_dsl(g["game"]), rounds=g["rounds"])
+    tb = GameTable(golden_dsl(g), rounds=g["rounds"])
     for case in g["cases"]:
         with RoomBatch([(tb, g["n_players"], 1)], seed=case["seed"], first_room=case["room"], max_fuse=1) as b:
             for t, want in enumerate(case["turns"]):
@@ -37,7 +37,7 @@ def test_golden_trajectories_turn_by_turn(name):
 def test_golden_trajectories_fused(name):
     """Same end states when all turns run inside one launch (state kept in registers)."""
     g = load_golden(name)
-    tb = GameTable(load_dsl(g["game"]), rounds=g["rounds"])
+    tb = GameTable(golden_dsl(g), rounds=g["rounds"])
     for case in g["cases"]:
         T = len(case["turns"])
         with RoomBatch([(tb, g["n_players"], 1)], seed=case["seed"], first_room=case["room"], max_fuse=T) as b:
@@ -69,7 +69,7 @@ def test_batch_equals_oracle(game, n, n_rooms, turns, rounds, seed):
 @pytest.mark.parametrize("name", restart_files())
 def test_restart_mode_golden(name):
     g = load_golden(name)
-    tb = GameTable(load_dsl(g["game"]))
+    tb = GameTable(golden_dsl(g))
     for case in g["cases"]:
         with RoomBatch([(tb, g["n_players"], 1)], seed=case["seed"], first_room=case["room"],
                        max_fuse=1, restart=True) as b:
@@ -134,7 +134,7 @@ def test_host_driven_player_golden(name):
     from oracle.human_script import scripted_human
     from oracle import dsl_table
     g = load_golden(name)
-    dsl = load_dsl(g["game"])
+    dsl = golden_dsl(g)
     tb, otb, n = GameTable(dsl), dsl_table.compile_dsl(dsl), g["n_players"]
     for case in g["cases"]:
         with RoomBatch([(tb, n, 1, g["human_mask"])], seed=case["seed"], first_room=case["room"], max_fuse=1) as b:

@@ -3,14 +3,14 @@ produced by running the REFERENCE's own node coroutines (game_agent_v2.py / v3) 
 fixed policy — turn by turn, bit-exact.  CPU only."""
 import pytest
 
-from conftest import golden_files, human_files, load_dsl, load_golden, restart_files
+from conftest import golden_dsl, golden_files, human_files, load_dsl, load_golden, restart_files
 from oracle.oracle import Oracle
 
 
 @pytest.mark.parametrize("name", golden_files())
 def test_oracle_matches_reference_trajectories(name):
     g = load_golden(name)
-    orc = Oracle(load_dsl(g["game"]), g["n_players"], rounds=g["rounds"])
+    orc = Oracle(golden_dsl(g), g["n_players"], rounds=g["rounds"])
     for case in g["cases"]:
         got = orc.trajectory(case["seed"], case["room"], len(case["turns"]))
         for t, (a, b) in enumerate(zip(got, case["turns"])):
@@ -35,7 +35,7 @@ def test_oracle_restart_mode_matches_chained_reference_sessions(name):
     """Steady-state mode: a finished room is replaced, on its next turn, by a new reference
     session whose clock starts there."""
     g = load_golden(name)
-    orc = Oracle(load_dsl(g["game"]), g["n_players"])
+    orc = Oracle(golden_dsl(g), g["n_players"])
     for case in g["cases"]:
         got = orc.trajectory(case["seed"], case["room"], len(case["turns"]), restart=True)
         for t, (a, b) in enumerate(zip(got, case["turns"])):
@@ -48,7 +48,7 @@ def test_oracle_with_host_driven_player_matches_reference(name):
     (oracle/human_script.py) and its action is logged at the start of the next graph run."""
     from oracle.human_script import scripted_human
     g = load_golden(name)
-    orc = Oracle(load_dsl(g["game"]), g["n_players"])
+    orc = Oracle(golden_dsl(g), g["n_players"])
     n = g["n_players"]
     acted_as_human = 0
     for case in g["cases"]:
