@@ -121,7 +121,7 @@ def _batch_equals_oracle(dsl, n, rooms, turns, seed, first, rounds=1, restart=Tr
 def test_variant_batches_equal_oracle(name, n, rooms):
     game, builder, rounds = dsl_variants.VARIANTS[name]
     s = _batch_equals_oracle(builder(load_dsl(game)), n, rooms, 120, 0xC0FFEE, 1 << 30, rounds)
-    assert s["games_recycled"] > (rooms // 2 if n <= 8 else 0) and s["turn"] == 120     # (nine players x two rounds outlast 120 turns)
+    assert s["games_recycled"] >= (rooms // 2 if n <= 8 else 0) and s["turn"] == 120     # (nine players x two rounds outlast 120 turns)
 
 
 @pytest.mark.gpu
