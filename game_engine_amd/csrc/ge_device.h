@@ -34,6 +34,13 @@ constexpr uint32_t GOLDEN = 0x9E3779B9u;
 #ifndef GE_ORD
 #define GE_ORD 1
 #endif
+// the shadows (and the pins that keep their values live across the queue) in the large-batch build too.  Measured
+// (profiles/r02_ab_occupancy.txt): Werewolf x 8 gains 1.7 % from them at 1 M rooms (68 -> 71 VGPRs, still 7 wavefronts per
+// SIMD); Werewolf x 12 is better off without them and held to 80 VGPRs = 6 wavefronts per SIMD (2 spilled registers):
+// 21.96 -> 21.53 us/turn at 2 M rooms
+#ifndef GE_SHADOW_HI
+#define GE_SHADOW_HI 1
+#endif
 // diagnostic build (-DGE_STAMPS=1, tools/stamps.py): s_memtime stamps at points of the werewolf turn where no LDS
 // operation is outstanding anyway, accumulated per wavefront; never in the product build
 #ifndef GE_STAMPS
@@ -378,6 +385,7 @@ __device__ __forceinline__ void ww_turn(WWR<NB> &s, DevRow &row, const DevRow *r
     using nib_t = typename WWR<NB>::nib_t;
     using R = WWR<NB>;
     constexpr bool ORD = GE_ORD && NB <= 8;                    // queue slots find their player through the ord8 table
+    constexpr bool SHADOW = GE_SHADOW && (LOWOCC || (GE_SHADOW_HI && NB <= 8));   // action-independent work inside the queue's LDS round trips
     auto *lw = static_cast<typename WaveLdsOf<LOWOCC>::type *>(wave_lds);
     const uint32_t ALL = (1u << n) - 1u;
     const uint32_t comp = row.r0 & 3u, act = (row.r0 >> 2) & 7u, p_eff = (row.r0 >> 5) & 7u;
@@ -538,7 +546,7 @@ __device__ __forceinline__ void ww_turn(WWR<NB> &s, DevRow &row, const DevRow *r
                     return hi->ctx[hi->queue[k] & 63u];
                 };
                 uint4 c4 = fetch(lane);
-                if (GE_SHADOW) {
+                if (SHADOW) {
                     phase_precompute();
                     asm volatile("" : "+v"(qe_cand));              // stays here: not sunk below the loop
                 }
@@ -589,7 +597,7 @@ __device__ __forceinline__ void ww_turn(WWR<NB> &s, DevRow &row, const DevRow *r
                 wave_sync();
                 const uint4 r = NB <= 8 ? make_uint4(reinterpret_cast<const uint2 *>(&lw->res[lane])->x, reinterpret_cast<const uint2 *>(&lw->res[lane])->y, 0u, 0u)
                                         : lw->res[lane];
-                if (GE_SHADOW) {                                   // shadow of the result read
+                if (SHADOW) {                                      // shadow of the result read
                     tk_next = turn_key(rkey, turn + 1u);
                     deal_precompute();
                     asm volatile("" : "+v"(tk_next));
@@ -612,7 +620,7 @@ __device__ __forceinline__ void ww_turn(WWR<NB> &s, DevRow &row, const DevRow *r
                     new_det_w = tb & team_w;
                     new_det_v = tb & ~team_w;
                 }
-                if (!GE_SHADOW) { phase_precompute(); tk_next = turn_key(rkey, turn + 1u); deal_precompute(); }
+                if (!SHADOW) { phase_precompute(); tk_next = turn_key(rkey, turn + 1u); deal_precompute(); }
             } else {
                 phase_precompute();
                 deal_precompute();

@@ -284,8 +284,15 @@ extern __shared__ __align__(16) unsigned char ge_lds[];
 // gets its own register allocation
 // GENERIC: some row of the table has a generic target condition (DevCond); those builds exist for the large-batch
 // form only and serve every batch size of such a table
+// minimum wavefronts per SIMD asked of the register allocator for the large-batch Werewolf builds (see GE_SHADOW_HI)
+#ifndef GE_WW12_WAVES
+#define GE_WW12_WAVES 6
+#endif
+#ifndef GE_WW8_WAVES
+#define GE_WW8_WAVES 1
+#endif
 template <int KIND, bool LOWOCC, bool GENERIC = false>
-__global__ void __launch_bounds__(256) ge_step_kernel(const StepArgs a, const SegDev *__restrict__ segs,
+__global__ void __launch_bounds__(256, (KIND == K_WW12 && !LOWOCC && !GENERIC) ? GE_WW12_WAVES : (KIND == K_WW8 && !LOWOCC && !GENERIC) ? GE_WW8_WAVES : 1) ge_step_kernel(const StepArgs a, const SegDev *__restrict__ segs,
                                                       const DevTable *__restrict__ tables) {
     constexpr bool WWK = KIND == K_WW8 || KIND == K_WW12 || tt_uses_queue(KIND == K_TT4 ? 4 : KIND == K_TT8 ? 8 : 12, LOWOCC);   // uses the action queue
     DevRow *rows = reinterpret_cast<DevRow *>(ge_lds);
