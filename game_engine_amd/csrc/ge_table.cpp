@@ -292,8 +292,39 @@ bool is_bool_field(int pack, const std::string &field) { return base_of(pack, fi
 
 using Clause = std::vector<ge_literal>;
 
+// is `field` one the rule pack models (a base predicate, an enum or a numeric field of its records)?
+bool pack_models(int pack, const std::string &field) {
+    int top;
+    return is_bool_field(pack, field) || num_field_of(pack, field, top) >= 0 ||
+           (pack == GE_PACK_WEREWOLF && (field == "role" || field == "team"));
+}
+
+// a term over a declared field the pack does not model: nobody ever writes it under the fixed policy, so every player
+// keeps the template's value and the term is a constant.  1 = holds, 0 = does not, -1 = outside the grammar
+int const_term(const JVal &have, const std::string &op, const std::vector<Atom> &vals) {
+    auto same = [&](const Atom &v) {
+        if (have.type == JVal::BOOL) return v.type == Atom::BOOL ? v.b == have.b : (v.type == Atom::INT && (v.num == 0 || v.num == 1) && (v.num != 0) == have.b);
+        if (have.type == JVal::NUM) {
+            if (v.type == Atom::BOOL) return (have.num == 0 || have.num == 1) && (have.num != 0) == v.b;
+            return v.type == Atom::INT && (double)v.num == have.num;
+        }
+        return v.type == Atom::STR && v.str == have.str;
+    };
+    if (op == "==" || op == "!=" || op == "in" || op == "not in") {
+        bool hit = false;
+        for (auto &v : vals) hit = hit || same(v);
+        return hit != (op == "!=" || op == "not in") ? 1 : 0;
+    }
+    if (have.type != JVal::NUM || vals[0].type != Atom::INT) return -1;
+    const double k = (double)vals[0].num;
+    if (op == "<") return have.num < k;
+    if (op == "<=") return have.num <= k;
+    if (op == ">") return have.num > k;
+    return have.num >= k;
+}
+
 // one term -> the literals it stands for (several = an OR, for a numeric `in` over a list with gaps)
-int parse_term(int pack, const std::string &part, std::vector<ge_literal> &options, std::string &why) {
+int parse_term(int pack, const JVal *tmpl, const std::string &part, std::vector<ge_literal> &options, std::string &why) {
     std::string p = squeeze(part);
     if (p.compare(0, 7, "player.") != 0) { why = "unsupported condition term: " + p; return -1; }
     size_t i = 7;
@@ -334,6 +365,18 @@ int parse_term(int pack, const std::string &part, std::vector<ge_literal> &optio
         vals.push_back(a);
     }
     const bool neg = op == "!=" || op == "not in";
+    if (!pack_models(pack, field) && tmpl && field != "name") {
+        const JVal *have = tmpl->get(field.c_str());
+        if (have && (have->type == JVal::BOOL || (have->type == JVal::NUM && have->num == (double)(long)have->num) || have->type == JVal::STR)) {
+            const int holds = const_term(*have, op, vals);
+            if (holds < 0) { why = "unsupported comparison on a non-numeric field: " + p; return -1; }
+            ge_literal l;
+            memset(&l, 0, sizeof l);
+            l.kind = GE_LIT_BASE; l.bases = 0; l.neg = (uint8_t)holds;          // empty base set = never; negated = always
+            options.push_back(l);
+            return 0;
+        }
+    }
     int top = 0;
     const int nf = num_field_of(pack, field, top);
     bool all_int = true;
@@ -395,7 +438,7 @@ int parse_term(int pack, const std::string &part, std::vector<ge_literal> &optio
 }
 
 // the whole condition -> row.clause[][] (+ term_base / term_neg and generic = 0 when it is a plain conjunction)
-int parse_condition(int pack, const std::string &cond_in, ge_phase_row &row, std::string &why) {
+int parse_condition(int pack, const JVal *tmpl, const std::string &cond_in, ge_phase_row &row, std::string &why) {
     row.n_terms = 0; row.n_clauses = 0; row.generic = 0;
     const std::string cond = squeeze(cond_in);
     if (cond.empty()) return 0;
@@ -412,7 +455,7 @@ int parse_condition(int pack, const std::string &cond_in, ge_phase_row &row, std
         std::vector<Clause> partial(1);
         for (const std::string &part : split_kw(alt, "and")) {
             std::vector<ge_literal> options;
-            if (parse_term(pack, part, options, why) != 0) return -1;
+            if (parse_term(pack, tmpl, part, options, why) != 0) return -1;
             std::vector<Clause> next;
             for (auto &c : partial)
                 for (auto &o : options) { Clause x = c; x.push_back(o); next.push_back(x); }
@@ -587,7 +630,7 @@ static int compile_impl(const char *dsl_json, size_t len, int rounds, ge_game_ta
                 if (w != "single_player_choice" && w != "all_players_action" && w != "multiple_players_action")
                     return err.set(where + ("unknown wait_for " + w));
             }
-            if (parse_condition(t.pack, as_str(tp ? tp->get("condition") : nullptr), row, why) != 0)
+            if (parse_condition(t.pack, tmpl, as_str(tp ? tp->get("condition") : nullptr), row, why) != 0)
                 return err.set(where + why);
             // the action kind, from the condition: every alternative is classified on its own and all must agree
             if (row.n_clauses == 0) return err.set(where + std::string("cannot classify the player action"));

@@ -96,6 +96,14 @@ class GameTable {
     this.dsl = dsl;
     this.handle = addon.compileTable(JSON.stringify(dsl), rounds);
     this.info = addon.tableInfo(this.handle);
+    // declared fields the rule packs do not model: constants from the template (nobody writes them under the fixed policy)
+    const tps = ((dsl.declaration || {}).player_states_template || {}).player_states || {};
+    const tmpl = tps['1'] || tps[Object.keys(tps)[0]] || {};
+    const modelled = new Set(['name', 'role', 'team', 'is_alive', 'role_revealed', 'can_vote', 'has_secret_role', 'night_action_eligible',
+                              'night_action_submitted', 'selected_target_id', 'investigated_alignments', 'is_speaker', 'statements',
+                              'statements_submitted', 'lie_index', 'lie_revealed', 'vote_choice', 'has_voted', 'total_score', 'rounds_as_speaker']);
+    this.extraFields = {};
+    for (const [k, v] of Object.entries(tmpl)) if (!modelled.has(k) && ['boolean', 'number', 'string'].includes(typeof v)) this.extraFields[k] = v;
   }
   static fromGamename(gamename, gamesDir, rounds = 1) {
     return new GameTable(loadDslByGamename(gamename, gamesDir), rounds);
@@ -129,6 +137,7 @@ function decodeRoom(table, buf, off) {
         can_vote: !!f[4], vote_choice: f[5], has_voted: !!f[6], total_score: f[7], rounds_as_speaker: f[8],
       };
     }
+    Object.assign(playerStates[String(i + 1)], table.extraFields || {});
   }
   const phaseId = dv.getInt32(0, true);
   return {

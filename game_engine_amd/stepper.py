@@ -96,6 +96,11 @@ class GameTable:
         if not isinstance(dsl, dict) or not dsl:
             raise GeError(-2, "empty DSL")
         self.dsl = dsl
+        # declared fields the rule packs do not model: constants from the template (nobody writes them under the fixed policy)
+        tmpl_all = ((dsl.get("declaration") or {}).get("player_states_template") or {}).get("player_states") or {}
+        tmpl = tmpl_all.get("1") or tmpl_all.get(1) or (tmpl_all[next(iter(tmpl_all))] if tmpl_all else {})
+        modelled = set(WW_FIELDS) | set(TT_FIELDS) | {"name", "investigated_alignments", "statements"}
+        self.extra_fields = {k: v for k, v in (tmpl or {}).items() if k not in modelled and isinstance(v, (bool, int, str))}
         text = json.dumps(dsl, ensure_ascii=False).encode("utf-8")   # int phase keys become strings
         self.c = _lib.Table()
         err = C.create_string_buffer(512)

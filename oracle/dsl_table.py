@@ -205,7 +205,24 @@ def _atom(text: str):
     raise DslError(f"unsupported literal: {text!r}")
 
 
-def parse_clauses(pack: int, cond: Optional[str]) -> List[List[Literal]]:
+def _const_holds(have: Any, op: str, vals: list, part: str) -> bool:
+    """A term over a declared field the rule pack does not model: under the fixed policy nobody ever writes it, so
+    every player holds the template's value forever and the term is a constant."""
+    def same(a, b):
+        if isinstance(a, bool) or isinstance(b, bool):
+            return isinstance(b, (bool, int)) and isinstance(a, (bool, int)) and bool(a) == bool(b) and \
+                (isinstance(a, bool) or a in (0, 1)) and (isinstance(b, bool) or b in (0, 1))
+        return type(a) is type(b) and a == b
+    if op in ("==", "!=", "in", "not in"):
+        hit = any(same(have, v) for v in vals)
+        return hit != (op in ("!=", "not in"))
+    if isinstance(have, bool) or not isinstance(have, int) or isinstance(vals[0], bool) or not isinstance(vals[0], int):
+        raise DslError(f"unsupported comparison on a non-numeric field: {part!r}")
+    k = vals[0]
+    return {"<": have < k, "<=": have <= k, ">": have > k, ">=": have >= k}[op]
+
+
+def parse_clauses(pack: int, cond: Optional[str], template: Optional[dict] = None) -> List[List[Literal]]:
     """The condition grammar the DSL generator is told to use (dsl_phases_generation_prompt.txt:120-132):
     terms `player.<field> <op> <value>` with == != < <= > >= `in [...]` `not in [...]`, joined by `and`,
     alternatives joined by `or` (`and` binds tighter; no parentheses).  Result: OR of AND-clauses of
@@ -238,7 +255,11 @@ def parse_clauses(pack: int, cond: Optional[str]) -> List[List[Literal]]:
                 vals = [_atom(rhs)]
             neg = op in ("!=", "not in")
             options: List[Literal]
-            if fld in nums and all(isinstance(v, int) and not isinstance(v, bool) for v in vals):
+            modelled = fld in nums or fld in ("role", "team") or (fld, True) in base
+            if not modelled and template is not None and fld != "name" and isinstance(template.get(fld), (bool, int, str)):
+                # a declared field outside the pack: constant (empty base set = never, negated = always)
+                options = [Literal("base", _const_holds(template[fld], op, vals, part), bases=(), field=fld)]
+            elif fld in nums and all(isinstance(v, int) and not isinstance(v, bool) for v in vals):
                 idx, top = nums[fld]
                 if op in ("==", "!=", "in", "not in"):
                     ks = sorted({v for v in vals})
@@ -292,7 +313,7 @@ def parse_clauses(pack: int, cond: Optional[str]) -> List[List[Literal]]:
 
 def plain_terms(clauses: List[List[Literal]]) -> Optional[List[Tuple[int, bool]]]:
     """[(base, negate)] when the clause form is one conjunction of single base predicates, else None."""
-    if len(clauses) != 1 or any(l.kind != "base" or len(l.bases) != 1 for l in clauses[0]):
+    if len(clauses) != 1 or any(l.kind != "base" or len(l.bases) != 1 for l in clauses[0]):       # (a constant has no base)
         return None
     return [(l.bases[0], l.negate) for l in clauses[0]]
 
@@ -379,7 +400,7 @@ def compile_dsl(dsl: dict, rounds: int = 1) -> Table:
             if wf is not None and wf not in WAIT_FOR:
                 raise DslError(f"phase {pid}: unknown wait_for {wf!r}")
             try:
-                p.clauses = parse_clauses(pack, (cc.get("target_players") or {}).get("condition"))
+                p.clauses = parse_clauses(pack, (cc.get("target_players") or {}).get("condition"), template)
             except DslError as e:
                 raise DslError(f"phase {pid}: {e}") from None
             plain = plain_terms(p.clauses) if p.clauses else []

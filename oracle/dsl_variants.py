@@ -48,10 +48,32 @@ def tt_generic(base: dict) -> dict:
     return d
 
 
+def ww_extra_fields(base: dict) -> dict:
+    """Werewolf with two declared fields the rule pack does not model (`suspicion: num`, `tier: string`).  Nobody writes
+    them under the fixed policy, so conditions on them are constants: the day vote's is always true, the Doctor's never
+    (nobody is ever protected), the Detective's first alternative never, its second as in the shipped game."""
+    d = copy.deepcopy(base)
+    decl = d["declaration"]
+    decl["player_states"]["suspicion"] = {"type": "num", "description": "how suspicious the table finds the player", "example": 3}
+    decl["player_states"]["tier"] = {"type": "string", "description": "lobby tier", "example": "gold"}
+    for tmpl in decl["player_states_template"]["player_states"].values():
+        tmpl["suspicion"] = 3
+        tmpl["tier"] = "gold"
+    for pid in (3, 11):
+        _set_condition(d, pid, "player.role == 'Doctor' and player.is_alive == true and player.tier != 'gold'")
+    for pid in (4, 12):
+        _set_condition(d, pid, "player.role == 'Detective' and player.suspicion > 3 or player.role == 'Detective' and player.is_alive == true "
+                               "and player.tier in ['gold', 'silver']")
+    for pid in (7, 15):
+        _set_condition(d, pid, "player.can_vote == true and player.is_alive == true and player.suspicion >= 2 and player.suspicion not in [4, 5]")
+    return d
+
+
 # name -> (base game, builder, rounds)
 VARIANTS: Dict[str, Tuple[str, Callable[[dict], dict], int]] = {
     "ww_generic": ("werewolf-(mafia)", ww_generic, 1),
     "tt_generic": ("two-truths-and-a-lie", tt_generic, 2),
+    "ww_extra_fields": ("werewolf-(mafia)", ww_extra_fields, 1),
 }
 
 

@@ -133,7 +133,8 @@ def variant_cases():
     (oracle/dsl_variants.py: in [...], !=, <, <=, >, >=, or, wait_for kinds) -> traj_variant_<name>_n<N>.json."""
     from .. import dsl_variants
     for name, n, rooms, turns in (("ww_generic", 8, [0, 5], 90), ("ww_generic", 11, [2], 130),
-                                  ("tt_generic", 4, [0, 3], 110), ("tt_generic", 7, [1], 200)):
+                                  ("tt_generic", 4, [0, 3], 110), ("tt_generic", 7, [1], 200),
+                                  ("ww_extra_fields", 8, [0, 4], 90)):
         game, builder, rounds = dsl_variants.VARIANTS[name]
         cases = []
         for seed in SEEDS:

@@ -86,6 +86,29 @@ def test_outside_the_grammar_is_an_error_in_both_compilers(dsl_ww, cond, needle)
     assert needle in str(oe.value)
 
 
+def test_declared_fields_outside_the_pack_are_constants(dsl_ww):
+    """A condition may test any declared scalar field; one the rule pack does not model keeps the template's value
+    (the fixed policy never writes it), so its literal compiles to 'never' (empty base set) or 'always' (negated)."""
+    d = dsl_variants.build("ww_extra_fields", dsl_ww)
+    tb, ot = _assert_same_table(d)
+    rows = {r["phase_id"]: r for r in tb.rows()}
+    assert (1, 0, 0, 0, 0, 0) in rows[3]["clauses"][0]                      # tier != 'gold' : never
+    assert rows[7]["clauses"][0].count((1, 1, 0, 0, 0, 0)) == 2             # suspicion >= 2, suspicion not in [4, 5] : always
+    assert rows[4]["clauses"][0][1] == (1, 0, 0, 0, 0, 0) and rows[4]["clauses"][1][2] == (1, 1, 0, 0, 0, 0)
+    assert tb.extra_fields == {"suspicion": 3, "tier": "gold"}
+    for cond, needle in (("player.role == 'Doctor' and player.tier > 2", "non-numeric"),
+                         ("player.role == 'Doctor' and player.name == 'Ann'", "not in rule pack"),
+                         ("player.role == 'Doctor' and player.investigated_alignments == 1", "unsupported value")):
+        bad = copy.deepcopy(d)
+        bad["phases"]["3"]["completion_criteria"]["target_players"]["condition"] = cond
+        with pytest.raises(GeError) as e:
+            GameTable(bad)
+        assert needle in str(e.value), str(e.value)
+        with pytest.raises(T.DslError) as oe:
+            T.compile_dsl(bad)
+        assert needle in str(oe.value)
+
+
 def test_wait_for_kinds(dsl_ww):
     """All three wait_for kinds mean 'every target player' (prompt :138 Completion Logic); others are errors."""
     for wf in ("single_player_choice", "all_players_action", "multiple_players_action"):
@@ -117,6 +140,7 @@ def _batch_equals_oracle(dsl, n, rooms, turns, seed, first, rounds=1, restart=Tr
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,n,rooms", [("ww_generic", 8, 40000), ("ww_generic", 12, 150000), ("ww_generic", 5, 3000),
+                                          ("ww_extra_fields", 8, 70000), ("ww_extra_fields", 10, 9000),
                                           ("tt_generic", 4, 200000), ("tt_generic", 9, 30000)])
 def test_variant_batches_equal_oracle(name, n, rooms):
     game, builder, rounds = dsl_variants.VARIANTS[name]
