@@ -18,24 +18,51 @@ function literal(text) {
   return n;
 }
 
-/** `player.team == 'werewolves' and player.is_alive == true` -> predicate (==, !=, in [...], and). */
+function splitOutside(expr, word) {
+  const out = [];
+  const pat = ` ${word} `;
+  let cur = '', quote = '', depth = 0;
+  for (let i = 0; i < expr.length;) {
+    const c = expr[i];
+    if (quote) { if (c === quote) quote = ''; } else if (c === "'" || c === '"') quote = c;
+    else if (c === '[') depth++;
+    else if (c === ']') depth--;
+    else if (depth === 0 && expr.substr(i, pat.length).toLowerCase() === pat) { out.push(cur); cur = ''; i += pat.length; continue; }
+    cur += c; i++;
+  }
+  out.push(cur);
+  return out;
+}
+
+/**
+ * `player.team == 'werewolves' and player.is_alive == true` -> predicate over one player's state.  The same grammar as
+ * phase target conditions (dsl_phases_generation_prompt.txt:120-132): == != < <= > >=, in [..] / not in [..], terms joined
+ * by `and`, alternatives by `or` (and binds tighter; no parentheses).  Same semantics as game_engine_amd/ui_script.py.
+ */
 function compileCriteria(expr) {
-  const terms = expr.split(/\s+/).join(' ').split(/\s+and\s+/).map((part) => {
-    const m = /^\s*player\.(\w+)\s*(==|!=|in)\s*(.+?)\s*$/.exec(part);
+  const flat = expr.split(/\s+/).filter((x) => x).join(' ');
+  if (/[()]/.test(flat.replace(/'[^']*'|"[^"]*"/g, ''))) throw new Error(`unsupported selection criterion (parentheses): ${expr}`);
+  const clauses = splitOutside(flat, 'or').map((alt) => splitOutside(alt, 'and').map((part) => {
+    const m = /^\s*player\.(\w+)\s*(==|!=|<=|>=|<|>|not\s+in|in)\s*(.+?)\s*$/i.exec(part);
     if (!m) throw new Error(`unsupported selection criterion: ${part}`);
-    const [, field, op, rhs] = m;
-    if (op === 'in') {
+    const field = m[1], op = m[2].toLowerCase().split(/\s+/).join(' '), rhs = m[3];
+    if (op === 'in' || op === 'not in') {
       const inner = rhs.trim();
       if (!(inner.startsWith('[') && inner.endsWith(']'))) throw new Error(`unsupported list literal: ${rhs}`);
       return [field, op, inner.slice(1, -1).split(',').filter((x) => x.trim()).map(literal)];
     }
-    return [field, op, literal(rhs)];
-  });
-  return (player) => terms.every(([field, op, val]) => {
+    const val = literal(rhs);
+    if (['<', '<=', '>', '>='].includes(op) && typeof val !== 'number') throw new Error(`unsupported comparison: ${part}`);
+    return [field, op, val];
+  }));
+  const holds = (player, field, op, val) => {
     const have = player[field];
-    const ok = op === 'in' ? val.includes(have) : have === val;
-    return op === '!=' ? !ok : ok;
-  });
+    if (op === '==' || op === '!=') return (have === val) !== (op === '!=');
+    if (op === 'in' || op === 'not in') return val.includes(have) !== (op === 'not in');
+    if (typeof have !== 'number') return false;
+    return op === '<' ? have < val : op === '<=' ? have <= val : op === '>' ? have > val : have >= val;
+  };
+  return (player) => clauses.some((terms) => terms.every(([f, o, v]) => holds(player, f, o, v)));
 }
 
 const byId = (a, b) => Number(a) - Number(b);

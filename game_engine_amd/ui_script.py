@@ -30,7 +30,7 @@ import os
 import re
 from typing import Any, Callable, Dict, List, Optional
 
-_TERM = re.compile(r"^\s*player\.(\w+)\s*(==|!=|in)\s*(.+?)\s*$", re.S)
+_TERM = re.compile(r"^\s*player\.(\w+)\s*(==|!=|<=|>=|<|>|not\s+in|in)\s*(.+?)\s*$", re.S | re.I)
 
 
 def _literal(text: str) -> Any:
@@ -39,39 +39,82 @@ def _literal(text: str) -> Any:
         return True
     if t.lower() == "false":
         return False
-    if (t[0] == t[-1]) and t[0] in "'\"":
+    if len(t) >= 2 and (t[0] == t[-1]) and t[0] in "'\"":
         return t[1:-1]
     return int(t)
 
 
+def _split_outside(expr: str, word: str) -> List[str]:
+    """Split on a blank-delimited keyword outside quotes and brackets."""
+    out, cur, quote, depth, i = [], "", "", 0, 0
+    pat = f" {word} "
+    while i < len(expr):
+        c = expr[i]
+        if quote:
+            quote = "" if c == quote else quote
+        elif c in "'\"":
+            quote = c
+        elif c == "[":
+            depth += 1
+        elif c == "]":
+            depth -= 1
+        elif depth == 0 and expr[i:i + len(pat)].lower() == pat:
+            out.append(cur)
+            cur = ""
+            i += len(pat)
+            continue
+        cur += c
+        i += 1
+    out.append(cur)
+    return out
+
+
 def compile_criteria(expr: str) -> Callable[[Dict[str, Any]], bool]:
-    """`player.team == 'werewolves' and player.is_alive == true` -> predicate over one player's
-    state dict.  Supports ==, !=, `in [a, b]` and `and` (everything the shipped DSLs and the
-    generator prompts use for selection criteria)."""
-    terms = []
-    for part in re.split(r"\s+and\s+", " ".join(expr.split())):
-        m = _TERM.match(part)
-        if not m:
-            raise ValueError(f"unsupported selection criterion: {part!r}")
-        field, op, rhs = m.groups()
-        if op == "in":
-            inner = rhs.strip()
-            if not (inner.startswith("[") and inner.endswith("]")):
-                raise ValueError(f"unsupported list literal: {rhs!r}")
-            values = [_literal(x) for x in inner[1:-1].split(",") if x.strip()]
-            terms.append((field, "in", values))
-        else:
-            terms.append((field, op, _literal(rhs)))
+    """`player.team == 'werewolves' and player.is_alive == true` -> predicate over one player's state dict.
+    The same grammar as phase target conditions (dsl_phases_generation_prompt.txt:120-132): == != < <= > >=,
+    `in [a, b]` / `not in [a, b]`, terms joined by `and`, alternatives by `or` (and binds tighter; no parentheses).
+    Evaluated on the dict, so any declared field may appear."""
+    flat = " ".join(expr.split())
+    if re.search(r"[()]", re.sub(r"'[^']*'|\"[^\"]*\"", "", flat)):
+        raise ValueError(f"unsupported selection criterion (parentheses): {expr!r}")
+    clauses = []
+    for alt in _split_outside(flat, "or"):
+        terms = []
+        for part in _split_outside(alt, "and"):
+            m = _TERM.match(part)
+            if not m:
+                raise ValueError(f"unsupported selection criterion: {part!r}")
+            field, op, rhs = m.group(1), " ".join(m.group(2).lower().split()), m.group(3)
+            if op in ("in", "not in"):
+                inner = rhs.strip()
+                if not (inner.startswith("[") and inner.endswith("]")):
+                    raise ValueError(f"unsupported list literal: {rhs!r}")
+                try:
+                    val: Any = [_literal(x) for x in inner[1:-1].split(",") if x.strip()]
+                except ValueError:
+                    raise ValueError(f"unsupported literal in: {part!r}") from None
+            else:
+                try:
+                    val = _literal(rhs)
+                except ValueError:
+                    raise ValueError(f"unsupported literal in: {part!r}") from None
+                if op in ("<", "<=", ">", ">=") and (isinstance(val, bool) or not isinstance(val, int)):
+                    raise ValueError(f"unsupported comparison: {part!r}")
+            terms.append((field, op, val))
+        clauses.append(terms)
+
+    def holds(player: Dict[str, Any], field: str, op: str, val: Any) -> bool:
+        have = player.get(field)
+        if op in ("==", "!="):
+            return (have == val and type(have) is type(val)) != (op == "!=")
+        if op in ("in", "not in"):
+            return any(have == v and type(have) is type(v) for v in val) != (op == "not in")
+        if isinstance(have, bool) or not isinstance(have, (int, float)):
+            return False
+        return {"<": have < val, "<=": have <= val, ">": have > val, ">=": have >= val}[op]
 
     def pred(player: Dict[str, Any]) -> bool:
-        for field, op, val in terms:
-            have = player.get(field)
-            ok = (have in val) if op == "in" else (have == val)
-            if op == "!=":
-                ok = not ok
-            if not ok:
-                return False
-        return True
+        return any(all(holds(player, f, o, v) for f, o, v in terms) for terms in clauses)
 
     return pred
 

@@ -119,6 +119,16 @@ def test_criteria_language():
     assert compile_criteria("player.team != 'werewolves'")({"team": "villagers"})
     with pytest.raises(ValueError):
         compile_criteria("len(players) > 3")
+    # the rest of the grammar: or, not in, numeric comparisons over any declared field
+    q = compile_criteria("player.team == 'werewolves' and player.is_alive == true or player.selected_target_id >= 3 and player.role not in ['Doctor', 'Detective']")
+    assert q({"team": "werewolves", "is_alive": True, "selected_target_id": 0, "role": "Werewolf"})
+    assert q({"team": "villagers", "is_alive": True, "selected_target_id": 5, "role": "Villager"})
+    assert not q({"team": "villagers", "is_alive": True, "selected_target_id": 5, "role": "Doctor"})
+    assert not q({"team": "villagers", "is_alive": True, "selected_target_id": 2, "role": "Villager"})
+    assert compile_criteria("player.total_score < 2 or player.name in ['Ann or Bob', 'Cy']")({"total_score": 7, "name": "Ann or Bob"})
+    for bad in ("(player.is_alive == true)", "player.is_alive > true", "player.x in 3", "player.x == maybe"):
+        with pytest.raises(ValueError):
+            compile_criteria(bad)
 
 
 def test_audience_groups_follow_the_dsl(dsl_ww):
@@ -208,6 +218,20 @@ def test_js_ui_script_equals_python(dsl_ww, dsl_tt, tmp_path):
         cases.append({"dsl": dsl, "state": st, "opts": {"act": 0}, "want": ui_tool_calls(dsl, st, tb)})      # defaults: no items -> no exemptList
     inp = tmp_path / "cases.json"
     inp.write_text(json.dumps(cases))
+    # the criteria language itself, on synthetic players
+    import itertools
+    exprs = ["player.team == 'werewolves' and player.is_alive == true or player.selected_target_id >= 3 and player.role not in ['Doctor', 'Detective']",
+             "player.total_score < 2 or player.name in ['Ann or Bob', 'Cy']", "player.is_alive != false and player.selected_target_id in [0, 2, 4]",
+             "player.role in ['Werewolf'] or player.can_vote == false", "player.selected_target_id <= 1 and player.team != 'villagers'"]
+    players = [dict(zip(("team", "is_alive", "selected_target_id", "role", "total_score", "name", "can_vote"), v)) for v in itertools.product(
+        ("werewolves", "villagers"), (True, False), (0, 2, 5), ("Werewolf", "Doctor", "Villager"), (1, 3), ("Ann or Bob", "Dee"), (True, False))]
+    crit = [{"expr": e, "want": [compile_criteria(e)(p) for p in players]} for e in exprs]
+    (tmp_path / "crit.json").write_text(json.dumps({"players": players, "crit": crit}))
+    js0 = ("const {compileCriteria}=require(process.argv[1]);const d=JSON.parse(require('fs').readFileSync(process.argv[2],'utf8'));"
+           "let bad=0;d.crit.forEach((c)=>{const f=compileCriteria(c.expr);d.players.forEach((p,i)=>{if(f(p)!==c.want[i])bad++;});});console.log(bad);")
+    out0 = subprocess.run(["node", "-e", js0, os.path.join(ROOT, "game_engine_amd", "node", "ui_script.js"), str(tmp_path / "crit.json")],
+                          capture_output=True, text=True, timeout=120)
+    assert out0.returncode == 0 and out0.stdout.strip() == "0", out0.stderr + out0.stdout
     js = ("const {uiToolCalls,validateCall}=require(process.argv[1]);const c=JSON.parse(require('fs').readFileSync(process.argv[2],'utf8'));"
           "let bad=0;c.forEach((x,i)=>{const got=uiToolCalls(x.dsl,x.state,x.opts);"
           "if(JSON.stringify(got)!==JSON.stringify(x.want)||got.some((k)=>validateCall(k).length)){bad++;console.error('case',i,JSON.stringify(got).slice(0,300));}});"
