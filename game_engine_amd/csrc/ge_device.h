@@ -67,6 +67,11 @@ constexpr uint32_t GOLDEN = 0x9E3779B9u;
 #ifndef GE_DEAL_PERIOD
 #define GE_DEAL_PERIOD 16
 #endif
+// werewolf N <= 8: a queue slot returns its result with ONE LDS atomic (the choice into the actor's nibble); the room derives
+// who acted from the non-zero nibbles instead of receiving a second, go-mask atomic
+#ifndef GE_ONE_ATOMIC
+#define GE_ONE_ATOMIC 1
+#endif
 
 // ---- POLICY.md §RNG: stateless 32-bit counter hash
 GE_HD uint32_t mix32(uint32_t x) {
@@ -249,19 +254,24 @@ struct Stamps {
     __device__ __forceinline__ void mark(int k) { const unsigned long long now = __builtin_amdgcn_s_memtime(); acc[k] += now - last; last = now; }
 };
 
-// candidate choice of one bot action (POLICY.md §3); shared by the per-lane loop and the queue
+// candidate choice of one bot action (POLICY.md §3); shared by the per-lane loop and the queue.
+// Written as mask arithmetic (sel = b ^ ((a ^ b) & -cond)), not ?: chains: the compiler turned some of those into
+// exec-mask regions, each a pair of scalar instructions and a branch that a lone wavefront pays in full.
+__device__ __forceinline__ uint32_t sel32(bool c, uint32_t a, uint32_t b) { return b ^ ((a ^ b) & (0u - (uint32_t)c)); }
+
 template <int NB, bool TABLE>
 __device__ __forceinline__ uint32_t ww_choose(uint32_t act, uint32_t i, uint32_t d, uint32_t alive, uint32_t team_w,
                                               uint32_t known, uint32_t lo_kw, uint32_t r_det, const uint8_t *nth8) {
     const uint32_t me = 1u << i;
     const uint32_t others = alive & ~me, non_wolf = alive & ~team_w;
-    uint32_t cand = alive;                                    // ACT_DOCTOR_PROTECT
-    cand = act == ACT_WOLF_TARGET ? non_wolf : cand;
     const uint32_t fresh = others & ~known;
-    cand = act == ACT_DETECTIVE ? (fresh ? fresh : others) : cand;
-    const uint32_t vote = (team_w & me) ? non_wolf : (((r_det & me) && lo_kw) ? lo_kw : others);
-    cand = act == ACT_DAY_VOTE ? vote : cand;
-    cand = cand ? cand : alive;
+    const uint32_t det_c = sel32(fresh != 0u, fresh, others);                       // ACT_DETECTIVE
+    const uint32_t vote = sel32((team_w & me) != 0u, non_wolf, sel32((r_det & me) != 0u && lo_kw != 0u, lo_kw, others));   // ACT_DAY_VOTE
+    uint32_t cand = alive;                                                          // ACT_DOCTOR_PROTECT
+    cand = sel32(act == ACT_WOLF_TARGET, non_wolf, cand);
+    cand = sel32(act == ACT_DETECTIVE, det_c, cand);
+    cand = sel32(act == ACT_DAY_VOTE, vote, cand);
+    cand = sel32(cand != 0u, cand, alive);
     const uint32_t idx = pick(d, popc(cand));
     return (TABLE ? nth_set_bit_lds<NB>(nth8, cand, idx) : nth_set_bit<NB>(cand, idx)) + 1u;
 }
@@ -385,6 +395,7 @@ __device__ __forceinline__ void ww_turn(WWR<NB> &s, DevRow &row, const DevRow *r
     using nib_t = typename WWR<NB>::nib_t;
     using R = WWR<NB>;
     constexpr bool ORD = GE_ORD && NB <= 8;                    // queue slots find their player through the ord8 table
+    constexpr bool ONE = GE_ONE_ATOMIC && NB <= 8;             // one result atomic per slot
     constexpr bool SHADOW = GE_SHADOW && (LOWOCC || (GE_SHADOW_HI && NB <= 8));   // action-independent work inside the queue's LDS round trips
     auto *lw = static_cast<typename WaveLdsOf<LOWOCC>::type *>(wave_lds);
     const uint32_t ALL = (1u << n) - 1u;
@@ -581,14 +592,14 @@ __device__ __forceinline__ void ww_turn(WWR<NB> &s, DevRow &row, const DevRow *r
                             atomicOr(r + 1 + (i >> 3), go ? (c << (4u * (i & 7u))) : 0u);
                         } else if (go) {
                             uint32_t *r = reinterpret_cast<uint32_t *>(&lw->res[L]);
-                            atomicOr(r, 1u << i);
+                            if (!ONE) atomicOr(r, 1u << i);
                             atomicOr(r + 1 + (i >> 3), c << (4u * (i & 7u)));
                         }
                     } else if (go) {
                         const uint32_t c = ww_choose<NB, true>(c4.x >> 28, i, d, c4.x & 0xFFFFu, (c4.x >> 16) & 0xFFFu,
                                                                know, lokw, know, nth8);
                         uint32_t *r = reinterpret_cast<uint32_t *>(&lw->res[L]);
-                        atomicOr(r, 1u << i);
+                        if (!ONE) atomicOr(r, 1u << i);
                         atomicOr(r + 1 + (i >> 3), c << (4u * (i & 7u)));
                     }
                     if (base + 64u >= total) break;                // wave-uniform
@@ -611,6 +622,11 @@ __device__ __forceinline__ void ww_turn(WWR<NB> &s, DevRow &row, const DevRow *r
                 if (GE_STAMPS && stamps) { asm volatile("" :: "v"(newly)); stamps->mark(2); }                 // [.. results in registers]
                 const nib_t got = NB > 8 ? (nib_t)(((uint64_t)r.z << 32) | r.y) : (nib_t)r.y;
                 const nib_t m15 = nib_nonzero(got);              // c >= 1, so a nibble is set iff that player acted
+                if (ONE) {                                       // bit i = nibble i is non-zero
+                    uint32_t x = (uint32_t)m15 & 0x11111111u;
+                    x = (x | (x >> 3)) & 0x03030303u; x = (x | (x >> 6)) & 0x000F000Fu;
+                    newly = (x | (x >> 12)) & 0xFFu;
+                }
                 s.choice = (s.choice & ~m15) | got;
                 // RefereeNode (A): record the action (bt:204-225 update_player_state)
                 s.sel = night ? ((s.sel & ~m15) | got) : s.sel;

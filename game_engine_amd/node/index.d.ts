@@ -78,6 +78,14 @@ export class ShardedBatch {
   summary(): Summary;
 }
 export function turnToolCalls(table: GameTable, before: RoomState, after: RoomState, event: TurnEvent): ToolCall[];
+/** What _execute_add_game_note appends: '<mark> <TYPE>: <content>' (backend_tools.py:175-198). */
+export function formatNote(noteType: string, content: string): string;
+/** playerActions / game_notes / phase_history / statements of one room, folded from each turn's tool calls as the reference's _execute_* would. */
+export class RoomLog {
+  constructor(table: GameTable, names: string[], gameName?: string);
+  fold(calls: ToolCall[], after: RoomState, now?: number): void;
+  agentState(room: RoomState): Record<string, unknown>;
+}
 export function loadDslByGamename(gamename: string, gamesDir?: string): object;
 export function deviceCount(): number;
 /** route.ts:62-70 file matching (case-insensitive, non-alphanumerics equal '-') */
@@ -88,5 +96,8 @@ export function initializePlayers(dsl: object, roomPlayers: RoomPlayer[]): { pla
 export function compileCriteria(expr: string): (player: Record<string, unknown>) => boolean;
 export function audienceGroups(dsl: object, playerStates: Record<string, Record<string, unknown>>): Record<string, string[]>;
 export interface FrontendToolCall { name: string; args: { audience_type?: boolean; audience_ids?: string[]; [k: string]: unknown }; }
-/** Frontend tool calls of the room's current phase (ActionExecutor / UIUpdateNode without an LLM). */
-export function uiToolCalls(dsl: object, room: RoomState): FrontendToolCall[];
+/** Frontend tool calls of the room's current phase (ActionExecutor / UIUpdateNode without an LLM): every parameter the
+ * handler requires (frontend_tools.json), nothing it does not declare. */
+export function uiToolCalls(dsl: object, room: RoomState, opts?: { table?: GameTable; act?: number; turn?: number; deaths?: string[];
+  items?: { id: string; type: string }[] }): FrontendToolCall[];
+export function validateCall(call: FrontendToolCall): string[];

@@ -13,10 +13,11 @@ export interface AgentStateView {
 export interface TurnResult { state: AgentStateView; toolCalls: ToolCall[]; uiCalls: FrontendToolCall[]; }
 export class RoomService {
   constructor(opts?: { gamesDir?: string; seed?: bigint | number; device?: number });
-  createRoom(opts: { threadId: string; gameName: string; players: RoomPlayer[]; dsl?: object }): AgentStateView;
+  createRoom(opts: { threadId: string; gameName: string; players: RoomPlayer[]; dsl?: object; /** global room index the RNG is keyed by (default: hash of the thread id) */ roomIndex?: number | bigint }): AgentStateView;
   /** Requests of one thread are served strictly one after the other. */
   humanAction(threadId: string, playerId: number, choice: number): Promise<AgentStateView>;
-  continueRoom(threadId: string): Promise<TurnResult>;
+  /** items: the frontend's canvas items (AgentState.items), for clearCanvas's exemptList */
+  continueRoom(threadId: string, items?: { id: string; type: string }[]): Promise<TurnResult>;
   /** Forget a thread and free its device memory; resolves false for an unknown thread. */
   close(threadId: string): Promise<boolean>;
   serve(port?: number): Promise<import('http').Server>;
