@@ -72,6 +72,15 @@ constexpr uint32_t GOLDEN = 0x9E3779B9u;
 #ifndef GE_ONE_ATOMIC
 #define GE_ONE_ATOMIC 1
 #endif
+// more of the lone-wavefront build's exec-mask regions turned into data flow (profiles/r02_ab_sel_pin.txt): the victim /
+// protection selects of a resolution (GE_SEL_RESOLVE: no effect, off); the choice computed outside the `acts this turn`
+// region of a queue slot (GE_PIN_CHOICE: Werewolf x 12 1.787 -> 1.751 us/turn at 65 536 rooms, x 8 1.313 -> 1.327: on for N > 8)
+#ifndef GE_SEL_RESOLVE
+#define GE_SEL_RESOLVE 0
+#endif
+#ifndef GE_PIN_CHOICE
+#define GE_PIN_CHOICE 1
+#endif
 
 // ---- POLICY.md §RNG: stateless 32-bit counter hash
 GE_HD uint32_t mix32(uint32_t x) {
@@ -265,13 +274,25 @@ __device__ __forceinline__ uint32_t ww_choose(uint32_t act, uint32_t i, uint32_t
     const uint32_t me = 1u << i;
     const uint32_t others = alive & ~me, non_wolf = alive & ~team_w;
     const uint32_t fresh = others & ~known;
-    const uint32_t det_c = sel32(fresh != 0u, fresh, others);                       // ACT_DETECTIVE
-    const uint32_t vote = sel32((team_w & me) != 0u, non_wolf, sel32((r_det & me) != 0u && lo_kw != 0u, lo_kw, others));   // ACT_DAY_VOTE
-    uint32_t cand = alive;                                                          // ACT_DOCTOR_PROTECT
-    cand = sel32(act == ACT_WOLF_TARGET, non_wolf, cand);
-    cand = sel32(act == ACT_DETECTIVE, det_c, cand);
-    cand = sel32(act == ACT_DAY_VOTE, vote, cand);
-    cand = sel32(cand != 0u, cand, alive);
+    uint32_t cand;
+    if (!TABLE) {
+        // lone-wavefront build: mask arithmetic (profiles/r02_ab_choose_one_atomic.txt: C2 1.383 -> 1.331 us/turn; the
+        // large-batch build loses 2 % with it and keeps the ?: form)
+        const uint32_t det_c = sel32(fresh != 0u, fresh, others);                       // ACT_DETECTIVE
+        const uint32_t vote = sel32((team_w & me) != 0u, non_wolf, sel32((r_det & me) != 0u && lo_kw != 0u, lo_kw, others));   // ACT_DAY_VOTE
+        cand = alive;                                                                   // ACT_DOCTOR_PROTECT
+        cand = sel32(act == ACT_WOLF_TARGET, non_wolf, cand);
+        cand = sel32(act == ACT_DETECTIVE, det_c, cand);
+        cand = sel32(act == ACT_DAY_VOTE, vote, cand);
+        cand = sel32(cand != 0u, cand, alive);
+    } else {
+        cand = alive;                                                                   // ACT_DOCTOR_PROTECT
+        cand = act == ACT_WOLF_TARGET ? non_wolf : cand;
+        cand = act == ACT_DETECTIVE ? (fresh ? fresh : others) : cand;
+        const uint32_t vote = (team_w & me) ? non_wolf : (((r_det & me) && lo_kw) ? lo_kw : others);
+        cand = act == ACT_DAY_VOTE ? vote : cand;
+        cand = cand ? cand : alive;
+    }
     const uint32_t idx = pick(d, popc(cand));
     return (TABLE ? nth_set_bit_lds<NB>(nth8, cand, idx) : nth_set_bit<NB>(cand, idx)) + 1u;
 }
@@ -395,7 +416,7 @@ __device__ __forceinline__ void ww_turn(WWR<NB> &s, DevRow &row, const DevRow *r
     using nib_t = typename WWR<NB>::nib_t;
     using R = WWR<NB>;
     constexpr bool ORD = GE_ORD && NB <= 8;                    // queue slots find their player through the ord8 table
-    constexpr bool ONE = GE_ONE_ATOMIC && NB <= 8;             // one result atomic per slot
+    constexpr bool ONE = GE_ONE_ATOMIC && NB <= 8 && LOWOCC;   // one result atomic per slot (C2 1.331 -> 1.312 us/turn; the large-batch build loses 1.4 %)
     constexpr bool SHADOW = GE_SHADOW && (LOWOCC || (GE_SHADOW_HI && NB <= 8));   // action-independent work inside the queue's LDS round trips
     auto *lw = static_cast<typename WaveLdsOf<LOWOCC>::type *>(wave_lds);
     const uint32_t ALL = (1u << n) - 1u;
@@ -583,8 +604,9 @@ __device__ __forceinline__ void ww_turn(WWR<NB> &s, DevRow &row, const DevRow *r
                     if (LOWOCC) {
                         // the choice is computed for every slot and only the result is predicated: a
                         // conditional block would split the slot read in two dependent LDS round trips
-                        const uint32_t c = ww_choose<NB, false>(c4.x >> 28, i, d, c4.x & 0xFFFFu, (c4.x >> 16) & 0xFFFu,
-                                                                know, lokw, know, nth8);
+                        uint32_t c = ww_choose<NB, false>(c4.x >> 28, i, d, c4.x & 0xFFFFu, (c4.x >> 16) & 0xFFFu,
+                                                          know, lokw, know, nth8);
+                        if (GE_PIN_CHOICE && NB > 8) asm volatile("" : "+v"(c));   // stays outside the exec-masked block below
                         if (GE_GO_BRANCHLESS) {
                             // every slot ORs into its room's result (L is a lane index even for a stale slot), zeros if it does not act
                             uint32_t *r = reinterpret_cast<uint32_t *>(&lw->res[L]);
@@ -679,8 +701,14 @@ __device__ __forceinline__ void ww_turn(WWR<NB> &s, DevRow &row, const DevRow *r
         const uint32_t victim = plurality<NB, nib_t>(day ? s.choice : s.sel, voters);
         const uint32_t docs = alive & s.template get<F_DOC>();
         const uint32_t guarded = (uint32_t)(s.sel >> (4u * (31u - (uint32_t)__clz((int)(docs | 1u))))) & 15u;
-        const uint32_t protect = (!day && docs) ? guarded : 0u;
-        const uint32_t bit = (on && victim != 0u && victim != protect) ? (1u << ((victim - 1u) & 15u)) : 0u;
+        uint32_t protect, bit;
+        if (LOWOCC && GE_SEL_RESOLVE) {                        // data flow, no exec-mask region (see ww_choose)
+            protect = guarded & (0u - (uint32_t)(!day && docs != 0u));
+            bit = (1u << ((victim - 1u) & 15u)) & (0u - (uint32_t)(on && victim != 0u && victim != protect));
+        } else {
+            protect = (!day && docs) ? guarded : 0u;
+            bit = (on && victim != 0u && victim != protect) ? (1u << ((victim - 1u) & 15u)) : 0u;
+        }
         s.template clear<F_ALIVE>(bit); s.template clear<F_CAN_VOTE>(bit); s.template clear<F_ELIG>(bit);
         s.template set<F_REVEALED>(bit);
     };
