@@ -81,6 +81,14 @@ constexpr uint32_t GOLDEN = 0x9E3779B9u;
 #ifndef GE_PIN_CHOICE
 #define GE_PIN_CHOICE 1
 #endif
+// GE_SEL_OPEN: the completion test without short-circuit evaluation (&& / || had become three nested exec-mask regions):
+// C2 1.308 -> 1.282 us/turn (profiles/r02_ab_open_tpldeal.txt); GE_SEL_NEED: the same for the fallback-deal test, no effect
+#ifndef GE_SEL_OPEN
+#define GE_SEL_OPEN 1
+#endif
+#ifndef GE_SEL_NEED
+#define GE_SEL_NEED 0
+#endif
 
 // ---- POLICY.md §RNG: stateless 32-bit counter hash
 GE_HD uint32_t mix32(uint32_t x) {
@@ -403,7 +411,9 @@ template <int NB> __device__ __forceinline__ uint32_t tt_cond_generic(const TT<N
 // LOWOCC: the launch has fewer than ~3 wavefronts per SIMD (e.g. 65 536 rooms): a lone wavefront
 // stalls on every branch instruction and every dependent LDS access, so that build is branch-lean
 // and computes; the other build (many wavefronts, VALU-bound) prefers LDS tables and skip-branches.
-template <int NB, bool QUEUE, bool LOWOCC, bool GENERIC = false>
+// DEAL: 1 / 0 = this instantiation is for the turns that do / do not prepare role deals (the lone-wavefront build compiles
+// the turn twice rather than test a wave-uniform flag inside an exec-mask region every turn); 2 = `deal_now` decides
+template <int NB, bool QUEUE, bool LOWOCC, bool GENERIC = false, int DEAL = 2>
 __device__ __forceinline__ void ww_turn(WWR<NB> &s, DevRow &row, const DevRow *rows, const DevCond *conds, void *wave_lds, const uint8_t *nth8, const uint32_t *ord8, bool valid, uint32_t n,
                                         uint32_t nw, uint32_t phase0_idx, uint32_t rkey, uint32_t turn, uint32_t &tk_io,
                                         bool trace, uint32_t human, Deal &deal, bool deal_now, uint32_t &ev_newly, uint64_t &ev_choice, Stamps *stamps = nullptr) {
@@ -482,7 +492,7 @@ __device__ __forceinline__ void ww_turn(WWR<NB> &s, DevRow &row, const DevRow *r
     // the role-assignment values of the prepared deal (what `assign` writes), also shadow work
     R dealt;
     auto deal_precompute = [&]() {
-        if (deal_now && !deal.valid) {
+        if ((DEAL == 2 ? deal_now : DEAL == 1) && !deal.valid) {
             // this game already has roles: prepare the next game's
             const bool has_roles = (NB <= 8 ? s.W[2] : (s.W[R::NW - 2] | s.W[R::NW - 1])) != 0u;
             const uint32_t g = has_roles ? (s.games < 0xFFFFu ? s.games + 1u : s.games) : s.games;
@@ -681,8 +691,15 @@ __device__ __forceinline__ void ww_turn(WWR<NB> &s, DevRow &row, const DevRow *r
     // ---- PhaseNode: phase-0 guard (v2:1025-1052): first turn only records phase 0, Referee skipped;
     // completion: every target player has acted in this visit
     s.flags |= FLAG_PHASE0_DONE;                               // set by the guard turn; already set afterwards
-    const bool open = pre_open && (comp != COMP_ACTION || (T & ~s.acted) == 0u);
-    const uint32_t qe = open ? qe_cand : s.phase;
+    uint32_t qe;
+    if (LOWOCC && GE_SEL_OPEN) {
+        // no short-circuit evaluation: && / || became three nested exec-mask regions here (see ww_choose)
+        const uint32_t open = (uint32_t)pre_open & ((uint32_t)(comp != COMP_ACTION) | (uint32_t)((T & ~s.acted) == 0u));
+        qe = sel32(open != 0u, qe_cand, s.phase);
+    } else {
+        const bool open = pre_open && (comp != COMP_ACTION || (T & ~s.acted) == 0u);
+        qe = open ? qe_cand : s.phase;
+    }
     const uint32_t q = qe & 31u;
     {   // investigated_alignments[c] = team(c): an assignment, so a stale entry is replaced
         // (the guard turn has no actions: both masks are 0)
@@ -715,7 +732,10 @@ __device__ __forceinline__ void ww_turn(WWR<NB> &s, DevRow &row, const DevRow *r
     // role assignment: the deal of this game was normally prepared ahead (run loop, every 8th turn, for
     // all lanes of the wavefront at once); fall back to dealing here if it was not
     const bool is_assign = eff == EFF_ASSIGN_ROLES;
-    if (GE_UNLIKELY ? __builtin_expect(is_assign && !(deal.valid && deal.game == s.games), 0) : (is_assign && !(deal.valid && deal.game == s.games))) {
+    // (bitwise, not && : one exec-mask region instead of two nested ones in the lone-wavefront build)
+    const bool deal_missing = GE_SEL_NEED ? (bool)((uint32_t)is_assign & ((uint32_t)(deal.valid == 0u) | (uint32_t)(deal.game != s.games)))
+                                          : (is_assign && !(deal.valid && deal.game == s.games));
+    if (GE_UNLIKELY ? __builtin_expect(deal_missing, 0) : deal_missing) {
         deal_roles<NB, LOWOCC>(deal, deal_key(rkey, s.games), s.games, n, nw, nth8);
         deal_precompute();
     }

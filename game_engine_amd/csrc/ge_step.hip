@@ -33,6 +33,13 @@ constexpr uint32_t LDS_ORD8 = 1024;
 #define GE_WAVE_QUEUE true
 #endif
 
+// the lone-wavefront build could compile the turn once for the turns that prepare role deals and once for those that do
+// not (no per-turn test of the wave-uniform flag): measured 1.281 -> 1.362 us/turn at C2 (profiles/r02_ab_open_tpldeal.txt;
+// the two copies disagree on registers and pay moves at the join, 90 -> 118 VGPRs): off
+#ifndef GE_TPL_DEAL
+#define GE_TPL_DEAL 0
+#endif
+
 enum Kind { K_WW8 = 0, K_WW12, K_TT4, K_TT8, K_TT12, K_COUNT };
 
 struct SegDev {
@@ -177,9 +184,17 @@ __device__ __forceinline__ void run_ww(const SegDev *__restrict__ sgp, const Ste
             const uint32_t p = s.phase;
             uint32_t ev_newly = 0;
             uint64_t ev_choice = 0;
-            ww_turn<NB, GE_WAVE_QUEUE, LOWOCC, GENERIC>(s, row, rows, tables[sg.table_idx].conds, lw, nth8, ord8, valid, sg.n_players, sg.nw, sg.phase0_idx, rk, turn0 + t, tk,
-                                       trace, sg.human_mask, deal, ahead && (t & (GE_DEAL_PERIOD - 1u)) == 0u, ev_newly, ev_choice,
-                                       (GE_STAMPS && a.stamps) ? &stamps : nullptr);
+            const bool deal_now = ahead && (t & (GE_DEAL_PERIOD - 1u)) == 0u;        // wave-uniform
+            Stamps *const stp = (GE_STAMPS && a.stamps) ? &stamps : nullptr;
+            if (LOWOCC && GE_TPL_DEAL) {                                              // two copies of the turn, a scalar branch between them
+                if (deal_now) ww_turn<NB, GE_WAVE_QUEUE, LOWOCC, GENERIC, 1>(s, row, rows, tables[sg.table_idx].conds, lw, nth8, ord8, valid, sg.n_players, sg.nw, sg.phase0_idx, rk, turn0 + t, tk,
+                                                                              trace, sg.human_mask, deal, true, ev_newly, ev_choice, stp);
+                else ww_turn<NB, GE_WAVE_QUEUE, LOWOCC, GENERIC, 0>(s, row, rows, tables[sg.table_idx].conds, lw, nth8, ord8, valid, sg.n_players, sg.nw, sg.phase0_idx, rk, turn0 + t, tk,
+                                                                    trace, sg.human_mask, deal, false, ev_newly, ev_choice, stp);
+            } else {
+                ww_turn<NB, GE_WAVE_QUEUE, LOWOCC, GENERIC, 2>(s, row, rows, tables[sg.table_idx].conds, lw, nth8, ord8, valid, sg.n_players, sg.nw, sg.phase0_idx, rk, turn0 + t, tk,
+                                                               trace, sg.human_mask, deal, deal_now, ev_newly, ev_choice, stp);
+            }
             if (trace && valid) store_event(sg.trace, sg.rooms_padded, t, room, turn0 + t, p, s.phase, restarted, ev_newly, ev_choice);
         }
     };
