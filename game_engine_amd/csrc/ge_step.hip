@@ -863,12 +863,13 @@ static int fill_args(const ge_batch *b, StepArgs &a, uint32_t turn0, uint32_t n_
     a.block_threads = b->block_threads;
     a.restart = (b->flags & GE_FLAG_RESTART) ? 1u : 0u;
     a.trace = (b->flags & GE_FLAG_TRACE) ? 1u : 0u;
-    // at most ~1 wavefront per SIMD on 256 CUs -> the branch-lean build (ge_device.h LOWOCC); from two
-    // wavefronts per SIMD on the other build is faster (measured: 131 072 rooms 1.87 vs 1.99 us/turn).
+    // up to one wavefront per SIMD (1 024 SIMDs x 64 rooms) -> the branch-lean lone-wavefront build (ge_device.h LOWOCC):
+    // 65 536 rooms 1.283 vs 1.372 us/turn; from the first SIMD with two wavefronts on the large-batch build is as fast or
+    // faster (69 632 rooms 1.680 vs 1.668, 131 072: 1.791 vs 1.738; tools/threshold_probe.sh, profiles/r02_threshold.txt).
     // GE_LOWOCC_ROOMS overrides the threshold (tuning / A-B runs)
     static const uint64_t low_rooms = [] {
         const char *e = getenv("GE_LOWOCC_ROOMS");
-        return e ? strtoull(e, nullptr, 10) : (uint64_t)(1024u * 64u * 3u / 2u);
+        return e ? strtoull(e, nullptr, 10) : (uint64_t)(1024u * 64u + 1u);
     }();
     a.lowocc = b->n_rooms < low_rooms ? 1u : 0u;
     a.stamps = b->stamps_dev;
