@@ -8,8 +8,8 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libge_step.so")
 
-GE_MAX_PHASES, GE_MAX_SEGMENTS, GE_NAME_LEN = 32, 4, 64
-GE_ABI_VERSION = 2
+GE_MAX_PHASES, GE_MAX_SEGMENTS, GE_NAME_LEN, GE_MAX_SLOTS = 32, 4, 64, 12
+GE_ABI_VERSION = 3
 
 
 class Literal(C.Structure):
@@ -29,7 +29,8 @@ class PhaseRow(C.Structure):
 class Table(C.Structure):
     _fields_ = [("abi_version", C.c_int32), ("pack", C.c_int32), ("n_phases", C.c_int32),
                 ("rounds", C.c_int32), ("min_players", C.c_int32), ("init_fields", C.c_uint8 * 12),
-                ("role_names", (C.c_char * GE_NAME_LEN) * 5), ("rows", PhaseRow * GE_MAX_PHASES)]
+                ("role_names", (C.c_char * GE_NAME_LEN) * 5), ("field_names", (C.c_char * GE_NAME_LEN) * GE_MAX_SLOTS),
+                ("rows", PhaseRow * GE_MAX_PHASES)]
 
 
 class SegmentDesc(C.Structure):

@@ -201,12 +201,47 @@ bool truthy(const JVal *v) {
 int as_int(const JVal *v) { return v && v->type == JVal::NUM ? (int)v->num : 0; }
 std::string as_str(const JVal *v) { return v && v->type == JVal::STR ? v->str : std::string(); }
 
-// base predicate index of `player.<field> == <value>` inside a pack, -1 if the pack has none
+// The packs' state slots and the declared names each binds to (first = canonical); include/ge_step.h GE_WW_* / GE_TT_*.
+const char *const WW_SLOT_NAMES[GE_WW_SLOTS][3] = {
+    {"role"}, {"team"}, {"is_alive"}, {"role_revealed"}, {"can_vote"}, {"has_secret_role"},
+    {"night_action_eligible", "has_night_action"}, {"night_action_submitted"}, {"selected_target_id"},
+    {"investigated_alignments", "known_alignments"}, {"wolf_chat_enabled"}};
+const char *const TT_SLOT_NAMES[GE_TT_SLOTS][3] = {
+    {"is_speaker"}, {"statements_submitted"}, {"lie_index"}, {"lie_revealed"}, {"can_vote"}, {"vote_choice"},
+    {"has_voted"}, {"total_score"}, {"rounds_as_speaker"}, {"statements"}};
+
+// which declared field each slot of the pack is (declaration.player_states decides; "" = not declared)
+struct Binding {
+    int pack = 0, n = 0;
+    std::string declared[GE_MAX_SLOTS];
+    const char *canonical(int slot) const { return pack == GE_PACK_WEREWOLF ? WW_SLOT_NAMES[slot][0] : TT_SLOT_NAMES[slot][0]; }
+    void bind(int pack_, const JVal *ps_def) {
+        pack = pack_;
+        n = pack == GE_PACK_WEREWOLF ? (int)GE_WW_SLOTS : (int)GE_TT_SLOTS;
+        for (int s = 0; s < n; s++) {
+            const char *const *names = pack == GE_PACK_WEREWOLF ? WW_SLOT_NAMES[s] : TT_SLOT_NAMES[s];
+            for (int k = 0; k < 3 && names[k] && declared[s].empty(); k++)
+                if (ps_def && ps_def->get(names[k])) declared[s] = names[k];
+        }
+    }
+    // canonical slot name of a declared field, "" if the field is not a slot of the pack
+    std::string slot_of(const std::string &field) const {
+        for (int s = 0; s < n; s++) if (!declared[s].empty() && declared[s] == field) return canonical(s);
+        return std::string();
+    }
+    const JVal *get(const JVal *obj, int slot) const { return obj && !declared[slot].empty() ? obj->get(declared[slot].c_str()) : nullptr; }
+};
+
+// base predicate index of `player.<slot> == <value>` inside a pack (canonical slot names), -1 if the pack has none
 int base_of(int pack, const std::string &field, const std::string &sval, bool is_str) {
     if (pack == GE_PACK_WEREWOLF) {
         static const char *bools[] = {"is_alive", "can_vote", "role_revealed", "has_secret_role",
                                       "night_action_eligible", "night_action_submitted"};
-        if (!is_str) { for (int i = 0; i < 6; i++) if (field == bools[i]) return i; return -1; }
+        if (!is_str) {
+            for (int i = 0; i < 6; i++) if (field == bools[i]) return i;
+            if (field == "wolf_chat_enabled") return 7;             // derived slot: set with the team, never again
+            return -1;
+        }
         if (field == "team") { if (sval == "villagers") return 6; if (sval == "werewolves") return 7; return -1; }
         if (field == "role") return 7 + role_class(sval);
         return -1;
@@ -324,12 +359,13 @@ int const_term(const JVal &have, const std::string &op, const std::vector<Atom> 
 }
 
 // one term -> the literals it stands for (several = an OR, for a numeric `in` over a list with gaps)
-int parse_term(int pack, const JVal *tmpl, const std::string &part, std::vector<ge_literal> &options, std::string &why) {
+int parse_term(const Binding &bind, const JVal *tmpl, const std::string &part, std::vector<ge_literal> &options, std::string &why) {
+    const int pack = bind.pack;
     std::string p = squeeze(part);
     if (p.compare(0, 7, "player.") != 0) { why = "unsupported condition term: " + p; return -1; }
     size_t i = 7;
     while (i < p.size() && (isalnum((unsigned char)p[i]) || p[i] == '_')) i++;
-    const std::string field = p.substr(7, i - 7);
+    std::string field = p.substr(7, i - 7);
     while (i < p.size() && p[i] == ' ') i++;
     std::string rest = p.substr(i), lrest = lower(rest), op;
     for (const char *cand : {"==", "!=", "<=", ">=", "<", ">", "not in ", "in "})
@@ -365,8 +401,10 @@ int parse_term(int pack, const JVal *tmpl, const std::string &part, std::vector<
         vals.push_back(a);
     }
     const bool neg = op == "!=" || op == "not in";
-    if (!pack_models(pack, field) && tmpl && field != "name") {
-        const JVal *have = tmpl->get(field.c_str());
+    const std::string declared_name = field;
+    field = bind.slot_of(declared_name);                                // from here on: the canonical slot ("" = none)
+    if (!pack_models(pack, field) && tmpl && declared_name != "name") {
+        const JVal *have = tmpl->get(declared_name.c_str());
         if (have && (have->type == JVal::BOOL || (have->type == JVal::NUM && have->num == (double)(long)have->num) || have->type == JVal::STR)) {
             const int holds = const_term(*have, op, vals);
             if (holds < 0) { why = "unsupported comparison on a non-numeric field: " + p; return -1; }
@@ -438,7 +476,7 @@ int parse_term(int pack, const JVal *tmpl, const std::string &part, std::vector<
 }
 
 // the whole condition -> row.clause[][] (+ term_base / term_neg and generic = 0 when it is a plain conjunction)
-int parse_condition(int pack, const JVal *tmpl, const std::string &cond_in, ge_phase_row &row, std::string &why) {
+int parse_condition(const Binding &bind, const JVal *tmpl, const std::string &cond_in, ge_phase_row &row, std::string &why) {
     row.n_terms = 0; row.n_clauses = 0; row.generic = 0;
     const std::string cond = squeeze(cond_in);
     if (cond.empty()) return 0;
@@ -455,7 +493,7 @@ int parse_condition(int pack, const JVal *tmpl, const std::string &cond_in, ge_p
         std::vector<Clause> partial(1);
         for (const std::string &part : split_kw(alt, "and")) {
             std::vector<ge_literal> options;
-            if (parse_term(pack, tmpl, part, options, why) != 0) return -1;
+            if (parse_term(bind, tmpl, part, options, why) != 0) return -1;
             std::vector<Clause> next;
             for (auto &c : partial)
                 for (auto &o : options) { Clause x = c; x.push_back(o); next.push_back(x); }
@@ -499,7 +537,8 @@ bool clause_has(const ge_phase_row &r, int c, int base, int neg) {
     return false;
 }
 
-int resolver_for(const std::string &key) {
+// `rows`: the table's phases with their effects, for keys that name a phase ("... follows Dawn Reveal ...")
+int resolver_for(const std::string &key, const ge_phase_row *rows, int n_rows) {
     std::string k = lower(key);
     if (has(k, "no living werewol") || has(k, "all werewolves eliminated")) return GE_RES_WOLVES_ZERO;
     if (has(k, "outnumber")) return GE_RES_WOLVES_GE_VILLAGERS;
@@ -507,6 +546,19 @@ int resolver_for(const std::string &key) {
     if (has(k, "follows a night")) return GE_RES_FOLLOWS_NIGHT;
     if (has(k, "all players have completed")) return GE_RES_ALL_ROUNDS_DONE;
     if (k.compare(0, 9, "otherwise") == 0) return GE_RES_OTHERWISE;
+    const size_t at = k.find("follows");
+    if (at != std::string::npos) {
+        // "follows <phase name>": what matters is which resolution that phase performs; the longest name wins
+        const std::string tail = k.substr(at + 7);
+        int best = -1;
+        size_t best_len = 0;
+        for (int i = 0; i < n_rows; i++) {
+            const std::string nm = lower(rows[i].name);
+            if (!nm.empty() && nm.size() > best_len && has(tail, nm.c_str())) { best = i; best_len = nm.size(); }
+        }
+        if (best >= 0 && rows[best].effect == GE_EFF_DAY_RESOLVE) return GE_RES_FOLLOWS_DAY;
+        if (best >= 0 && rows[best].effect == GE_EFF_NIGHT_RESOLVE) return GE_RES_FOLLOWS_NIGHT;
+    }
     return -1;
 }
 
@@ -533,12 +585,16 @@ static int compile_impl(const char *dsl_json, size_t len, int rounds, ge_game_ta
 
     const JVal *ps_def = decl->get("player_states");
     auto declared = [&](const char *f) { return ps_def && ps_def->get(f) != nullptr; };
-    if (declared("role") && declared("team") && declared("is_alive") && declared("selected_target_id"))
+    if (declared("role") && declared("team") && declared("is_alive"))
         t.pack = GE_PACK_WEREWOLF;
     else if (declared("is_speaker") && declared("lie_index") && declared("vote_choice") && declared("total_score"))
         t.pack = GE_PACK_TWO_TRUTHS;
     else
         return err.set("no rule pack matches declaration.player_states");
+
+    Binding bind;
+    bind.bind(t.pack, ps_def);
+    for (int s = 0; s < bind.n; s++) copy_name(t.field_names[s], bind.declared[s]);
 
     if (t.pack == GE_PACK_WEREWOLF) {
         const JVal *roles = decl->get("roles");
@@ -562,22 +618,23 @@ static int compile_impl(const char *dsl_json, size_t len, int rounds, ge_game_ta
             }
     if (!tmpl || tmpl->type != JVal::OBJ) return err.set("declaration.player_states_template.player_states is missing");
     uint8_t *f = t.init_fields;
+    auto tf = [&](int slot) { return bind.get(tmpl, slot); };          // the template's value of a slot (nullptr: not declared)
     if (t.pack == GE_PACK_WEREWOLF) {
-        std::string role = as_str(tmpl->get("role")), team = as_str(tmpl->get("team"));
+        std::string role = as_str(tf(GE_WW_ROLE)), team = as_str(tf(GE_WW_TEAM));
         f[0] = 0;
         for (int c = 1; c <= 4; c++) if (!role.empty() && role == t.role_names[c]) f[0] = (uint8_t)c;
         f[1] = team == "villagers" ? 1 : team == "werewolves" ? 2 : 0;
-        const JVal *alive = tmpl->get("is_alive");
+        const JVal *alive = tf(GE_WW_IS_ALIVE);
         f[2] = alive ? truthy(alive) : 1;
-        f[3] = truthy(tmpl->get("role_revealed")); f[4] = truthy(tmpl->get("can_vote"));
-        f[5] = truthy(tmpl->get("has_secret_role")); f[6] = truthy(tmpl->get("night_action_eligible"));
-        f[7] = truthy(tmpl->get("night_action_submitted")); f[8] = (uint8_t)as_int(tmpl->get("selected_target_id"));
+        f[3] = truthy(tf(GE_WW_ROLE_REVEALED)); f[4] = truthy(tf(GE_WW_CAN_VOTE));
+        f[5] = truthy(tf(GE_WW_HAS_SECRET_ROLE)); f[6] = truthy(tf(GE_WW_NIGHT_ELIGIBLE));
+        f[7] = truthy(tf(GE_WW_NIGHT_SUBMITTED)); f[8] = (uint8_t)as_int(tf(GE_WW_SELECTED_TARGET));
     } else {
-        f[0] = truthy(tmpl->get("is_speaker")); f[1] = truthy(tmpl->get("statements_submitted"));
-        f[2] = (uint8_t)as_int(tmpl->get("lie_index")); f[3] = truthy(tmpl->get("lie_revealed"));
-        f[4] = truthy(tmpl->get("can_vote")); f[5] = (uint8_t)as_int(tmpl->get("vote_choice"));
-        f[6] = truthy(tmpl->get("has_voted")); f[7] = (uint8_t)as_int(tmpl->get("total_score"));
-        f[8] = (uint8_t)as_int(tmpl->get("rounds_as_speaker"));
+        f[0] = truthy(tf(GE_TT_IS_SPEAKER)); f[1] = truthy(tf(GE_TT_STATEMENTS_SUBMITTED));
+        f[2] = (uint8_t)as_int(tf(GE_TT_LIE_INDEX)); f[3] = truthy(tf(GE_TT_LIE_REVEALED));
+        f[4] = truthy(tf(GE_TT_CAN_VOTE)); f[5] = (uint8_t)as_int(tf(GE_TT_VOTE_CHOICE));
+        f[6] = truthy(tf(GE_TT_HAS_VOTED)); f[7] = (uint8_t)as_int(tf(GE_TT_TOTAL_SCORE));
+        f[8] = (uint8_t)as_int(tf(GE_TT_ROUNDS_AS_SPEAKER));
     }
 
     if (phases->obj.size() > GE_MAX_PHASES) return err.set("too many phases");
@@ -630,7 +687,7 @@ static int compile_impl(const char *dsl_json, size_t len, int rounds, ge_game_ta
                 if (w != "single_player_choice" && w != "all_players_action" && w != "multiple_players_action")
                     return err.set(where + ("unknown wait_for " + w));
             }
-            if (parse_condition(t.pack, tmpl, as_str(tp ? tp->get("condition") : nullptr), row, why) != 0)
+            if (parse_condition(bind, tmpl, as_str(tp ? tp->get("condition") : nullptr), row, why) != 0)
                 return err.set(where + why);
             // the action kind, from the condition: every alternative is classified on its own and all must agree
             if (row.n_clauses == 0) return err.set(where + std::string("cannot classify the player action"));
@@ -640,6 +697,7 @@ static int compile_impl(const char *dsl_json, size_t len, int rounds, ge_game_ta
                     if (clause_has(row, c, 7 + ROLE_WEREWOLF, 0)) act = GE_ACT_WOLF_TARGET;
                     else if (clause_has(row, c, 7 + ROLE_DOCTOR, 0)) act = GE_ACT_DOCTOR_PROTECT;
                     else if (clause_has(row, c, 7 + ROLE_DETECTIVE, 0)) act = GE_ACT_DETECTIVE;
+                    else if (clause_has(row, c, 7, 0)) act = GE_ACT_WOLF_TARGET;          // "all alive werewolves" written by team
                     else if (clause_has(row, c, 1, 0)) act = GE_ACT_DAY_VOTE;
                 } else {
                     if (clause_has(row, c, 0, 1)) act = GE_ACT_TT_VOTE;
@@ -665,6 +723,13 @@ static int compile_impl(const char *dsl_json, size_t len, int rounds, ge_game_ta
             else if (has(lname, "scoring")) row.effect = GE_EFF_TT_SCORE;
         }
 
+    }
+    // branches second: a key may name another phase, whose effect must be known by then
+    for (int i = 0; i < t.n_phases; i++) {
+        const JVal *ph = phases->obj[i].second.get();
+        ge_phase_row &row = t.rows[i];
+        char where[32];
+        snprintf(where, sizeof where, "phase %d: ", ids[i]);
         const JVal *nx = ph->get("next_phase");
         auto add_branch = [&](int res, const JVal *tgt) -> int {
             if (row.n_branches >= GE_MAX_BRANCHES) return -1;
@@ -684,7 +749,7 @@ static int compile_impl(const char *dsl_json, size_t len, int rounds, ge_game_ta
                 if (add_branch(GE_RES_ALWAYS, nx) != 0) return err.set(where + std::string("next_phase id not in phases"));
             } else {
                 for (auto &kv : nx->obj) {
-                    int res = resolver_for(kv.first);
+                    int res = resolver_for(kv.first, t.rows, t.n_phases);
                     if (res < 0) return err.set(where + ("no branch resolver for next_phase key '" + kv.first + "'"));
                     int rc = add_branch(res, kv.second.get());
                     if (rc == -1) return err.set(where + std::string("too many branches"));

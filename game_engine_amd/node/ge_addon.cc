@@ -101,7 +101,7 @@ napi_value CompileTable(napi_env env, napi_callback_info info) {
     return ext;
 }
 
-// tableInfo(table): { pack, rounds, minPlayers, roleNames[], phases:[{id,name,completion,act,effect}] }
+// tableInfo(table): { pack, rounds, minPlayers, roleNames[], fieldNames[], phases:[{id,name,completion,act,effect}] }
 napi_value TableInfo(napi_env env, napi_callback_info info) {
     size_t argc = 1;
     napi_value argv[1];
@@ -120,6 +120,13 @@ napi_value TableInfo(napi_env env, napi_callback_info info) {
         NAPI_OK(napi_set_element(env, roles, i, v));
     }
     NAPI_OK(napi_set_named_property(env, out, "roleNames", roles));
+    napi_value fields;                     // slot (GE_WW_* / GE_TT_*) -> the DSL's own field name, "" = not declared
+    NAPI_OK(napi_create_array_with_length(env, GE_MAX_SLOTS, &fields));
+    for (uint32_t i = 0; i < GE_MAX_SLOTS; i++) {
+        NAPI_OK(napi_create_string_utf8(env, t->field_names[i], NAPI_AUTO_LENGTH, &v));
+        NAPI_OK(napi_set_element(env, fields, i, v));
+    }
+    NAPI_OK(napi_set_named_property(env, out, "fieldNames", fields));
     NAPI_OK(napi_create_array_with_length(env, t->n_phases, &phases));
     for (int i = 0; i < t->n_phases; i++) {
         napi_value ph;

@@ -17,7 +17,10 @@ export interface RoomState {
   previous_phase_id: number;
   end_turn: number;                 // -1 while the game runs
   games: number;
-  player_states: Record<string, WerewolfPlayerState | TwoTruthsPlayerState>;
+  /** exactly the fields the DSL declares, under the DSL's own names (GameTable.info.fieldNames) */
+  player_states: Record<string, WerewolfPlayerState | TwoTruthsPlayerState | Record<string, unknown>>;
+  pack: number;                     // 1 werewolf, 2 two-truths
+  slots: unknown[][];               // per player: one value per slot of the pack (GE_WW_* / GE_TT_* order), declared or not
   acted: number[];                  // this visit's action log, per player
   choice: number[];
 }
@@ -35,7 +38,8 @@ export interface PhaseInfo { id: number; name: string; completion: number; act: 
 export class GameTable {
   constructor(dsl: object, rounds?: number);
   static fromGamename(gamename: string, gamesDir?: string, rounds?: number): GameTable;
-  readonly info: { pack: number; rounds: number; minPlayers: number; roleNames: string[]; phases: PhaseInfo[] };
+  /** fieldNames: slot (include/ge_step.h GE_WW_* / GE_TT_*) -> the DSL's own field name, "" = not declared */
+  readonly info: { pack: number; rounds: number; minPlayers: number; roleNames: string[]; fieldNames: string[]; phases: PhaseInfo[] };
   phaseName(id: number): string;
 }
 export interface Segment { table: GameTable; nPlayers: number; nRooms: number; /** bit i: player i+1 is driven by the host (a human) */ humanMask?: number; }

@@ -99,9 +99,8 @@ class GameTable {
     // declared fields the rule packs do not model: constants from the template (nobody writes them under the fixed policy)
     const tps = ((dsl.declaration || {}).player_states_template || {}).player_states || {};
     const tmpl = tps['1'] || tps[Object.keys(tps)[0]] || {};
-    const modelled = new Set(['name', 'role', 'team', 'is_alive', 'role_revealed', 'can_vote', 'has_secret_role', 'night_action_eligible',
-                              'night_action_submitted', 'selected_target_id', 'investigated_alignments', 'is_speaker', 'statements',
-                              'statements_submitted', 'lie_index', 'lie_revealed', 'vote_choice', 'has_voted', 'total_score', 'rounds_as_speaker']);
+    // info.fieldNames: slot (include/ge_step.h GE_WW_* / GE_TT_*) -> the DSL's own field name, '' = not declared
+    const modelled = new Set(['name', ...this.info.fieldNames.filter((x) => x)]);
     this.extraFields = {};
     for (const [k, v] of Object.entries(tmpl)) if (!modelled.has(k) && ['boolean', 'number', 'string'].includes(typeof v)) this.extraFields[k] = v;
   }
@@ -121,29 +120,28 @@ function decodeRoom(table, buf, off) {
   const pack = u8[18];
   const playerStates = {};
   const det = Array.from(u8.slice(VIEW.det, VIEW.det + n));
+  const names = table.info.fieldNames;
+  const slots = [];              // per player: one value per slot of the pack, declared by the DSL or not
   for (let i = 0; i < n; i++) {
     const f = u8.slice(VIEW.players + 12 * i, VIEW.players + 12 * i + 12);
+    let vals;
     if (pack === 1) {
       const mem = {};
       if (f[0] === 4) det.forEach((d, k) => { if (d) mem[String(k + 1)] = TEAMS[d]; });
-      playerStates[String(i + 1)] = {
-        role: table.info.roleNames[f[0]], team: TEAMS[f[1]], is_alive: !!f[2], role_revealed: !!f[3],
-        can_vote: !!f[4], has_secret_role: !!f[5], night_action_eligible: !!f[6],
-        night_action_submitted: !!f[7], selected_target_id: f[8], investigated_alignments: mem,
-      };
+      vals = [table.info.roleNames[f[0]], TEAMS[f[1]], !!f[2], !!f[3], !!f[4], !!f[5], !!f[6], !!f[7], f[8], mem, f[1] === 2];
     } else {
-      playerStates[String(i + 1)] = {
-        is_speaker: !!f[0], statements_submitted: !!f[1], lie_index: f[2], lie_revealed: !!f[3],
-        can_vote: !!f[4], vote_choice: f[5], has_voted: !!f[6], total_score: f[7], rounds_as_speaker: f[8],
-      };
+      vals = [!!f[0], !!f[1], f[2], !!f[3], !!f[4], f[5], !!f[6], f[7], f[8]];
     }
-    Object.assign(playerStates[String(i + 1)], table.extraFields || {});
+    slots.push(vals);
+    const rec = {};                // player_states hold exactly what the DSL declares, under its own names
+    vals.forEach((v, s) => { if (names[s]) rec[names[s]] = v; });
+    playerStates[String(i + 1)] = Object.assign(rec, table.extraFields || {});
   }
   const phaseId = dv.getInt32(0, true);
   return {
     current_phase_id: phaseId, current_phase_name: table.phaseName(phaseId),
     previous_phase_id: dv.getInt32(4, true), end_turn: dv.getInt32(8, true), games: dv.getInt32(12, true),
-    player_states: playerStates,
+    player_states: playerStates, pack, slots,
     acted: Array.from({ length: n }, (_, i) => u8[VIEW.players + 12 * i + 9]),
     choice: Array.from({ length: n }, (_, i) => u8[VIEW.players + 12 * i + 10]),
   };
@@ -202,42 +200,44 @@ function turnToolCalls(table, before, after, event) {
   const moved = event.to_phase_id !== event.from_phase_id;
   calls.push({ name: 'set_next_phase', args: { transition: moved, next_phase_id: event.to_phase_id, transition_reason: moved ? 'phase complete' : 'waiting' } });
   const deaths = [];
+  const names = table.info.fieldNames;
+  const SA = after.slots, SB = before.slots;                      // slot values (WW: 0 role, 2 is_alive, 8 target; TT: 0 speaker, 1 submitted, 7 score)
+  const ww = after.pack === 1;
   ids.forEach((pid, i) => {
     const b = before.player_states[pid], a = after.player_states[pid];
     for (const name of Object.keys(a)) {
       if (JSON.stringify(b[name]) !== JSON.stringify(a[name])) calls.push({ name: 'update_player_state', args: { player_id: pid, state_name: name, state_value: a[name] } });
     }
-    if ('is_alive' in a && b.is_alive && !a.is_alive) deaths.push([pid, a.role]);
-    if ('statements_submitted' in a) {
-      if (a.statements_submitted && !b.statements_submitted) {
+    if (ww && SB[i][2] && !SA[i][2]) deaths.push([pid, SA[i][0]]);
+    if (!ww && names[9]) {                                         // `statements`: text the record does not carry
+      if (SA[i][1] && !SB[i][1]) {
         const st = {}; [1, 2, 3].forEach((s) => { st[String(s)] = `Statement ${s} of Player ${i + 1}`; });
-        calls.push({ name: 'update_player_state', args: { player_id: pid, state_name: 'statements', state_value: st } });
-      } else if (b.statements_submitted && !a.statements_submitted) {
-        calls.push({ name: 'update_player_state', args: { player_id: pid, state_name: 'statements', state_value: {} } });
+        calls.push({ name: 'update_player_state', args: { player_id: pid, state_name: names[9], state_value: st } });
+      } else if (SB[i][1] && !SA[i][1]) {
+        calls.push({ name: 'update_player_state', args: { player_id: pid, state_name: names[9], state_value: {} } });
       }
     }
   });
   if (!moved) return calls;
   const note = (kind, text) => calls.push({ name: 'add_game_note', args: { note_type: kind, content: text } });
   note('PHASE_STATUS', `[t=${event.turn}] phase ${event.from_phase_id} -> ${event.to_phase_id}`);
-  const A = ids.map((pid) => after.player_states[pid]), B = ids.map((pid) => before.player_states[pid]);
   if (to.effect === 1) {                                          // GE_EFF_ASSIGN_ROLES
-    note('NEXT_PHASE', 'Roles assigned: ' + A.map((p, i) => `Player${i + 1}=${p.role}`).join(', '));
+    note('NEXT_PHASE', 'Roles assigned: ' + SA.map((p, i) => `Player${i + 1}=${p[0]}`).join(', '));
   } else if (to.effect === 3 || to.effect === 4) {               // NIGHT_RESOLVE / DAY_RESOLVE
     const how = to.effect === 3 ? 'overnight by the werewolves' : 'by day vote';
     deaths.forEach(([pid, role]) => note('CRITICAL', `Player ${pid} (${role}) eliminated ${how} - marked is_alive=false`));
     if (to.effect === 3 && !deaths.length) {
       const roles = table.info.roleNames;                        // class 2 = Werewolf, 3 = Doctor
-      const victim = plurality(A.filter((p, i) => B[i].is_alive && B[i].role === roles[2]).map((p) => p.selected_target_id), n);
+      const victim = plurality(SA.filter((p, i) => SB[i][2] && SB[i][0] === roles[2]).map((p) => p[8]), n);
       let protect = 0;
-      A.forEach((p, i) => { if (B[i].is_alive && B[i].role === roles[3]) protect = p.selected_target_id; });
+      SA.forEach((p, i) => { if (SB[i][2] && SB[i][0] === roles[3]) protect = p[8]; });
       note('DECISION', `Werewolves targeted Player ${victim}, Doctor protected Player ${protect} - no elimination`);
     }
   } else if (to.effect === 5) {                                   // TT_ROUND_START
-    const sp = A.findIndex((p) => p.is_speaker);
+    const sp = SA.findIndex((p) => p[0]);
     note('DECISION', `Selected Player ${sp + 1} as next speaker (turn_order)`);
   } else if (to.effect === 7) {                                   // TT_SCORE
-    if (B.some((p) => p.is_speaker)) note('SCORE_UPDATE', 'Total scores - ' + A.map((p, i) => `Player ${i + 1}: ${p.total_score}`).join(', '));
+    if (SB.some((p) => p[0])) note('SCORE_UPDATE', 'Total scores - ' + SA.map((p, i) => `Player ${i + 1}: ${p[7]}`).join(', '));
   }
   return calls;
 }
@@ -264,7 +264,7 @@ class RoomLog {
         rec.actions[id] = { action: a.actions, timestamp: now, phase: a.phase, id };
       } else if (c.name === 'add_game_note') {
         this.gameNotes.push(formatNote(a.note_type, a.content));
-      } else if (c.name === 'update_player_state' && a.state_name === 'statements') {
+      } else if (c.name === 'update_player_state' && this.table.info.pack === 2 && a.state_name === this.table.info.fieldNames[9]) {
         this.statements[a.player_id] = Object.assign({}, a.state_value);
       }
     }
@@ -277,7 +277,8 @@ class RoomLog {
       const out = { name: this.names[i] };
       for (const [k, v] of Object.entries(room.player_states[pid])) {
         out[k] = v;
-        if (k === 'is_speaker') out.statements = Object.assign({}, this.statements[pid] || {});
+        const fn = this.table.info.fieldNames;
+        if (this.table.info.pack === 2 && k === fn[0] && fn[9]) out[fn[9]] = Object.assign({}, this.statements[pid] || {});
       }
       ps[pid] = out;
     });

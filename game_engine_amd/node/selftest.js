@@ -33,8 +33,12 @@ if (deviceCount() === 0) {
       const n = golden.n_players;
       for (let i = 0; i < n; i++) {
         const ps = r.player_states[String(i + 1)], w = want.slice(4 + 11 * i, 15 + 11 * i);
-        if (golden.game.startsWith('werewolf')) {
-          if (ps.is_alive !== !!w[2] || ps.selected_target_id !== w[8] || ps.role !== table.info.roleNames[w[0]]) throw new Error(`player ${i + 1} turn ${t}`);
+        if (table.info.pack === 1) {
+          // a slot the DSL does not declare (the draft has no selected_target_id) reads 0 in the golden and is absent from player_states
+          const target = table.info.fieldNames[8] ? ps[table.info.fieldNames[8]] : 0;
+          if (ps.is_alive !== !!w[2] || target !== w[8] || ps.role !== table.info.roleNames[w[0]]) throw new Error(`player ${i + 1} turn ${t}`);
+          const elig = table.info.fieldNames[6];
+          if (elig && ps[elig] !== !!w[6]) throw new Error(`player ${i + 1} turn ${t}: ${elig}`);
         } else if (ps.total_score !== w[7] || ps.vote_choice !== w[5] || ps.is_speaker !== !!w[0]) throw new Error(`player ${i + 1} turn ${t}`);
         if (r.acted[i] !== w[9] || r.choice[i] !== w[10]) throw new Error(`log ${i + 1} turn ${t}`);
       }

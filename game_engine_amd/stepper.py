@@ -31,6 +31,8 @@ WW_FIELDS = ["role", "team", "is_alive", "role_revealed", "can_vote", "has_secre
 TT_FIELDS = ["is_speaker", "statements_submitted", "lie_index", "lie_revealed", "can_vote",
              "vote_choice", "has_voted", "total_score", "rounds_as_speaker"]
 _TEAMS = ["", "villagers", "werewolves"]
+# slots that are not ge_room_view columns (include/ge_step.h GE_WW_DET_MEMORY, GE_WW_WOLF_CHAT, GE_TT_STATEMENTS)
+SLOT_DET_MEMORY, SLOT_WOLF_CHAT, SLOT_STATEMENTS = 9, 10, 9
 
 
 class GeError(RuntimeError):
@@ -99,14 +101,16 @@ class GameTable:
         # declared fields the rule packs do not model: constants from the template (nobody writes them under the fixed policy)
         tmpl_all = ((dsl.get("declaration") or {}).get("player_states_template") or {}).get("player_states") or {}
         tmpl = tmpl_all.get("1") or tmpl_all.get(1) or (tmpl_all[next(iter(tmpl_all))] if tmpl_all else {})
-        modelled = set(WW_FIELDS) | set(TT_FIELDS) | {"name", "investigated_alignments", "statements"}
-        self.extra_fields = {k: v for k, v in (tmpl or {}).items() if k not in modelled and isinstance(v, (bool, int, str))}
         text = json.dumps(dsl, ensure_ascii=False).encode("utf-8")   # int phase keys become strings
         self.c = _lib.Table()
         err = C.create_string_buffer(512)
         st = _lib.load().ge_table_compile_json(text, len(text), rounds, C.byref(self.c), err, len(err))
         if st != 0:
             raise GeError(st, err.value.decode("utf-8", "replace"))
+        # slot -> the DSL's own name for it ("" = the DSL does not declare the slot); include/ge_step.h GE_WW_* / GE_TT_*
+        self.field_names: List[str] = [self.c.field_names[s].value.decode("utf-8", "replace") for s in range(_lib.GE_MAX_SLOTS)]
+        modelled = set(n for n in self.field_names if n) | {"name"}
+        self.extra_fields = {k: v for k, v in (tmpl or {}).items() if k not in modelled and isinstance(v, (bool, int, str))}
 
     @classmethod
     def from_gamename(cls, gamename: str, games_dir: Optional[str] = None, rounds: int = 1) -> "GameTable":
@@ -291,37 +295,42 @@ def summary_to_dict(w: np.ndarray) -> Dict[str, Any]:
             "sum_end_turn": w[5], "end_turn_hist": w[6:22], "score_hist": w[22:38], "checksum": w[38], "turn": w[39], "games_recycled": w[40]}
 
 
-def project_view(view) -> List[int]:
+def project_view(view, table: Optional["GameTable"] = None) -> List[int]:
     """Canonical integer projection of one room: [phase, prev_phase, phase0_done, end_turn]
     + 11 ints per player (+ detective memory per player, werewolf) — the form the parity
-    tests compare (tests/golden/*.json 'layout')."""
+    tests compare (tests/golden/*.json 'layout').  With `table`: only what the DSL declares (a slot it does not
+    declare reads 0, as it does in a reference-run room, whose player_states have no such field)."""
     n = int(view["n_players"])
     out = [int(view["phase_id"]), int(view["prev_phase_id"]), int(view["phase0_done"]), int(view["end_turn"])]
+    names = table.field_names if table is not None else None
+    shown = [1 if (names is None or names[s]) else 0 for s in range(9)] + [1, 1]
     for i in range(n):
-        out += [int(x) for x in view["players"][i][:11]]
+        out += [int(x) * k for x, k in zip(view["players"][i][:11], shown)]
     if int(view["pack"]) == PACK_WEREWOLF:
-        out += [int(x) for x in view["det"][:n]]
+        det = 1 if (names is None or names[SLOT_DET_MEMORY]) else 0
+        out += [int(x) * det for x in view["det"][:n]]
     return out
 
 
+def slot_values(tb: GameTable, view, i: int) -> List[Any]:
+    """Player i's state, one value per slot of the pack (GE_WW_* / GE_TT_* order), whether or not the DSL declares it."""
+    f = [int(x) for x in view["players"][i]]
+    if int(view["pack"]) == PACK_WEREWOLF:
+        n = int(view["n_players"])
+        mem = {str(k + 1): _TEAMS[int(d)] for k, d in enumerate(view["det"][:n]) if d} if f[0] == 4 else {}
+        return [tb.role_name(f[0]), _TEAMS[f[1]], bool(f[2]), bool(f[3]), bool(f[4]), bool(f[5]), bool(f[6]), bool(f[7]), f[8],
+                mem, f[1] == 2]
+    return [bool(f[0]), bool(f[1]), f[2], bool(f[3]), bool(f[4]), f[5], bool(f[6]), f[7], f[8]]
+
+
 def view_to_agent_state(tb: GameTable, view) -> Dict[str, Any]:
+    """player_states hold exactly the fields the DSL declares, under the DSL's own names (GameTable.field_names)."""
     n = int(view["n_players"])
     ps: Dict[str, Dict[str, Any]] = {}
-    det = [int(x) for x in view["det"][:n]]
     for i in range(n):
-        f = [int(x) for x in view["players"][i]]
-        if int(view["pack"]) == PACK_WEREWOLF:
-            rec = {"role": tb.role_name(f[0]), "team": _TEAMS[f[1]], "is_alive": bool(f[2]),
-                   "role_revealed": bool(f[3]), "can_vote": bool(f[4]), "has_secret_role": bool(f[5]),
-                   "night_action_eligible": bool(f[6]), "night_action_submitted": bool(f[7]),
-                   "selected_target_id": f[8],
-                   "investigated_alignments": ({str(k + 1): _TEAMS[d] for k, d in enumerate(det) if d}
-                                               if f[0] == 4 else {})}
-        else:
-            rec = {"is_speaker": bool(f[0]), "statements_submitted": bool(f[1]), "lie_index": f[2],
-                   "lie_revealed": bool(f[3]), "can_vote": bool(f[4]), "vote_choice": f[5],
-                   "has_voted": bool(f[6]), "total_score": f[7], "rounds_as_speaker": f[8]}
-        ps[str(i + 1)] = rec
+        vals = slot_values(tb, view, i)
+        ps[str(i + 1)] = {tb.field_names[s]: v for s, v in enumerate(vals) if tb.field_names[s]}
+        ps[str(i + 1)].update(tb.extra_fields)             # declared fields no rule writes: the template's values
     pid = int(view["phase_id"])
     return {"current_phase_id": pid, "current_phase_name": tb.phase_name(pid), "player_states": ps,
             "previous_phase_id": int(view["prev_phase_id"]), "end_turn": int(view["end_turn"])}

@@ -16,7 +16,7 @@ from __future__ import annotations
 
 from typing import Any, Dict, List, Optional
 
-from .stepper import PACK_WEREWOLF, TT_FIELDS, WW_FIELDS, GameTable
+from .stepper import PACK_WEREWOLF, SLOT_STATEMENTS, GameTable, slot_values
 
 _TEAMS = ["", "villagers", "werewolves"]
 ACT_WOLF_TARGET, ACT_DOCTOR_PROTECT, ACT_DETECTIVE, ACT_DAY_VOTE = 1, 2, 3, 4
@@ -38,20 +38,8 @@ def action_text(act: int, player: int, choice: int) -> str:
     return f"voted that statement {choice} is the lie"
 
 
-def _field_values(table: GameTable, view, i: int) -> Dict[str, Any]:
-    f = [int(x) for x in view["players"][i]]
-    if int(view["pack"]) == PACK_WEREWOLF:
-        n = int(view["n_players"])
-        det = [int(x) for x in view["det"][:n]]
-        return {"role": table.role_name(f[0]), "team": _TEAMS[f[1]], "is_alive": bool(f[2]),
-                "role_revealed": bool(f[3]), "can_vote": bool(f[4]), "has_secret_role": bool(f[5]),
-                "night_action_eligible": bool(f[6]), "night_action_submitted": bool(f[7]),
-                "selected_target_id": f[8],
-                "investigated_alignments": ({str(k + 1): _TEAMS[d] for k, d in enumerate(det) if d}
-                                            if f[0] == 4 else {})}
-    return {"is_speaker": bool(f[0]), "statements_submitted": bool(f[1]), "lie_index": f[2],
-            "lie_revealed": bool(f[3]), "can_vote": bool(f[4]), "vote_choice": f[5], "has_voted": bool(f[6]),
-            "total_score": f[7], "rounds_as_speaker": f[8]}
+WW_ROLE, WW_IS_ALIVE, WW_SELECTED_TARGET = 0, 2, 8          # slots the notes read (include/ge_step.h GE_WW_*)
+TT_IS_SPEAKER, TT_STATEMENTS_SUBMITTED, TT_TOTAL_SCORE = 0, 1, 7
 
 
 # entry effects (include/ge_step.h GE_EFF_*)
@@ -112,28 +100,29 @@ def turn_tool_calls(table: GameTable, before, after, event) -> List[Dict[str, An
                   "args": {"transition": q_id != p_id, "next_phase_id": q_id,
                            "transition_reason": "phase complete" if q_id != p_id else "waiting"}})
 
-    # RefereeNode: every declared field that changed, player by player
-    fields = WW_FIELDS + ["investigated_alignments"] if ww else TT_FIELDS
+    # RefereeNode: every declared field that changed, player by player, under the DSL's own field names
+    # (a slot the DSL does not declare is engine state only: no call)
+    names = table.field_names
     deaths = []
-    bvals = [_field_values(table, before, i) for i in range(n)]
-    avals = [_field_values(table, after, i) for i in range(n)]
+    bvals = [slot_values(table, before, i) for i in range(n)]
+    avals = [slot_values(table, after, i) for i in range(n)]
     for i in range(n):
         b, a = bvals[i], avals[i]
-        for name in fields:
-            if b[name] != a[name]:
+        for s in range(len(a)):
+            if names[s] and b[s] != a[s]:
                 calls.append({"name": "update_player_state",
-                              "args": {"player_id": str(i + 1), "state_name": name, "state_value": a[name]}})
-        if ww and b["is_alive"] and not a["is_alive"]:
-            deaths.append((i + 1, a["role"]))
-        if not ww:
+                              "args": {"player_id": str(i + 1), "state_name": names[s], "state_value": a[s]}})
+        if ww and b[WW_IS_ALIVE] and not a[WW_IS_ALIVE]:
+            deaths.append((i + 1, a[WW_ROLE]))
+        if not ww and names[SLOT_STATEMENTS]:
             # `statements` is text the packed state does not carry; it follows statements_submitted
-            if a["statements_submitted"] and not b["statements_submitted"]:
+            if a[TT_STATEMENTS_SUBMITTED] and not b[TT_STATEMENTS_SUBMITTED]:
                 calls.append({"name": "update_player_state", "args": {
-                    "player_id": str(i + 1), "state_name": "statements",
+                    "player_id": str(i + 1), "state_name": names[SLOT_STATEMENTS],
                     "state_value": {str(s): f"Statement {s} of Player {i + 1}" for s in (1, 2, 3)}}})
-            elif b["statements_submitted"] and not a["statements_submitted"]:
+            elif b[TT_STATEMENTS_SUBMITTED] and not a[TT_STATEMENTS_SUBMITTED]:
                 calls.append({"name": "update_player_state",
-                              "args": {"player_id": str(i + 1), "state_name": "statements", "state_value": {}}})
+                              "args": {"player_id": str(i + 1), "state_name": names[SLOT_STATEMENTS], "state_value": {}}})
     if q_id == p_id:
         return calls
 
@@ -143,27 +132,27 @@ def turn_tool_calls(table: GameTable, before, after, event) -> List[Dict[str, An
     note("PHASE_STATUS", f"[t={turn}] phase {p_id} -> {q_id}")
     eff = rows[q_id]["effect"]
     if eff == EFF_ASSIGN_ROLES:
-        note("NEXT_PHASE", "Roles assigned: " + ", ".join(f"Player{i + 1}={avals[i]['role']}" for i in range(n)))
+        note("NEXT_PHASE", "Roles assigned: " + ", ".join(f"Player{i + 1}={avals[i][WW_ROLE]}" for i in range(n)))
     elif eff in (EFF_NIGHT_RESOLVE, EFF_DAY_RESOLVE):
         how = "overnight by the werewolves" if eff == EFF_NIGHT_RESOLVE else "by day vote"
         for pid, role in deaths:
             note("CRITICAL", f"Player {pid} ({role}) eliminated {how} - marked is_alive=false")
         if eff == EFF_NIGHT_RESOLVE and not deaths:
-            # nobody died: say what was decided (the choices are still in selected_target_id)
+            # nobody died: say what was decided (the choices are still in the record's selected-target slot)
             cls = [int(before["players"][i][0]) for i in range(n)]
-            alive = [bvals[i]["is_alive"] for i in range(n)]
-            victim = _plurality([avals[i]["selected_target_id"] for i in range(n) if alive[i] and cls[i] == ROLE_WEREWOLF], n)
+            alive = [bvals[i][WW_IS_ALIVE] for i in range(n)]
+            victim = _plurality([avals[i][WW_SELECTED_TARGET] for i in range(n) if alive[i] and cls[i] == ROLE_WEREWOLF], n)
             protect = 0
             for i in range(n):
                 if alive[i] and cls[i] == ROLE_DOCTOR:
-                    protect = avals[i]["selected_target_id"]
+                    protect = avals[i][WW_SELECTED_TARGET]
             note("DECISION", f"Werewolves targeted Player {victim}, Doctor protected Player {protect} - no elimination")
     elif eff == EFF_TT_ROUND_START:
-        speaker = next((i + 1 for i in range(n) if avals[i]["is_speaker"]), 0)
+        speaker = next((i + 1 for i in range(n) if avals[i][TT_IS_SPEAKER]), 0)
         note("DECISION", f"Selected Player {speaker} as next speaker (turn_order)")
     elif eff == EFF_TT_SCORE:
-        if any(bvals[i]["is_speaker"] for i in range(n)):
-            note("SCORE_UPDATE", "Total scores - " + ", ".join(f"Player {i + 1}: {avals[i]['total_score']}" for i in range(n)))
+        if any(bvals[i][TT_IS_SPEAKER] for i in range(n)):
+            note("SCORE_UPDATE", "Total scores - " + ", ".join(f"Player {i + 1}: {avals[i][TT_TOTAL_SCORE]}" for i in range(n)))
     return calls
 
 
@@ -194,7 +183,8 @@ class RoomLog:
                                        "phase": a["phase"], "id": aid}
             elif c["name"] == "add_game_note":
                 self.game_notes.append(format_note(a["note_type"], a["content"]))
-            elif c["name"] == "update_player_state" and a["state_name"] == "statements":
+            elif c["name"] == "update_player_state" and a["state_name"] == self.table.field_names[SLOT_STATEMENTS] and \
+                    self.table.pack != PACK_WEREWOLF:
                 self.statements[a["player_id"]] = dict(a["state_value"])
         pid = int(after["phase_id"])
         entry = {"phase_id": pid, "phase_name": self.table.phase_name(pid)}
@@ -213,8 +203,8 @@ class RoomLog:
             out = {"name": self.names[i]}
             for k, v in rec.items():
                 out[k] = v
-                if tt and k == "is_speaker":
-                    out["statements"] = dict(self.statements.get(pid, {}))
+                if tt and k == self.table.field_names[TT_IS_SPEAKER] and self.table.field_names[SLOT_STATEMENTS]:
+                    out[self.table.field_names[SLOT_STATEMENTS]] = dict(self.statements.get(pid, {}))
             s["player_states"][pid] = out
         s.update(gameName=self.game_name, playerActions=self.player_actions, phase_history=self.phase_history,
                  game_notes=self.game_notes)

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GE_ABI_VERSION 2
+#define GE_ABI_VERSION 3
 #define GE_MAX_PHASES 32
 #define GE_MAX_PLAYERS 12
 #define GE_MAX_SEGMENTS 4
@@ -39,6 +39,7 @@ extern "C" {
 #define GE_MAX_CLAUSES 4
 #define GE_MAX_BRANCHES 4
 #define GE_NAME_LEN 64
+#define GE_MAX_SLOTS 12
 
 typedef enum ge_status {
     GE_OK = 0,
@@ -54,6 +55,21 @@ typedef enum ge_status {
 /* rule packs: which declared player_states schema the game uses
  * (reference games/werewolf-(mafia).yaml:21-72, games/two-truths-and-a-lie.yaml declaration) */
 enum { GE_PACK_WEREWOLF = 1, GE_PACK_TWO_TRUTHS = 2 };
+/* State slots of the packs, in ge_room_view.players[] column order (0..8), then the slots that are not columns.
+ * A generated DSL names its fields itself: each slot binds to the name the declaration uses for it
+ * (ge_game_table.field_names; e.g. the reference's earlier Werewolf draft, game_draft/werewolf-(mafia).yaml:30-75,
+ * says has_night_action / known_alignments / wolf_chat_enabled and declares no selected_target_id).  A slot the
+ * DSL does not declare still exists in the record; it is just not part of the room's player_states. */
+enum { GE_WW_ROLE = 0, GE_WW_TEAM, GE_WW_IS_ALIVE, GE_WW_ROLE_REVEALED, GE_WW_CAN_VOTE, GE_WW_HAS_SECRET_ROLE,
+       GE_WW_NIGHT_ELIGIBLE,      /* night_action_eligible | has_night_action */
+       GE_WW_NIGHT_SUBMITTED, GE_WW_SELECTED_TARGET,
+       GE_WW_DET_MEMORY,          /* investigated_alignments | known_alignments (ge_room_view.det) */
+       GE_WW_WOLF_CHAT,           /* wolf_chat_enabled: derived, = (team == werewolves) (POLICY.md 3a) */
+       GE_WW_SLOTS };
+enum { GE_TT_IS_SPEAKER = 0, GE_TT_STATEMENTS_SUBMITTED, GE_TT_LIE_INDEX, GE_TT_LIE_REVEALED, GE_TT_CAN_VOTE,
+       GE_TT_VOTE_CHOICE, GE_TT_HAS_VOTED, GE_TT_TOTAL_SCORE, GE_TT_ROUNDS_AS_SPEAKER,
+       GE_TT_STATEMENTS,          /* text the record does not carry; follows statements_submitted */
+       GE_TT_SLOTS };
 /* completion_criteria.type (dsl_phases_generation_prompt.txt:106-150) */
 enum { GE_COMP_UI = 0, GE_COMP_TIMER = 1, GE_COMP_ACTION = 2 };
 /* what a bot action in a player_action phase means (bot_behavior_system_prompt.txt:21-56) */
@@ -121,6 +137,7 @@ typedef struct ge_game_table {
     int32_t min_players;                  /* declaration.min_players */
     uint8_t init_fields[12];              /* player_states_template, canonical field order */
     char role_names[5][GE_NAME_LEN];      /* werewolf: "", Villager, Werewolf, Doctor, Detective as declared */
+    char field_names[GE_MAX_SLOTS][GE_NAME_LEN];  /* slot (GE_WW_* / GE_TT_*) -> declared field name, "" = not declared */
     ge_phase_row rows[GE_MAX_PHASES];
 } ge_game_table;
 

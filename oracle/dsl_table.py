@@ -77,6 +77,28 @@ TT_BASE = {
     ("can_vote", True): 3, ("has_voted", True): 4,
 }
 
+# State slots of the rule packs and the declared field names each one binds to (first = canonical).  A generated DSL
+# names its fields itself (the reference's own earlier Werewolf draft, game_draft/werewolf-(mafia).yaml, says
+# has_night_action / known_alignments / wolf_chat_enabled and declares no selected_target_id); a slot the DSL does not
+# declare still exists in the engine's record, it just is not part of the room's player_states.
+# `wolf_chat_enabled` is derived: the fixed policy sets it with the team and never again (POLICY.md §3a).
+WW_SLOTS = (("role",), ("team",), ("is_alive",), ("role_revealed",), ("can_vote",), ("has_secret_role",),
+            ("night_action_eligible", "has_night_action"), ("night_action_submitted",), ("selected_target_id",),
+            ("investigated_alignments", "known_alignments"), ("wolf_chat_enabled",))
+TT_SLOTS = (("is_speaker",), ("statements_submitted",), ("lie_index",), ("lie_revealed",), ("can_vote",), ("vote_choice",),
+            ("has_voted",), ("total_score",), ("rounds_as_speaker",), ("statements",))
+WW_REQUIRED = ("role", "team", "is_alive")
+
+
+def bind_fields(pack: int, declaration: dict) -> Dict[str, Optional[str]]:
+    """canonical slot name -> the name the DSL declares for it (None: not declared)."""
+    declared = (declaration.get("player_states") or {}).keys()
+    out: Dict[str, Optional[str]] = {}
+    for names in (WW_SLOTS if pack == PACK_WEREWOLF else TT_SLOTS):
+        out[names[0]] = next((n for n in names if n in declared), None)
+    return out
+
+
 # role classes of the werewolf pack (index into declaration.roles is game data;
 # the *class* of each declared role is what the policy needs)
 ROLE_NONE, ROLE_VILLAGER, ROLE_WEREWOLF, ROLE_DOCTOR, ROLE_DETECTIVE = 0, 1, 2, 3, 4
@@ -151,6 +173,11 @@ class Table:
     template: Dict[str, Any]
     rounds: int = 1                  # two-truths: agreed speaking turns per player
     fields: List[str] = field(default_factory=list)
+    names: Dict[str, Optional[str]] = field(default_factory=dict)   # canonical slot -> declared field name (bind_fields)
+
+    def declared(self, slot: str) -> Optional[str]:
+        """The DSL's name for a canonical slot; the canonical name itself for a table built without a binding."""
+        return self.names.get(slot) if self.names else slot
 
     def idx_of(self, phase_id: int) -> int:
         for p in self.phases:
@@ -222,7 +249,8 @@ def _const_holds(have: Any, op: str, vals: list, part: str) -> bool:
     return {"<": have < k, "<=": have <= k, ">": have > k, ">=": have >= k}[op]
 
 
-def parse_clauses(pack: int, cond: Optional[str], template: Optional[dict] = None) -> List[List[Literal]]:
+def parse_clauses(pack: int, cond: Optional[str], template: Optional[dict] = None,
+                  names: Optional[Dict[str, Optional[str]]] = None) -> List[List[Literal]]:
     """The condition grammar the DSL generator is told to use (dsl_phases_generation_prompt.txt:120-132):
     terms `player.<field> <op> <value>` with == != < <= > >= `in [...]` `not in [...]`, joined by `and`,
     alternatives joined by `or` (`and` binds tighter; no parentheses).  Result: OR of AND-clauses of
@@ -231,6 +259,9 @@ def parse_clauses(pack: int, cond: Optional[str], template: Optional[dict] = Non
         return []
     base = WW_BASE if pack == PACK_WEREWOLF else TT_BASE
     nums = WW_NUM if pack == PACK_WEREWOLF else TT_NUM
+    # declared field name -> canonical slot (`names`: bind_fields; None = the canonical names themselves)
+    slots = WW_SLOTS if pack == PACK_WEREWOLF else TT_SLOTS
+    canon = {d: c for c, d in names.items() if d} if names is not None else {s_[0]: s_[0] for s_ in slots}
     flat = " ".join(cond.split())
     if re.search(r"[()]", re.sub(r"'[^']*'|\"[^\"]*\"", "", flat)):          # outside quoted strings
         raise DslError(f"unsupported condition (parentheses): {cond!r}")
@@ -243,7 +274,8 @@ def parse_clauses(pack: int, cond: Optional[str], template: Optional[dict] = Non
             m = _GTERM_RE.match(part)
             if not m:
                 raise DslError(f"unsupported condition term: {part!r}")
-            fld, op, rhs = m.group(1), " ".join(m.group(2).lower().split()), m.group(3)
+            declared_name, op, rhs = m.group(1), " ".join(m.group(2).lower().split()), m.group(3)
+            fld = canon.get(declared_name, "")                     # "" = not a slot of the pack
             if op in ("in", "not in"):
                 inner = rhs.strip()
                 if not (inner.startswith("[") and inner.endswith("]")):
@@ -255,10 +287,11 @@ def parse_clauses(pack: int, cond: Optional[str], template: Optional[dict] = Non
                 vals = [_atom(rhs)]
             neg = op in ("!=", "not in")
             options: List[Literal]
-            modelled = fld in nums or fld in ("role", "team") or (fld, True) in base
-            if not modelled and template is not None and fld != "name" and isinstance(template.get(fld), (bool, int, str)):
+            modelled = fld in nums or fld in ("role", "team", "wolf_chat_enabled") or (fld, True) in base
+            if not modelled and template is not None and declared_name != "name" and \
+                    isinstance(template.get(declared_name), (bool, int, str)):
                 # a declared field outside the pack: constant (empty base set = never, negated = always)
-                options = [Literal("base", _const_holds(template[fld], op, vals, part), bases=(), field=fld)]
+                options = [Literal("base", _const_holds(template[declared_name], op, vals, part), bases=(), field=declared_name)]
             elif fld in nums and all(isinstance(v, int) and not isinstance(v, bool) for v in vals):
                 idx, top = nums[fld]
                 if op in ("==", "!=", "in", "not in"):
@@ -285,7 +318,9 @@ def parse_clauses(pack: int, cond: Optional[str], template: Optional[dict] = Non
                     raise DslError(f"unsupported comparison on a non-numeric field: {part!r}")
                 bases, flips = [], set()
                 for v in vals:
-                    if isinstance(v, bool) or (isinstance(v, int) and v in (0, 1) and (fld, True) in base):
+                    if fld == "wolf_chat_enabled" and (isinstance(v, bool) or (isinstance(v, int) and v in (0, 1))):
+                        key, flip = ("team", "werewolves"), (not bool(v))      # derived slot: set with the team, never again
+                    elif isinstance(v, bool) or (isinstance(v, int) and v in (0, 1) and (fld, True) in base):
                         key, flip = (fld, True), (not bool(v))
                     elif isinstance(v, str) and fld == "role" and pack == PACK_WEREWOLF:
                         key, flip = ("role", _role_class(v)), False
@@ -294,7 +329,7 @@ def parse_clauses(pack: int, cond: Optional[str], template: Optional[dict] = Non
                     else:
                         raise DslError(f"unsupported value in: {part!r}")
                     if key not in base:
-                        raise DslError(f"condition field {fld!r} not in rule pack: {part!r}")
+                        raise DslError(f"condition field {declared_name!r} not in rule pack: {part!r}")
                     bases.append(base[key])
                     flips.add(flip)
                 if len(flips) > 1:
@@ -331,14 +366,15 @@ def _role_class(name: str) -> int:
 
 def detect_pack(declaration: dict) -> int:
     f = set((declaration.get("player_states") or {}).keys())
-    if {"role", "team", "is_alive", "selected_target_id"} <= f:
+    if set(WW_REQUIRED) <= f:
         return PACK_WEREWOLF
     if {"is_speaker", "lie_index", "vote_choice", "total_score"} <= f:
         return PACK_TWO_TRUTHS
     raise DslError("no rule pack matches declaration.player_states " + str(sorted(f)))
 
 
-def _resolver_for(key: str) -> int:
+def _resolver_for(key: str, phases: Optional[List["Phase"]] = None) -> int:
+    """`phases`: the table's phases with their effects, for keys that name a phase ("... follows Dawn Reveal ...")."""
     k = key.lower()
     if "no living werewol" in k or "all werewolves eliminated" in k:
         return RES_WOLVES_ZERO
@@ -352,6 +388,14 @@ def _resolver_for(key: str) -> int:
         return RES_ALL_ROUNDS_DONE
     if k.startswith("otherwise"):
         return RES_OTHERWISE
+    if "follows" in k and phases:
+        # "follows <phase name>": what matters is which resolution that phase performs; the longest name wins
+        tail = k.split("follows", 1)[1]
+        named = sorted((p for p in phases if p.name.lower() in tail), key=lambda p: -len(p.name))
+        if named and named[0].effect == EFF_DAY_RESOLVE:
+            return RES_FOLLOWS_DAY
+        if named and named[0].effect == EFF_NIGHT_RESOLVE:
+            return RES_FOLLOWS_NIGHT
     raise DslError(f"no branch resolver for next_phase key {key!r}")
 
 
@@ -381,6 +425,7 @@ def compile_dsl(dsl: dict, rounds: int = 1) -> Table:
         role_names = [""]
         base = TT_BASE
 
+    names = bind_fields(pack, decl)
     items = _phase_items(dsl.get("phases") or {})
     if not items or len(items) > MAX_PHASES:
         raise DslError("phase count out of range")
@@ -400,7 +445,7 @@ def compile_dsl(dsl: dict, rounds: int = 1) -> Table:
             if wf is not None and wf not in WAIT_FOR:
                 raise DslError(f"phase {pid}: unknown wait_for {wf!r}")
             try:
-                p.clauses = parse_clauses(pack, (cc.get("target_players") or {}).get("condition"), template)
+                p.clauses = parse_clauses(pack, (cc.get("target_players") or {}).get("condition"), template, names)
             except DslError as e:
                 raise DslError(f"phase {pid}: {e}") from None
             plain = plain_terms(p.clauses) if p.clauses else []
@@ -409,6 +454,13 @@ def compile_dsl(dsl: dict, rounds: int = 1) -> Table:
                 p.terms = [Term(l.field, True, l.negate, base=l.bases[0]) for l in (p.clauses[0] if p.clauses else [])]
             p.act = _classify_action(pack, p, text)
         p.effect = _classify_effect(pack, p, text)
+        phases.append(p)
+    # a night begins at the first wolf-target phase reached from a non-night phase
+    for p in phases:
+        if p.act == ACT_WOLF_TARGET and p.effect == EFF_NONE:
+            p.effect = EFF_NIGHT_BEGIN
+    # branches second: a key may name another phase, whose effect must be known by then
+    for p, (pid, ph) in zip(phases, items):
         nxt = ph.get("next_phase")
         if nxt is None:
             pass
@@ -416,21 +468,19 @@ def compile_dsl(dsl: dict, rounds: int = 1) -> Table:
             p.branches = [Branch(RES_ALWAYS, int(nxt["id"]))]
         else:
             for key, tgt in nxt.items():
-                p.branches.append(Branch(_resolver_for(str(key)), int(tgt["id"]), key=str(key)))
+                try:
+                    p.branches.append(Branch(_resolver_for(str(key), phases), int(tgt["id"]), key=str(key)))
+                except DslError as e:
+                    raise DslError(f"phase {pid}: {e}") from None
         if len(p.branches) > MAX_BRANCHES:
             raise DslError(f"phase {pid}: too many branches")
-        phases.append(p)
     for p in phases:
         for b in p.branches:
             if b.target_id not in idx_of:
                 raise DslError(f"phase {p.id}: next_phase id {b.target_id} not in phases")
             b.target_idx = idx_of[b.target_id]
-    # a night begins at the first wolf-target phase reached from a non-night phase
-    for p in phases:
-        if p.act == ACT_WOLF_TARGET and p.effect == EFF_NONE:
-            p.effect = EFF_NIGHT_BEGIN
     return Table(pack=pack, phases=phases, role_names=role_names, template=template,
-                 rounds=rounds, fields=list((decl.get("player_states") or {}).keys()))
+                 rounds=rounds, fields=list((decl.get("player_states") or {}).keys()), names=names)
 
 
 def _classify_action(pack: int, p: Phase, text: str) -> int:
@@ -451,6 +501,8 @@ def _classify_clause(pack: int, p: Phase, clause: List[Literal]) -> int:
             return ACT_DOCTOR_PROTECT
         if (WW_BASE[("role", ROLE_DETECTIVE)], False) in bases:
             return ACT_DETECTIVE
+        if (WW_BASE[("team", "werewolves")], False) in bases:       # "all alive werewolves" written by team
+            return ACT_WOLF_TARGET
         if (WW_BASE[("can_vote", True)], False) in bases:
             return ACT_DAY_VOTE
     else:

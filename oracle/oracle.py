@@ -73,7 +73,13 @@ def lib():
 
 
 def _init_fields(table: T.Table) -> List[int]:
-    t = table.template
+    tmpl = table.template
+
+    class _Bound(dict):          # the template read through the schema binding (canonical slot -> declared name)
+        def get(self, slot, default=None):
+            name = table.declared(slot)
+            return tmpl.get(name, default) if name else default
+    t = _Bound()
     if table.pack == T.PACK_WEREWOLF:
         team = {"": 0, "villagers": 1, "werewolves": 2}[t.get("team", "")]
         role = table.role_names.index(t.get("role", "")) if t.get("role", "") in table.role_names else 0
@@ -137,13 +143,19 @@ class Oracle:
         ptr = rooms.ctypes.data + index * ROOM_DTYPE.itemsize
         return lib().orc_inject_action(C.byref(self.ct), ptr, player_id, choice) == 0
 
-    def project(self, room) -> List[int]:
+    def project(self, room, declared_only: bool = False) -> List[int]:
+        """The room as integers.  Default: the whole record (what the product's read_rooms is compared with);
+        `declared_only`: the reference-run form of the goldens - a slot the DSL does not declare reads 0."""
         out = [self.ids[int(room["phase"])], self.ids[int(room["prev"])], int(room["phase0_done"]),
                int(room["end_turn"])]
+        # a slot the DSL does not declare is not part of player_states: 0 in the projection, as in walker.project_state
+        slots = T.WW_SLOTS if self.table.pack == T.PACK_WEREWOLF else T.TT_SLOTS
+        shown = [1 if (self.table.declared(s[0]) or not declared_only) else 0 for s in slots[:9]] + [1, 1]
         for i in range(self.n):
-            out += [int(x) for x in room["p"][i][:11]]
+            out += [int(x) * k for x, k in zip(room["p"][i][:11], shown)]
         if self.table.pack == T.PACK_WEREWOLF:
-            out += [int(x) for x in room["det"][: self.n]]
+            det = 1 if (self.table.declared("investigated_alignments") or not declared_only) else 0
+            out += [int(x) * det for x in room["det"][: self.n]]
         return out
 
     def trajectory(self, seed: int, room_index: int, n_turns: int, restart: bool = False,
@@ -157,5 +169,5 @@ class Oracle:
                 if act:
                     assert self.inject(rooms, 0, act[0], act[1]), (t, act)
             self.run(rooms, seed, room_index, t, 1, restart=restart, human_mask=human_mask)
-            out.append(self.project(rooms[0]))
+            out.append(self.project(rooms[0], declared_only=True))
         return out

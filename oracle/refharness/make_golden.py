@@ -35,13 +35,26 @@ CASES = [                                # (game, n_players, rooms, turns, round
     ("two-truths-and-a-lie", 12, [1], 200, 1),
     ("two-truths-and-a-lie", 5, [2], 260, 3),
     ("two-truths-and-a-lie", 8, [7], 150, 1),
+    # the reference's earlier Werewolf draft (game_draft/): same rules, its own field names, no per-player target field
+    ("draft-werewolf-(mafia)", 8, [0, 3, 65535], 90, 1),
+    ("draft-werewolf-(mafia)", 5, [1], 60, 1),
+    ("draft-werewolf-(mafia)", 12, [2], 120, 1),
 ]
+
+
+def dsl_path(game: str) -> str:
+    return os.path.join(REFERENCE_ROOT, "game_draft", f"{game[6:]}.yaml") if game.startswith("draft-") else \
+        os.path.join(REFERENCE_ROOT, "games", f"{game}.yaml")
+
+
+def file_tag(game: str) -> str:
+    return game.split("-(")[0].replace("-", "_")
 
 
 def main(only=None):
     os.makedirs(os.path.join(GOLD, "dsl"), exist_ok=True)
     for game in sorted({c[0] for c in CASES}):
-        with open(os.path.join(REFERENCE_ROOT, "games", f"{game}.yaml"), encoding="utf-8") as f:
+        with open(dsl_path(game), encoding="utf-8") as f:
             dsl = yaml.safe_load(f)
         with open(os.path.join(GOLD, "dsl", f"{game}.json"), "w", encoding="utf-8") as f:
             json.dump(dsl, f, ensure_ascii=False, indent=1)
@@ -61,7 +74,7 @@ def main(only=None):
                 assert traj[-1][3] >= 0, (game, n, seed, room, "did not finish; raise turns")
                 cases.append({"seed": seed, "room": room, "turns": traj})
                 print(game, n, hex(seed), room, "end_turn", traj[-1][3], file=sys.stderr)
-        name = f"traj_{game.split('-(')[0].replace('-', '_')}_n{n}.json"
+        name = f"traj_{file_tag(game)}_n{n}.json"
         if only and name not in only:
             continue
         with open(os.path.join(GOLD, name), "w") as f:
@@ -77,7 +90,7 @@ def restart_cases():
     fresh RoomSession(turn0=...) — a new LangGraph thread — chained after the finished one."""
     out = []
     for game, n, turns in (("werewolf-(mafia)", 8, 260), ("two-truths-and-a-lie", 4, 200),
-                           ("werewolf-(mafia)", 12, 300)):
+                           ("werewolf-(mafia)", 12, 300), ("draft-werewolf-(mafia)", 8, 260)):
         cases = []
         for seed in SEEDS:
             room = 77
@@ -95,7 +108,7 @@ def restart_cases():
             assert games >= 3
             cases.append({"seed": seed, "room": room, "turns": traj, "games": games})
             print("restart", game, n, hex(seed), "games", games, file=sys.stderr)
-        name = f"restart_{game.split('-(')[0].replace('-', '_')}_n{n}.json"
+        name = f"restart_{file_tag(game)}_n{n}.json"
         with open(os.path.join(GOLD, name), "w") as f:
             json.dump({"game": game, "n_players": n, "rounds": 1, "restart": True,
                        "source": "chained reference sessions (v2 + v3) under FixedPolicy, clock continuing",
@@ -106,7 +119,8 @@ def human_cases():
     """Player 1 is host-driven (the reference's human): the bot policy skips it and a scripted
     person (oracle/human_script.py) acts for it."""
     from ..human_script import HUMAN_MASK, scripted_human
-    for game, n, turns in (("werewolf-(mafia)", 8, 110), ("two-truths-and-a-lie", 4, 100), ("werewolf-(mafia)", 12, 140)):
+    for game, n, turns in (("werewolf-(mafia)", 8, 110), ("two-truths-and-a-lie", 4, 100), ("werewolf-(mafia)", 12, 140),
+                           ("draft-werewolf-(mafia)", 8, 110)):
         cases = []
         for seed in SEEDS:
             room = 31
@@ -121,7 +135,7 @@ def human_cases():
             assert traj[-1][3] >= 0, (game, n, seed, "did not finish")
             cases.append({"seed": seed, "room": room, "turns": traj})
             print("human", game, n, hex(seed), "end", traj[-1][3], file=sys.stderr)
-        name = f"human_{game.split('-(')[0].replace('-', '_')}_n{n}.json"
+        name = f"human_{file_tag(game)}_n{n}.json"
         with open(os.path.join(GOLD, name), "w") as f:
             json.dump({"game": game, "n_players": n, "rounds": 1, "human_mask": HUMAN_MASK,
                        "source": "reference v2 + v3 nodes under FixedPolicy with player 1 host-driven (oracle/human_script.py)",
@@ -175,7 +189,8 @@ def string_cases():
     for game, n, picks in (("werewolf-(mafia)", 8, [(0xC0FFEE, 0), (1, 3)]),
                            ("werewolf-(mafia)", 12, [(0xC0FFEE, 1)]),
                            ("two-truths-and-a-lie", 4, [(0xC0FFEE, 0), (0, 2)]),
-                           ("two-truths-and-a-lie", 6, [(1, 4)])):
+                           ("two-truths-and-a-lie", 6, [(1, 4)]),
+                           ("draft-werewolf-(mafia)", 8, [(0xC0FFEE, 0), (0, 5)])):
         cases = []
         for seed, room in picks:
             s_ = RoomSession(game, n, seed, room, "v2")
@@ -204,7 +219,7 @@ def string_cases():
                           "final": {"playerActions": _strip_ts(s_.state["playerActions"]), "game_notes": s_.state["game_notes"],
                                     "phase_history": _strip_ts(s_.state["phase_history"])}})
             print("strings", game, n, hex(seed), room, "turns", len(turns), file=sys.stderr)
-        name = f"strings_{game.split('-(')[0].replace('-', '_')}_n{n}.json"
+        name = f"strings_{file_tag(game)}_n{n}.json"
         with open(os.path.join(GOLD, name), "w", encoding="utf-8") as f:
             json.dump({"game": game, "n_players": n, "rounds": 1,
                        "source": "reference game_agent_v2 nodes + backend_tools plumbing under FixedPolicy; timestamps stripped",

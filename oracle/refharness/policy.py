@@ -46,9 +46,11 @@ class RoomView:
         self.t_enter = t_enter          # turn in which the current phase was entered
         self.prev_phase = prev_phase    # phase it was entered from
 
-    # ---- per-player fields (0-based index i <-> player id str(i+1))
+    # ---- per-player fields (0-based index i <-> player id str(i+1)); `fld` is a canonical slot name, the dict
+    # ---- holds it under the name the DSL declares (dsl_table.bind_fields); an undeclared slot reads as `default`
     def get(self, i: int, fld: str, default=None):
-        return self.ps[self.ids[i]].get(fld, default)
+        name = self.table.declared(fld) if fld in self.table.names else fld
+        return self.ps[self.ids[i]].get(name, default) if name else default
 
     def alive(self, i: int) -> bool:
         return bool(self.get(i, "is_alive", True))
@@ -100,9 +102,9 @@ class RoomView:
         return self.mask(lambda i: self.alive(i) and (not ph.clauses or any(
             all(self.literal_true(i, l) for l in clause) for clause in ph.clauses)))
 
-    def visit_actions(self, ph: T.Phase, only_turn: Optional[int] = None) -> Dict[int, Tuple[int, int]]:
+    def visit_actions(self, ph: T.Phase, only_turn: Optional[int] = None, ever: bool = False) -> Dict[int, Tuple[int, int]]:
         """player index -> (turn, choice) of the latest action in this visit of `ph`
-        (referee_system_prompt_1.txt:19: latest action matching the current phase name)."""
+        (referee_system_prompt_1.txt:19: latest action matching the current phase name); `ever`: in any visit."""
         out: Dict[int, Tuple[int, int]] = {}
         for i, pid in enumerate(self.ids):
             rec = self.actions.get(pid)
@@ -114,7 +116,7 @@ class RoomView:
                 if not m or a.get("phase") != ph.name:
                     continue
                 turn, choice = int(m.group(1)), int(m.group(2))
-                if turn <= self.t_enter:
+                if turn <= self.t_enter and not ever:
                     continue
                 if only_turn is not None and turn != only_turn:
                     continue
@@ -284,10 +286,21 @@ class FixedPolicy:
         # working copy so that (B) sees (A)'s writes, as sequential tool application does
         ps = {pid: dict(v.ps[pid]) for pid in v.ids}
 
+        def declared(name: str) -> Optional[str]:
+            return tb.declared(name) if name in tb.names else name
+
         def put(i: int, name: str, value: Any):
-            ps[v.ids[i]][name] = value
+            """`name`: canonical slot; written under the DSL's own name, skipped when the DSL does not declare it."""
+            decl = declared(name)
+            if decl is None:
+                return
+            ps[v.ids[i]][decl] = value
             calls.append({"name": "update_player_state",
-                          "args": {"player_id": v.ids[i], "state_name": name, "state_value": value}})
+                          "args": {"player_id": v.ids[i], "state_name": decl, "state_value": value}})
+
+        def rd(i: int, name: str, default=None):
+            decl = declared(name)
+            return ps[v.ids[i]].get(decl, default) if decl else default
 
         def note(kind: str, text: str):
             calls.append({"name": "add_game_note", "args": {"note_type": kind, "content": text}})
@@ -300,8 +313,8 @@ class FixedPolicy:
                 put(i, "night_action_submitted", True)
                 put(i, "selected_target_id", choice)
                 if p.act == T.ACT_DETECTIVE:
-                    mem = dict(ps[v.ids[i]].get("investigated_alignments") or {})
-                    mem[str(choice)] = ps[v.ids[choice - 1]].get("team", "")
+                    mem = dict(rd(i, "investigated_alignments") or {})
+                    mem[str(choice)] = rd(choice - 1, "team", "")
                     put(i, "investigated_alignments", mem)
             elif p.act == T.ACT_TT_STATEMENTS:
                 put(i, "statements", {str(s): f"Statement {s} of Player {i + 1}" for s in (1, 2, 3)})
@@ -317,7 +330,7 @@ class FixedPolicy:
         # (B) entering q
         note("PHASE_STATUS", f"[t={t}] phase {p_id} -> {q_id}")
         n = v.n
-        alive = [bool(ps[pid].get("is_alive", True)) for pid in v.ids]
+        alive = [bool(rd(i, "is_alive", True)) for i in range(n)]
 
         def kill(k: int, how: str):
             i = k - 1
@@ -325,7 +338,7 @@ class FixedPolicy:
             put(i, "can_vote", False)
             put(i, "night_action_eligible", False)
             put(i, "role_revealed", True)
-            note("CRITICAL", f"Player {k} ({ps[v.ids[i]].get('role', '')}) eliminated {how} - marked is_alive=false")
+            note("CRITICAL", f"Player {k} ({rd(i, 'role', '')}) eliminated {how} - marked is_alive=false")
 
         if q.effect == T.EFF_ASSIGN_ROLES:
             tkey = rng.deal_key(self.rkey, self.game)       # roles are dealt per game, not per turn
@@ -345,24 +358,35 @@ class FixedPolicy:
                 put(i, "team", "werewolves" if cls[i] == T.ROLE_WEREWOLF else "villagers")
                 put(i, "has_secret_role", special)
                 put(i, "night_action_eligible", special)
+                put(i, "wolf_chat_enabled", cls[i] == T.ROLE_WEREWOLF)
             note("NEXT_PHASE", "Roles assigned: " + ", ".join(
                 f"Player{i + 1}={tb.role_names[cls[i]]}" for i in range(n)))
         elif q.effect == T.EFF_NIGHT_BEGIN:
             for i in range(n):
-                if ps[v.ids[i]].get("night_action_submitted"):
+                if rd(i, "night_action_submitted"):
                     put(i, "night_action_submitted", False)
-                if ps[v.ids[i]].get("selected_target_id"):
+                if rd(i, "selected_target_id"):
                     put(i, "selected_target_id", 0)
         elif q.effect == T.EFF_NIGHT_RESOLVE:
-            roles = [tb.role_names.index(ps[pid].get("role", "")) if ps[pid].get("role", "") in tb.role_names else 0
-                     for pid in v.ids]
-            votes = [int(ps[v.ids[i]].get("selected_target_id") or 0)
-                     for i in range(n) if alive[i] and roles[i] == T.ROLE_WEREWOLF]
+            roles = [tb.role_names.index(rd(i, "role", "")) if rd(i, "role", "") in tb.role_names else 0 for i in range(n)]
+            if declared("selected_target_id"):
+                target = [int(rd(i, "selected_target_id") or 0) for i in range(n)]
+            else:
+                # the DSL keeps no per-player target: this night's choices are the players' latest night actions in the log
+                # (a living wolf / doctor has acted this night, or the night phases would not have completed)
+                latest: Dict[int, Tuple[int, int]] = {}
+                for ph in tb.phases:
+                    if ph.act in (T.ACT_WOLF_TARGET, T.ACT_DOCTOR_PROTECT):
+                        for i, (turn, choice) in v.visit_actions(ph, ever=True).items():
+                            if i not in latest or turn > latest[i][0]:
+                                latest[i] = (turn, choice)
+                target = [latest[i][1] if i in latest else 0 for i in range(n)]
+            votes = [target[i] for i in range(n) if alive[i] and roles[i] == T.ROLE_WEREWOLF]
             victim = plurality(votes, n)
             protect = 0
             for i in range(n):
                 if alive[i] and roles[i] == T.ROLE_DOCTOR:
-                    protect = int(ps[v.ids[i]].get("selected_target_id") or 0)
+                    protect = target[i]
             if victim and victim != protect:
                 kill(victim, "overnight by the werewolves")
             else:

@@ -95,8 +95,15 @@ class RoomSession:
         import yaml
         self.version = version
         self.mod = load_reference(version)
-        with open(os.path.join(REFERENCE_ROOT, "games", f"{game}.yaml"), encoding="utf-8") as f:
+        draft = game.startswith("draft-")
+        path = os.path.join(REFERENCE_ROOT, "game_draft", f"{game[6:]}.yaml") if draft else \
+            os.path.join(REFERENCE_ROOT, "games", f"{game}.yaml")
+        with open(path, encoding="utf-8") as f:
             dsl = yaml.safe_load(f)
+        if draft and dsl_variant is None:
+            # a DSL from game_draft/ is not where load_dsl_by_gamename looks (utils.py:557-581): it is handed over
+            # in the state, as a freshly generated DSL is (v2:254-262 keeps a DSL that is already there)
+            dsl_variant = lambda d: d
         if dsl_variant is not None:
             # a variant of the game's DSL (oracle/dsl_variants.py): the reference's InitialRouterNode keeps a DSL
             # that is already in the state instead of loading the game's file (v2:254-262)
@@ -207,9 +214,11 @@ def project_state(table, state: dict, t_enter: int, prev_phase: int, end_turn: i
     acts = v.visit_actions(ph)
     for i in range(v.n):
         acted, choice = (1, acts[i][1]) if i in acts else (0, 0)
-        g = lambda f, d=0: v.get(i, f, d)
+        g = lambda f, d=0: v.get(i, f, d)           # canonical slot -> the DSL's own field; an undeclared slot reads as 0
         if table.pack == T.PACK_WEREWOLF:
             team = {"": 0, "villagers": 1, "werewolves": 2}[g("team", "")]
+            if table.declared("wolf_chat_enabled"):   # derived slot (POLICY.md §3a): not in the layout, checked here
+                assert bool(g("wolf_chat_enabled")) == (team == 2), "wolf_chat_enabled must equal team == werewolves"
             out += [v.role_class(i), team, int(bool(g("is_alive", True))), int(bool(g("role_revealed"))),
                     int(bool(g("can_vote"))), int(bool(g("has_secret_role"))),
                     int(bool(g("night_action_eligible"))), int(bool(g("night_action_submitted"))),

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     assert set(names) == set(_lib.SYMBOLS)
     for n in names:
         assert getattr(lib, n) is not None
-    assert lib.ge_abi_version() == _lib.GE_ABI_VERSION == 2
+    assert lib.ge_abi_version() == _lib.GE_ABI_VERSION == 3
 
 
 def test_struct_sizes_match_header():

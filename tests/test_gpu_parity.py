@@ -29,7 +29,7 @@ def test_golden_trajectories_turn_by_turn(name):
         with RoomBatch([(tb, g["n_players"], 1)], seed=case["seed"], first_room=case["room"], max_fuse=1) as b:
             for t, want in enumerate(case["turns"]):
                 b.step(1)
-                got = project_view(b.read_rooms(0, 1)[0])
+                got = project_view(b.read_rooms(0, 1)[0], tb)
                 assert got == want, f"{name} seed={case['seed']:#x} room={case['room']} turn={t}"
 
 
@@ -42,7 +42,7 @@ def test_golden_trajectories_fused(name):
         T = len(case["turns"])
         with RoomBatch([(tb, g["n_players"], 1)], seed=case["seed"], first_room=case["room"], max_fuse=T) as b:
             b.step(T)
-            assert project_view(b.read_rooms(0, 1)[0]) == case["turns"][-1]
+            assert project_view(b.read_rooms(0, 1)[0], tb) == case["turns"][-1]
 
 
 @pytest.mark.parametrize("game,n,n_rooms,turns,rounds", [
@@ -50,6 +50,8 @@ def test_golden_trajectories_fused(name):
     ("werewolf-(mafia)", 12, 20000, 80, 1),
     ("werewolf-(mafia)", 4, 5000, 40, 1),
     ("werewolf-(mafia)", 9, 3001, 64, 1),
+    ("draft-werewolf-(mafia)", 8, 65536, 72, 1),    # the reference's earlier Werewolf draft: own field names, two terminal phases
+    ("draft-werewolf-(mafia)", 11, 3001, 90, 1),
     ("two-truths-and-a-lie", 4, 65536, 64, 1),
     ("two-truths-and-a-lie", 3, 777, 48, 1),
     ("two-truths-and-a-lie", 7, 4099, 120, 2),
@@ -75,11 +77,12 @@ def test_restart_mode_golden(name):
                        max_fuse=1, restart=True) as b:
             for t, want in enumerate(case["turns"]):
                 b.step(1)
-                assert project_view(b.read_rooms(0, 1)[0]) == want, f"{name} seed={case['seed']:#x} turn={t}"
+                assert project_view(b.read_rooms(0, 1)[0], tb) == want, f"{name} seed={case['seed']:#x} turn={t}"
             assert int(b.read_rooms(0, 1)[0]["games"]) == case["games"]
 
 
-@pytest.mark.parametrize("game,n", [("werewolf-(mafia)", 8), ("werewolf-(mafia)", 12), ("two-truths-and-a-lie", 4)])
+@pytest.mark.parametrize("game,n", [("werewolf-(mafia)", 8), ("werewolf-(mafia)", 12), ("two-truths-and-a-lie", 4),
+                                    ("draft-werewolf-(mafia)", 8)])
 def test_restart_mode_equals_oracle(game, n):
     """The bench workload: steady state, finished rooms recycled, many fused launches."""
     dsl = load_dsl(game)
@@ -94,7 +97,7 @@ def test_restart_mode_equals_oracle(game, n):
 
 
 @pytest.mark.parametrize("game,n,n_rooms", [("werewolf-(mafia)", 8, 262144), ("werewolf-(mafia)", 12, 200000),
-                                            ("two-truths-and-a-lie", 4, 262144)])
+                                            ("two-truths-and-a-lie", 4, 262144), ("draft-werewolf-(mafia)", 12, 200000)])
 def test_high_occupancy_path_equals_oracle(game, n, n_rooms):
     """Above ~196 608 rooms the launch switches to its many-wavefronts-per-SIMD code path (256-thread
     blocks, predicated queue writes): compare it with the oracle too, steady state."""
@@ -139,11 +142,11 @@ def test_host_driven_player_golden(name):
     for case in g["cases"]:
         with RoomBatch([(tb, n, 1, g["human_mask"])], seed=case["seed"], first_room=case["room"], max_fuse=1) as b:
             for t, want in enumerate(case["turns"]):
-                act = scripted_human(otb, t, project_view(b.read_rooms(0, 1)[0]), n)
+                act = scripted_human(otb, t, project_view(b.read_rooms(0, 1)[0], tb), n)
                 if act:
                     b.inject_action(0, act[0], act[1])
                 b.step(1)
-                assert project_view(b.read_rooms(0, 1)[0]) == want, f"{name} seed={case['seed']:#x} turn={t}"
+                assert project_view(b.read_rooms(0, 1)[0], tb) == want, f"{name} seed={case['seed']:#x} turn={t}"
 
 
 @pytest.mark.parametrize("game,n,mask", [("werewolf-(mafia)", 8, 0b1), ("werewolf-(mafia)", 12, 0b100000000101),

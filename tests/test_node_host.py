@@ -68,7 +68,8 @@ def test_initialize_players_twin(tmp_path, monkeypatch):
 @needs_node
 @pytest.mark.gpu
 @pytest.mark.parametrize("dsl,gold", [("werewolf-(mafia).json", "traj_werewolf_n8.json"),
-                                      ("two-truths-and-a-lie.json", "traj_two_truths_and_a_lie_n4.json")])
+                                      ("two-truths-and-a-lie.json", "traj_two_truths_and_a_lie_n4.json"),
+                                      ("draft-werewolf-(mafia).json", "traj_draft_werewolf_n8.json")])
 def test_node_host_matches_golden(dsl, gold):
     r = _run(os.path.join(GOLD, "dsl", dsl), os.path.join(GOLD, gold))
     g = json.load(open(os.path.join(GOLD, gold)))

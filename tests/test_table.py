@@ -79,18 +79,63 @@ def test_empty_dsl():
         GameTable({})
 
 
-def test_reference_draft_dsl_is_rejected_not_guessed():
-    """game_draft/werewolf-(mafia).yaml declares a different player_states schema (has_night_action,
-    known_alignments, ...): no rule pack matches, and both compilers say so instead of guessing."""
+def test_reference_draft_dsl_binds_its_own_field_names():
+    """game_draft/werewolf-(mafia).yaml (fixture tests/golden/dsl/draft-werewolf-(mafia).json) is the same game under
+    a different player_states schema: has_night_action / known_alignments / wolf_chat_enabled, no selected_target_id,
+    no has_secret_role, no night_action_submitted; wolves are addressed by team; two terminal phases; a branch key that
+    names a phase ("follows Dawn Reveal").  Both compilers bind the pack's slots to the declared names and agree."""
+    from conftest import load_dsl
+    d = load_dsl("draft-werewolf-(mafia)")
+    tb, ot = GameTable(d), T.compile_dsl(d)
+    assert tb.pack == ot.pack == T.PACK_WEREWOLF
+    assert tb.field_names[:11] == ["role", "team", "is_alive", "role_revealed", "can_vote", "", "has_night_action", "", "",
+                                   "known_alignments", "wolf_chat_enabled"]
+    assert [ot.declared(s[0]) or "" for s in T.WW_SLOTS] == tb.field_names[:11]
+    rows = {r["phase_id"]: r for r in tb.rows()}
+    assert sorted(rows) == [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 98, 99]
+    for r, p in zip(tb.rows(), ot.phases):
+        assert (r["phase_id"], r["completion"], r["act"], r["effect"], r["terms"]) == \
+            (p.id, p.completion, p.act, p.effect, [(t.base, int(t.negate)) for t in p.terms])
+        assert r["branches"] == [(b.resolver, b.target_idx) for b in p.branches]
+    assert (rows[2]["act"], rows[3]["act"], rows[4]["act"], rows[8]["act"]) == (T.ACT_WOLF_TARGET, T.ACT_DOCTOR_PROTECT, T.ACT_DETECTIVE, T.ACT_DAY_VOTE)
+    assert (rows[1]["effect"], rows[2]["effect"], rows[6]["effect"], rows[9]["effect"]) == \
+        (T.EFF_ASSIGN_ROLES, T.EFF_NIGHT_BEGIN, T.EFF_NIGHT_RESOLVE, T.EFF_DAY_RESOLVE)
+    idx = {r["phase_id"]: i for i, r in enumerate(tb.rows())}
+    assert rows[10]["branches"] == [(T.RES_WOLVES_ZERO, idx[98]), (T.RES_WOLVES_GE_VILLAGERS, idx[99]),
+                                    (T.RES_FOLLOWS_NIGHT, idx[7]), (T.RES_OTHERWISE, idx[2])]
+    assert rows[98]["branches"] == rows[99]["branches"] == []
+    # a field of the shipped schema that this DSL does not declare is not silently accepted in a condition
+    bad = copy.deepcopy(d)
+    bad["phases"]["3"]["completion_criteria"]["target_players"]["condition"] = "player.role == 'Doctor' and player.night_action_submitted == false"
+    with pytest.raises(GeError) as e:
+        GameTable(bad)
+    assert "not in rule pack" in str(e.value)
+    with pytest.raises(T.DslError):
+        T.compile_dsl(bad)
+    # a derived slot in a condition: wolf_chat_enabled is the team test
+    ok = copy.deepcopy(d)
+    ok["phases"]["2"]["completion_criteria"]["target_players"]["condition"] = "player.wolf_chat_enabled == true and player.is_alive == true"
+    assert [r for r in GameTable(ok).rows() if r["phase_id"] == 2][0]["terms"] == [(7, 0), (0, 0)]
+    assert [(t.base, t.negate) for t in T.compile_dsl(ok).by_id(2).terms] == [(7, False), (0, False)]
+    # a branch key that names no resolving phase stays an error
+    bad = copy.deepcopy(d)
+    nx = bad["phases"]["10"]["next_phase"]
+    bad["phases"]["10"]["next_phase"] = {("If this check follows Day Discussion" if "Dawn" in k else k): v for k, v in nx.items()}
+    with pytest.raises(GeError) as e:
+        GameTable(bad)
+    assert "no branch resolver" in str(e.value)
+    with pytest.raises(T.DslError):
+        T.compile_dsl(bad)
+
+
+def test_draft_fixture_is_the_reference_file():
+    """The fixture is yaml.safe_load of the reference's file (checked where the reference checkout exists)."""
     import os
     path = "/root/reference/game_draft/werewolf-(mafia).yaml"
     if not os.path.exists(path):
         pytest.skip("needs the reference checkout (build container)")
+    import json
     import yaml
+    from conftest import load_dsl
     with open(path, encoding="utf-8") as f:
-        d = yaml.safe_load(f)
-    with pytest.raises(GeError) as e:
-        GameTable(d)
-    assert "no rule pack" in str(e.value)
-    with pytest.raises(T.DslError):
-        T.compile_dsl(d)
+        assert json.loads(json.dumps(yaml.safe_load(f))) == load_dsl("draft-werewolf-(mafia)")

@@ -87,7 +87,8 @@ def _replay(name, restart=False):
 
 @pytest.mark.skipif(not os.path.exists(REF), reason="needs the reference checkout (build container)")
 @pytest.mark.parametrize("name", ["traj_werewolf_n8.json", "traj_werewolf_n12.json", "traj_werewolf_n5.json",
-                                  "traj_two_truths_and_a_lie_n4.json", "traj_two_truths_and_a_lie_n6.json"])
+                                  "traj_two_truths_and_a_lie_n4.json", "traj_two_truths_and_a_lie_n6.json",
+                                  "traj_draft_werewolf_n8.json", "traj_draft_werewolf_n12.json"])
 def test_rendered_calls_replay_through_reference_plumbing(name):
     _replay(name)
 
@@ -122,7 +123,8 @@ def test_call_shapes(dsl_ww):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("game,n,restart", [("werewolf-(mafia)", 8, True), ("werewolf-(mafia)", 12, False),
-                                            ("two-truths-and-a-lie", 4, True), ("two-truths-and-a-lie", 9, False)])
+                                            ("two-truths-and-a-lie", 4, True), ("two-truths-and-a-lie", 9, False),
+                                            ("draft-werewolf-(mafia)", 8, True)])
 def test_kernel_event_trace_equals_oracle(game, n, restart):
     from game_engine_amd import RoomBatch
     from oracle.oracle import Oracle
