@@ -90,6 +90,24 @@ constexpr uint32_t GOLDEN = 0x9E3779B9u;
 #define GE_SEL_NEED 0
 #endif
 
+// Round 3 of the lone-wavefront diet (werewolf N <= 8 only; every instruction of a lone wavefront is a >= 4-cycle issue slot,
+// and gfx950 needs two wait states between a VALU write of VCC / an SGPR and a VALU read of it - a dependent
+// v_cmp -> v_cndmask pair costs a third slot for the s_nop the compiler has to put between them):
+// GE_ACT_ONEHOT: a queue slot carries the action kind one-hot; selects by v_bfe_i32 masks + v_bfi instead of compares
+// GE_NTH_SWAR:   n-th set bit of the candidate mask from nibble prefix counts (one multiply) instead of a binary search
+// GE_PK_KEYS:    the plurality's max over (count << 4 | 15 - id) keys with packed 16-bit max
+// profiles/r02_ab_onehot_swar_pk.txt, us/turn at 64 fused turns, 65 536 / 1 048 576 rooms: none 1.280 / 8.50; one-hot 1.257 / 8.49;
+// SWAR n-th bit 1.266 / 8.48; packed keys 1.288 / 8.39; all three 1.222 / 8.33 (alone the packed keys lose 0.6 % at C2, together with the others they gain 1 %)
+#ifndef GE_ACT_ONEHOT
+#define GE_ACT_ONEHOT 1
+#endif
+#ifndef GE_NTH_SWAR
+#define GE_NTH_SWAR 1
+#endif
+#ifndef GE_PK_KEYS
+#define GE_PK_KEYS 1
+#endif
+
 // ---- POLICY.md §RNG: stateless 32-bit counter hash
 GE_HD uint32_t mix32(uint32_t x) {
     x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
@@ -123,6 +141,16 @@ template <int NB> __device__ __forceinline__ uint32_t nth_set_bit(uint32_t m, ui
     c = popc(m & 0x3u); if (n >= c) { n -= c; pos += 2; m >>= 2; }
     c = m & 1u;         if (n >= c) { pos += 1; }
     return pos;
+}
+
+// NB <= 8, the same from nibble prefix counts: spread the mask to one bit per nibble; (x + 7 - n) * 0x11111111 puts
+// (number of set bits at positions <= j) + 7 - n into nibble j (<= 15: no carry), whose bit 3 says "more than n set bits
+// up to here"; the lowest such nibble is the n-th set bit.  12 instructions (one quarter-rate) instead of 22.
+__device__ __forceinline__ uint32_t nth_set_bit_swar8(uint32_t m, uint32_t n) {
+    uint32_t x = m & 0xFFu;
+    x = (x | (x << 12)) & 0x000F000Fu; x = (x | (x << 6)) & 0x03030303u; x = (x | (x << 3)) & 0x11111111u;
+    const uint32_t t = (x + 7u - n) * 0x11111111u;
+    return (uint32_t)__builtin_ctz(t & 0x88888888u) >> 2;      // the n-th set bit exists: never zero
 }
 
 // the same through a 2 KB LDS table nth8[mask][n] (mask: 8 bits): one LDS read instead of ~15 VALU
@@ -169,7 +197,7 @@ __device__ __forceinline__ uint64_t nib_fill(uint64_t x) { x |= x << 1; asm("" :
 // 1-based id with the most votes among `voters`, ties -> lowest id, 0 if nobody voted.
 // votes: one nibble per player (1-based target id, 0 = none).  Counters are nibbles too
 // (<= 12 voters), so the whole tally is one or two registers.
-template <int NB, typename nib_t>
+template <int NB, typename nib_t, bool PK = false>
 __device__ __forceinline__ uint32_t plurality(nib_t votes, uint32_t voters) {
     // keep only the voters' nibbles: spread the voter bits to nibble position 0, times 15
     nib_t vm;
@@ -193,6 +221,19 @@ __device__ __forceinline__ uint32_t plurality(nib_t votes, uint32_t voters) {
         uint32_t tally = 0;
 #pragma unroll
         for (int i = 0; i < NB; i++) tally += 1u << ((4u * ((v32 >> (4 * i)) & 15u)) & 31u);
+        if (PK && NB == 8) {
+            // two keys per register, 16 bits each: counters 1 / 5 sit at bits 4..7 of the two halves already (count << 4),
+            // 2 / 6, 3 / 7 and 4 after a shift; player 8's count comes from bit 3 of the vote nibbles
+            typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+            auto pk = [](uint32_t a) { return __builtin_bit_cast(u16x2, a); };
+            const uint32_t c8 = popc(v32 & 0x88888888u);
+            const uint32_t a = (tally & 0x00F000F0u) | 0x000A000Eu;                 // ids 1, 5: 15 - id = 14, 10
+            const uint32_t b = ((tally >> 4) & 0x00F000F0u) | 0x0009000Du;          // ids 2, 6
+            const uint32_t c = ((tally >> 8) & 0x00F000F0u) | 0x0008000Cu;          // ids 3, 7
+            const uint32_t d = ((tally >> 12) & 0x000000F0u) | (c8 << 20) | 0x0007000Bu;   // ids 4, 8
+            const u16x2 m = __builtin_elementwise_max(__builtin_elementwise_max(pk(a), pk(b)), __builtin_elementwise_max(pk(c), pk(d)));
+            key = m.x > m.y ? m.x : m.y;
+        } else
 #pragma unroll
         for (int k = 1; k <= NB; k++) {
             const uint32_t cnt = k < 8 ? (tally >> (4 * k)) & 15u : popc(v32 & 0x88888888u);
@@ -302,7 +343,36 @@ __device__ __forceinline__ uint32_t ww_choose(uint32_t act, uint32_t i, uint32_t
         cand = cand ? cand : alive;
     }
     const uint32_t idx = pick(d, popc(cand));
-    return (TABLE ? nth_set_bit_lds<NB>(nth8, cand, idx) : nth_set_bit<NB>(cand, idx)) + 1u;
+    return (TABLE ? nth_set_bit_lds<NB>(nth8, cand, idx) : (GE_NTH_SWAR && NB <= 8) ? nth_set_bit_swar8(cand, idx) : nth_set_bit<NB>(cand, idx)) + 1u;
+}
+
+// 0 / ~0 from bit `pos` of x (v_bfe_i32), and a select by such a mask (v_bfi_b32): no compare, no VCC
+// (the empty asm keeps the optimiser from recognising the mask as a sign-extended compare and turning the select back
+// into v_cmp + v_cndmask)
+__device__ __forceinline__ uint32_t bit_mask(uint32_t x, uint32_t pos) {
+    uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)x, pos, 1u);
+    asm("" : "+v"(m));
+    return m;
+}
+__device__ __forceinline__ uint32_t bfi(uint32_t m, uint32_t a, uint32_t b) { return (m & a) | (~m & b); }
+
+// ww_choose for a queue slot of the lone-wavefront build, N <= 8 (GE_ACT_ONEHOT).  x = alive | team_w << 16 | kind << 28 with
+// the action kind ONE-HOT (bit 28 wolf target, 29 doctor, 30 detective, 31 day vote); `det_voter`: by day, the Detective's
+// bit if it knows a living werewolf (else 0) - the owning room resolves that, so the slot needs no compare for it.
+__device__ __forceinline__ uint32_t ww_choose_onehot8(uint32_t x, uint32_t i, uint32_t d, uint32_t known, uint32_t lo_kw, uint32_t det_voter) {
+    const uint32_t alive = x & 0xFFFFu, team_w = (x >> 16) & 0xFFFu;
+    const uint32_t me = 1u << i;
+    const uint32_t others = alive & ~me, non_wolf = alive & ~team_w;
+    const uint32_t fresh = others & ~known;
+    const uint32_t det_c = sel32(fresh != 0u, fresh, others);                                   // ACT_DETECTIVE
+    const uint32_t vote = bfi(bit_mask(team_w, i), non_wolf, bfi(bit_mask(det_voter, i), lo_kw, others));   // ACT_DAY_VOTE
+    uint32_t cand = alive;                                                                      // ACT_DOCTOR_PROTECT
+    cand = bfi(bit_mask(x, 28), non_wolf, cand);
+    cand = bfi(bit_mask(x, 30), det_c, cand);
+    cand = bfi(bit_mask(x, 31), vote, cand);
+    cand = sel32(cand != 0u, cand, alive);
+    const uint32_t idx = pick(d, popc(cand));
+    return (GE_NTH_SWAR ? nth_set_bit_swar8(cand, idx) : nth_set_bit<8>(cand, idx)) + 1u;
 }
 
 // nibble mask (0xF per player) of the non-zero nibbles of x
@@ -428,6 +498,7 @@ __device__ __forceinline__ void ww_turn(WWR<NB> &s, DevRow &row, const DevRow *r
     constexpr bool ORD = GE_ORD && NB <= 8;                    // queue slots find their player through the ord8 table
     constexpr bool ONE = GE_ONE_ATOMIC && NB <= 8 && LOWOCC;   // one result atomic per slot (C2 1.331 -> 1.312 us/turn; the large-batch build loses 1.4 %)
     constexpr bool SHADOW = GE_SHADOW && (LOWOCC || (GE_SHADOW_HI && NB <= 8));   // action-independent work inside the queue's LDS round trips
+    constexpr bool ONEHOT = GE_ACT_ONEHOT && LOWOCC && ORD;    // queue slots carry the action kind one-hot (ww_choose_onehot8)
     auto *lw = static_cast<typename WaveLdsOf<LOWOCC>::type *>(wave_lds);
     const uint32_t ALL = (1u << n) - 1u;
     const uint32_t comp = row.r0 & 3u, act = (row.r0 >> 2) & 7u, p_eff = (row.r0 >> 5) & 7u;
@@ -547,8 +618,9 @@ __device__ __forceinline__ void ww_turn(WWR<NB> &s, DevRow &row, const DevRow *r
             if (LOWOCC || total != 0u) {                        // wave-uniform; LOWOCC: some room almost always has a due bot
                 // per-room context of an action; `ky`: what the acting role knows (the Detective's memory
                 // at night, who the Detective is by day - ww_choose reads only one of the two per kind)
-                const uint32_t ky = night ? known : r_det;
-                const uint4 ctx = ORD ? make_uint4(alive | (team_w << 16) | (act << 28), ky | (lo_kw << 8) | (off << 16) | (lane << 26), ord, tk)
+                const uint32_t ky = night ? known : (ONEHOT ? (lo_kw != 0u ? r_det : 0u) : r_det);
+                const uint32_t kind = ONEHOT ? ((1u << act) >> 1) : act;          // one-hot: ACT_WOLF_TARGET = 1 -> bit 0 ...
+                const uint4 ctx = ORD ? make_uint4(alive | (team_w << 16) | (kind << 28), ky | (lo_kw << 8) | (off << 16) | (lane << 26), ord, tk)
                                       : make_uint4(alive | (team_w << 16) | (act << 28), ky | (lo_kw << 16), todo | (off << 16) | (lane << 26), tk);
                 if (NB <= 8) *reinterpret_cast<uint2 *>(&lw->res[lane]) = make_uint2(0u, 0u);     // only x, y come back
                 else lw->res[lane] = make_uint4(0u, 0u, 0u, 0u);
@@ -614,8 +686,9 @@ __device__ __forceinline__ void ww_turn(WWR<NB> &s, DevRow &row, const DevRow *r
                     if (LOWOCC) {
                         // the choice is computed for every slot and only the result is predicated: a
                         // conditional block would split the slot read in two dependent LDS round trips
-                        uint32_t c = ww_choose<NB, false>(c4.x >> 28, i, d, c4.x & 0xFFFFu, (c4.x >> 16) & 0xFFFu,
-                                                          know, lokw, know, nth8);
+                        uint32_t c = ONEHOT ? ww_choose_onehot8(c4.x, i, d, know, lokw, know)
+                                            : ww_choose<NB, false>(c4.x >> 28, i, d, c4.x & 0xFFFFu, (c4.x >> 16) & 0xFFFu,
+                                                                   know, lokw, know, nth8);
                         if (GE_PIN_CHOICE && NB > 8) asm volatile("" : "+v"(c));   // stays outside the exec-masked block below
                         if (GE_GO_BRANCHLESS) {
                             // every slot ORs into its room's result (L is a lane index even for a stale slot), zeros if it does not act
@@ -715,7 +788,7 @@ __device__ __forceinline__ void ww_turn(WWR<NB> &s, DevRow &row, const DevRow *r
     // night / day resolution: the plurality victim dies unless the (highest-id living) Doctor guards it
     auto resolve = [&](bool on, bool day) {
         const uint32_t voters = day ? (alive & s.acted) : (alive & s.template get<F_WOLF>());
-        const uint32_t victim = plurality<NB, nib_t>(day ? s.choice : s.sel, voters);
+        const uint32_t victim = plurality<NB, nib_t, GE_PK_KEYS != 0>(day ? s.choice : s.sel, voters);
         const uint32_t docs = alive & s.template get<F_DOC>();
         const uint32_t guarded = (uint32_t)(s.sel >> (4u * (31u - (uint32_t)__clz((int)(docs | 1u))))) & 15u;
         uint32_t protect, bit;
