@@ -146,6 +146,27 @@ def test_audience_groups_follow_the_dsl(dsl_ww):
         assert g["voters"] == [p for p in alive if ps[p]["can_vote"]]
 
 
+def test_audience_groups_of_the_draft_dsl_use_its_own_field_names():
+    """The draft Werewolf DSL's groups test has_night_action / wolf_chat_enabled / role_revealed - fields that exist in a
+    room's player_states only because the table binds its slots to the DSL's own names (POLICY.md 3a)."""
+    dsl = load_dsl("draft-werewolf-(mafia)")
+    seen_chat = seen_revealed = 0
+    for st in _room_states(dsl, 8, 60):
+        ps = st["player_states"]
+        assert all(set(ps[p]) == {"role", "team", "is_alive", "role_revealed", "can_vote", "has_night_action", "known_alignments",
+                                   "wolf_chat_enabled"} for p in ps)
+        g = audience_groups(dsl, ps)
+        assert set(g) == {"werewolves", "villagers", "alive_players", "voting_eligible", "night_actors", "doctors", "detectives",
+                          "wolf_chatters", "revealed_roles"}
+        alive = [p for p in ps if ps[p]["is_alive"]]
+        assert g["wolf_chatters"] == g["werewolves"] == [p for p in alive if ps[p]["team"] == "werewolves"]
+        assert g["night_actors"] == [p for p in alive if ps[p]["role"] in ("Werewolf", "Doctor", "Detective")]
+        assert g["revealed_roles"] == [p for p in ps if not ps[p]["is_alive"]]
+        seen_chat += len(g["wolf_chatters"])
+        seen_revealed += len(g["revealed_roles"])
+    assert seen_chat and seen_revealed
+
+
 def test_ui_script_of_werewolf_phases(dsl_ww):
     seen = {}
     audience_tools = {t for t, ps_ in frontend_tools().items() if any(p[0] == "audience_type" for p in ps_)}
@@ -207,7 +228,8 @@ def test_js_ui_script_equals_python(dsl_ww, dsl_tt, tmp_path):
     if shutil.which("node") is None:
         pytest.skip("node is not available")
     cases = []
-    for dsl, n in ((dsl_ww, 8), (dsl_ww, 11), (dsl_tt, 4), (dsl_tt, 6)):
+    dsl_draft = load_dsl("draft-werewolf-(mafia)")           # its own field names and audience groups (wolf_chatters, night_actors)
+    for dsl, n in ((dsl_ww, 8), (dsl_ww, 11), (dsl_tt, 4), (dsl_tt, 6), (dsl_draft, 8)):
         tb = GameTable(dsl)
         acts = {r["phase_id"]: r["act"] for r in tb.rows()}
         items = [{"id": "0003", "type": "death_marker"}, {"id": "0009", "type": "score_board"}]
@@ -246,7 +268,7 @@ def test_js_ui_script_equals_python(dsl_ww, dsl_tt, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("game,n", [("werewolf-(mafia)", 8), ("two-truths-and-a-lie", 4)])
+@pytest.mark.parametrize("game,n", [("werewolf-(mafia)", 8), ("two-truths-and-a-lie", 4), ("draft-werewolf-(mafia)", 8)])
 def test_ui_calls_of_gpu_stepped_room_equal_oracle_stepped_room(game, n):
     """RoomService (N=1 traced batch on the GPU) emits, turn by turn, the UI calls the script derives from the
     oracle-stepped room - deaths, voting options and audiences included - and every call validates."""
