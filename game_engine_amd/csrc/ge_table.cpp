@@ -215,14 +215,19 @@ struct Binding {
     int pack = 0, n = 0;
     std::string declared[GE_MAX_SLOTS];
     const char *canonical(int slot) const { return pack == GE_PACK_WEREWOLF ? WW_SLOT_NAMES[slot][0] : TT_SLOT_NAMES[slot][0]; }
-    void bind(int pack_, const JVal *ps_def) {
+    // false: the declaration names one slot twice (two accepted names of the same slot) - `twice` says which
+    bool bind(int pack_, const JVal *ps_def, std::string &twice) {
         pack = pack_;
         n = pack == GE_PACK_WEREWOLF ? (int)GE_WW_SLOTS : (int)GE_TT_SLOTS;
         for (int s = 0; s < n; s++) {
             const char *const *names = pack == GE_PACK_WEREWOLF ? WW_SLOT_NAMES[s] : TT_SLOT_NAMES[s];
-            for (int k = 0; k < 3 && names[k] && declared[s].empty(); k++)
-                if (ps_def && ps_def->get(names[k])) declared[s] = names[k];
+            for (int k = 0; k < 3 && names[k]; k++)
+                if (ps_def && ps_def->get(names[k])) {
+                    if (!declared[s].empty()) { twice = declared[s] + " / " + names[k]; return false; }
+                    declared[s] = names[k];
+                }
         }
+        return true;
     }
     // canonical slot name of a declared field, "" if the field is not a slot of the pack
     std::string slot_of(const std::string &field) const {
@@ -593,7 +598,8 @@ static int compile_impl(const char *dsl_json, size_t len, int rounds, ge_game_ta
         return err.set("no rule pack matches declaration.player_states");
 
     Binding bind;
-    bind.bind(t.pack, ps_def);
+    std::string twice;
+    if (!bind.bind(t.pack, ps_def, twice)) return err.set("two declared fields bind to one state slot: " + twice);
     for (int s = 0; s < bind.n; s++) copy_name(t.field_names[s], bind.declared[s]);
 
     if (t.pack == GE_PACK_WEREWOLF) {

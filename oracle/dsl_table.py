@@ -95,7 +95,10 @@ def bind_fields(pack: int, declaration: dict) -> Dict[str, Optional[str]]:
     declared = (declaration.get("player_states") or {}).keys()
     out: Dict[str, Optional[str]] = {}
     for names in (WW_SLOTS if pack == PACK_WEREWOLF else TT_SLOTS):
-        out[names[0]] = next((n for n in names if n in declared), None)
+        have = [n for n in names if n in declared]
+        if len(have) > 1:
+            raise DslError("two declared fields bind to one state slot: " + " / ".join(have))
+        out[names[0]] = have[0] if have else None
     return out
 
 

@@ -117,6 +117,14 @@ def test_reference_draft_dsl_binds_its_own_field_names():
     ok["phases"]["2"]["completion_criteria"]["target_players"]["condition"] = "player.wolf_chat_enabled == true and player.is_alive == true"
     assert [r for r in GameTable(ok).rows() if r["phase_id"] == 2][0]["terms"] == [(7, 0), (0, 0)]
     assert [(t.base, t.negate) for t in T.compile_dsl(ok).by_id(2).terms] == [(7, False), (0, False)]
+    # two names of one slot in the same declaration: which one the rules write would be a guess
+    bad = copy.deepcopy(d)
+    bad["declaration"]["player_states"]["night_action_eligible"] = {"type": "boolean", "example": False, "description": "x"}
+    with pytest.raises(GeError) as e:
+        GameTable(bad)
+    assert "bind to one state slot" in str(e.value)
+    with pytest.raises(T.DslError):
+        T.compile_dsl(bad)
     # a branch key that names no resolving phase stays an error
     bad = copy.deepcopy(d)
     nx = bad["phases"]["10"]["next_phase"]
