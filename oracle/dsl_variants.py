@@ -69,11 +69,31 @@ def ww_extra_fields(base: dict) -> dict:
     return d
 
 
+def ww_minimal_schema(base: dict) -> dict:
+    """Werewolf declaring only what its conditions need (name, role, team, is_alive, can_vote): every other slot of the
+    rule pack - role_revealed, has_secret_role, night eligibility / submitted, the selected target, the Detective's memory -
+    stays engine state and never appears in player_states (POLICY.md 3a).  The night's choices then live in the action log
+    only, as in the reference's earlier draft of the game."""
+    d = copy.deepcopy(base)
+    decl = d["declaration"]
+    drop = ("role_revealed", "has_secret_role", "night_action_eligible", "night_action_submitted", "selected_target_id",
+            "investigated_alignments")
+    for f in drop:
+        decl["player_states"].pop(f, None)
+        for block in ("player_states_template", "players_example"):
+            for rec in ((decl.get(block) or {}).get("player_states") or {}).values():
+                rec.pop(f, None)
+    for g in ("night_actors", "secret_holders"):
+        decl["audience_groups"].pop(g, None)
+    return d
+
+
 # name -> (base game, builder, rounds)
 VARIANTS: Dict[str, Tuple[str, Callable[[dict], dict], int]] = {
     "ww_generic": ("werewolf-(mafia)", ww_generic, 1),
     "tt_generic": ("two-truths-and-a-lie", tt_generic, 2),
     "ww_extra_fields": ("werewolf-(mafia)", ww_extra_fields, 1),
+    "ww_minimal_schema": ("werewolf-(mafia)", ww_minimal_schema, 1),
 }
 
 

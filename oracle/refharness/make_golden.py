@@ -148,7 +148,8 @@ def variant_cases():
     from .. import dsl_variants
     for name, n, rooms, turns in (("ww_generic", 8, [0, 5], 90), ("ww_generic", 11, [2], 130),
                                   ("tt_generic", 4, [0, 3], 110), ("tt_generic", 7, [1], 200),
-                                  ("ww_extra_fields", 8, [0, 4], 90)):
+                                  ("ww_extra_fields", 8, [0, 4], 90), ("ww_minimal_schema", 8, [0, 7], 90),
+                                  ("ww_minimal_schema", 12, [3], 130)):
         game, builder, rounds = dsl_variants.VARIANTS[name]
         cases = []
         for seed in SEEDS:

@@ -126,6 +126,22 @@ class RoomView:
     def known(self) -> Tuple[int, int]:
         """detective memory as (known_villagers_mask, known_werewolves_mask)."""
         kv = kw = 0
+        if self.table.pack == T.PACK_WEREWOLF and not self.table.declared("investigated_alignments"):
+            # the DSL keeps no memory field: what the Detective has learnt is what it has investigated so far - every
+            # "investigated Player c" of the action log - and a player's team never changes once dealt
+            for ph in self.table.phases:
+                if ph.act != T.ACT_DETECTIVE:
+                    continue
+                for rec in self.actions.values():
+                    for a in (rec.get("actions") or {}).values():
+                        m = _TAG.match(a.get("action", ""))
+                        if m and a.get("phase") == ph.name:
+                            c = int(m.group(2)) - 1
+                            if self.get(c, "team", "") == "werewolves":
+                                kw |= 1 << c
+                            else:
+                                kv |= 1 << c
+            return kv, kw
         for i in range(self.n):
             mem = self.get(i, "investigated_alignments", {}) or {}
             for k, team in mem.items():

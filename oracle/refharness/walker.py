@@ -231,6 +231,6 @@ def project_state(table, state: dict, t_enter: int, prev_phase: int, end_turn: i
     if table.pack == T.PACK_WEREWOLF:
         holders = [i for i in range(v.n) if (v.get(i, "investigated_alignments") or {})]
         assert len(holders) <= 1, "policy keeps a single detective memory"
-        kv, kw = v.known()
+        kv, kw = v.known() if table.declared("investigated_alignments") else (0, 0)     # not a field of this DSL's rooms: 0
         out += [(1 if (kv >> i) & 1 else 0) + (2 if (kw >> i) & 1 else 0) for i in range(v.n)]
     return out

@@ -44,7 +44,7 @@ def _acts(dsl):
 def test_variants_compile_to_the_same_clause_form(name):
     game, builder, rounds = dsl_variants.VARIANTS[name]
     tb, ot = _assert_same_table(builder(load_dsl(game)), rounds)
-    assert any(r["generic"] for r in tb.rows())
+    assert any(r["generic"] for r in tb.rows()) or name == "ww_minimal_schema"      # (that one varies the schema, not the conditions)
 
 
 @settings(max_examples=250, deadline=None, suppress_health_check=[HealthCheck.too_slow])
@@ -109,6 +109,32 @@ def test_declared_fields_outside_the_pack_are_constants(dsl_ww):
         assert needle in str(oe.value)
 
 
+def test_minimal_schema_keeps_the_other_slots_as_engine_state(dsl_ww):
+    """A Werewolf DSL that declares only name / role / team / is_alive / can_vote: both compilers bind five slots and leave
+    the rest undeclared; rooms then have exactly those fields, and the rules still run (the reference-run goldens
+    traj_variant_ww_minimal_schema_* pin that; there the policy reads targets and the Detective's memory off the action log)."""
+    from game_engine_amd.stepper import view_to_agent_state
+    from oracle.oracle import Oracle
+    from parity_util import oracle_rooms_as_views
+    d = dsl_variants.build("ww_minimal_schema", dsl_ww)
+    tb, ot = _assert_same_table(d)
+    assert [n for n in tb.field_names if n] == ["role", "team", "is_alive", "can_vote"]
+    assert [s[0] for s in T.WW_SLOTS if ot.declared(s[0])] == ["role", "team", "is_alive", "can_vote"]
+    orc = Oracle(d, 8)
+    rooms = orc.init_rooms(1)
+    orc.run(rooms, 1, 0, 0, 30)
+    st = view_to_agent_state(tb, oracle_rooms_as_views(orc, rooms)[0])
+    assert all(set(p) == {"role", "team", "is_alive", "can_vote"} for p in st["player_states"].values())
+    assert any(not p["is_alive"] for p in st["player_states"].values())          # the night / day resolutions happened
+    for cond in ("player.role == 'Doctor' and player.night_action_submitted == false", "player.selected_target_id > 0"):
+        bad = copy.deepcopy(d)
+        bad["phases"]["3"]["completion_criteria"]["target_players"]["condition"] = cond
+        with pytest.raises(GeError):
+            GameTable(bad)
+        with pytest.raises(T.DslError):
+            T.compile_dsl(bad)
+
+
 def test_wait_for_kinds(dsl_ww):
     """All three wait_for kinds mean 'every target player' (prompt :138 Completion Logic); others are errors."""
     for wf in ("single_player_choice", "all_players_action", "multiple_players_action"):
@@ -141,7 +167,8 @@ def _batch_equals_oracle(dsl, n, rooms, turns, seed, first, rounds=1, restart=Tr
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,n,rooms", [("ww_generic", 8, 40000), ("ww_generic", 12, 150000), ("ww_generic", 5, 3000),
                                           ("ww_extra_fields", 8, 70000), ("ww_extra_fields", 10, 9000),
-                                          ("tt_generic", 4, 200000), ("tt_generic", 9, 30000)])
+                                          ("tt_generic", 4, 200000), ("tt_generic", 9, 30000),
+                                          ("ww_minimal_schema", 8, 65536), ("ww_minimal_schema", 11, 9000)])
 def test_variant_batches_equal_oracle(name, n, rooms):
     game, builder, rounds = dsl_variants.VARIANTS[name]
     s = _batch_equals_oracle(builder(load_dsl(game)), n, rooms, 120, 0xC0FFEE, 1 << 30, rounds)

@@ -12,7 +12,7 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import load_dsl, load_golden, restart_files
+from conftest import golden_dsl, load_dsl, load_golden, restart_files
 from game_engine_amd import GameTable
 from game_engine_amd.toolcalls import turn_tool_calls
 from parity_util import oracle_events, oracle_rooms_as_views
@@ -36,7 +36,7 @@ def _replay(name, restart=False):
     from oracle.refharness.walker import project_state
     bt, ut = _reference_plumbing()
     g = load_golden(name)
-    dsl = load_dsl(g["game"])
+    dsl = golden_dsl(g)
     # the reference loads YAML with int phase keys; restore them for its helpers
     dsl_ref = dict(dsl, phases={int(k): v for k, v in dsl["phases"].items()})
     n = g["n_players"]
@@ -88,7 +88,8 @@ def _replay(name, restart=False):
 @pytest.mark.skipif(not os.path.exists(REF), reason="needs the reference checkout (build container)")
 @pytest.mark.parametrize("name", ["traj_werewolf_n8.json", "traj_werewolf_n12.json", "traj_werewolf_n5.json",
                                   "traj_two_truths_and_a_lie_n4.json", "traj_two_truths_and_a_lie_n6.json",
-                                  "traj_draft_werewolf_n8.json", "traj_draft_werewolf_n12.json"])
+                                  "traj_draft_werewolf_n8.json", "traj_draft_werewolf_n12.json",
+                                  "traj_variant_ww_minimal_schema_n8.json", "traj_variant_ww_generic_n8.json"])
 def test_rendered_calls_replay_through_reference_plumbing(name):
     _replay(name)
 
