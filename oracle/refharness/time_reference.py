@@ -22,7 +22,19 @@ def run(version, turns=300, reps=5):
     return statistics.median(rates)
 
 
+def _one(version):
+    return run(version, reps=3)
+
+
 if __name__ == "__main__":
+    import multiprocessing as mp
+    import sys
+    procs = int(sys.argv[1]) if len(sys.argv) > 1 else 1
     for v in ("v2", "v3"):
-        r = run(v)
-        print(f"{v}: {1e3 / r:.3f} ms/turn  {r:.0f} room-phase steps/s (1 core)")
+        if procs == 1:
+            r = run(v)
+            print(f"{v}: {1e3 / r:.3f} ms/turn  {r:.0f} room-phase steps/s (1 core)")
+        else:                                   # independent rooms, one process each
+            with mp.get_context("spawn").Pool(procs) as pool:
+                rates = pool.map(_one, [v] * procs)
+            print(f"{v}: {sum(rates):.0f} room-phase steps/s over {procs} processes ({min(rates):.0f}..{max(rates):.0f} each)")
