@@ -385,7 +385,12 @@ __device__ __forceinline__ uint64_t nib_nonzero(uint64_t x) {
 
 // A room's role deal (POLICY.md §3 ASSIGN_ROLES): nw werewolves, then a Doctor, then a Detective, by
 // repeated n-th-set-bit sampling of the players not yet dealt; `rem` = the Villagers.
-struct Deal { uint32_t wolves, doc, det, rem, game, valid; };
+// Large-batch build, N <= 8: kept as the three packed predicate words a role assignment writes (WWR::W, see deal_words) -
+// turning the four masks into those words is then paid once per deal, not once per turn (1 M x 8: 8.33 -> 8.10 us/turn).
+// The lone-wavefront build keeps the masks: there that work sits in an LDS wait shadow and costs nothing (C2: 1.220 -> 1.229
+// with the words).  profiles/r02_ab_onehot_swar_pk.txt
+struct Deal { uint32_t wolves, doc, det, rem, game, valid; };      // words form: wolves / doc / det hold W[0] / W[1] / W[2], rem is unused
+template <int NB, bool LOWOCC> constexpr bool deal_as_words() { return NB <= 8 && !LOWOCC; }
 
 template <int NB, bool LOWOCC>
 __device__ __forceinline__ void deal_roles(Deal &d, uint32_t dk, uint32_t game, uint32_t n, uint32_t nw, const uint8_t *nth8) {
@@ -402,7 +407,33 @@ __device__ __forceinline__ void deal_roles(Deal &d, uint32_t dk, uint32_t game, 
         doc = j == nw ? bit : doc;
         det = j == nw + 1u ? bit : det;
     }
-    d.wolves = wolves; d.doc = doc; d.det = det; d.rem = rem; d.game = game; d.valid = 1u;
+    if (deal_as_words<NB, LOWOCC>()) {
+        WWR<NB> w;
+        const uint32_t all = (1u << n) - 1u, special = all & ~rem;
+#pragma unroll
+        for (int k = 0; k < WWR<NB>::NW; k++) w.W[k] = 0;
+        w.template set<F_VIL>(rem); w.template set<F_WOLF>(wolves); w.template set<F_DOC>(doc); w.template set<F_DET>(det);
+        w.template set<F_TEAM_W>(wolves); w.template set<F_TEAM_V>(all & ~wolves);
+        w.template set<F_SECRET>(special); w.template set<F_ELIG>(special);
+        d.wolves = w.W[0]; d.doc = w.W[1]; d.det = w.W[2]; d.rem = 0u;
+    } else {
+        d.wolves = wolves; d.doc = doc; d.det = det; d.rem = rem;
+    }
+    d.game = game; d.valid = 1u;
+}
+
+// the packed predicate words a role assignment writes, from the prepared deal
+template <int NB, bool LOWOCC> __device__ __forceinline__ void deal_words(const Deal &deal, uint32_t all, WWR<NB> &dealt) {
+    if (deal_as_words<NB, LOWOCC>()) {
+        dealt.W[0] = deal.wolves; dealt.W[1] = deal.doc; dealt.W[2] = deal.det;
+        return;
+    }
+#pragma unroll
+    for (int k = 0; k < WWR<NB>::NW; k++) dealt.W[k] = 0;
+    const uint32_t special = all & ~deal.rem;
+    dealt.template set<F_VIL>(deal.rem); dealt.template set<F_WOLF>(deal.wolves); dealt.template set<F_DOC>(deal.doc); dealt.template set<F_DET>(deal.det);
+    dealt.template set<F_TEAM_W>(deal.wolves); dealt.template set<F_TEAM_V>(all & ~deal.wolves);
+    dealt.template set<F_SECRET>(special); dealt.template set<F_ELIG>(special);
 }
 
 // ------------------------------------------------------------------ generic target conditions
@@ -569,12 +600,7 @@ __device__ __forceinline__ void ww_turn(WWR<NB> &s, DevRow &row, const DevRow *r
             const uint32_t g = has_roles ? (s.games < 0xFFFFu ? s.games + 1u : s.games) : s.games;
             deal_roles<NB, LOWOCC>(deal, deal_key(rkey, g), g, n, nw, nth8);
         }
-#pragma unroll
-        for (int k = 0; k < R::NW; k++) dealt.W[k] = 0;
-        const uint32_t special = ALL & ~deal.rem;
-        dealt.template set<F_VIL>(deal.rem); dealt.template set<F_WOLF>(deal.wolves); dealt.template set<F_DOC>(deal.doc); dealt.template set<F_DET>(deal.det);
-        dealt.template set<F_TEAM_W>(deal.wolves); dealt.template set<F_TEAM_V>(ALL & ~deal.wolves);
-        dealt.template set<F_SECRET>(special); dealt.template set<F_ELIG>(special);
+        deal_words<NB, LOWOCC>(deal, ALL, dealt);
     };
     uint32_t tk_next = 0;
 
