@@ -381,3 +381,49 @@ def test_argument_and_range_errors(dsl_ww, dsl_tt):
         assert e.value.status == -6
         b.step(0)
         assert b.turn == 0
+
+
+@pytest.mark.parametrize("game,n", [("werewolf-(mafia)", 8), ("werewolf-(mafia)", 12), ("two-truths-and-a-lie", 4),
+                                    ("draft-werewolf-(mafia)", 8)])
+def test_turn_counter_past_16_bits_equals_oracle(game, n):
+    """The turn index is 32 bits in the RNG key but end_turn is a 16-bit field of the record that saturates at 0xFFFE
+    (0xFFFF = not finished): a batch whose clock starts shortly before turn 65 536 and runs across it, steady state, every
+    room against the oracle - in fused launches and one launch per turn."""
+    dsl = load_dsl(game)
+    orc = _oracle(dsl, n)
+    R, seed, t0, turns = 6000, 0xC0FFEE, 65536 - 300, 900
+    want = orc.init_rooms(R)
+    orc.run(want, seed, 0, t0, turns, threads=0, restart=True)
+    from parity_util import oracle_rooms_as_views
+    want_v = oracle_rooms_as_views(orc, want)
+    assert int(want_v["end_turn"].max()) == 0xFFFE                    # some room finished past the field's range
+    for fuse in (0, 1):
+        with RoomBatch([(GameTable(dsl), n, R)], seed=seed, restart=True, max_fuse=fuse) as b:
+            b.set_turn(t0)
+            b.step(turns if fuse == 0 else 400)
+            if fuse:
+                ref = orc.init_rooms(R)
+                orc.run(ref, seed, 0, t0, 400, threads=0, restart=True)
+                assert_views_equal(b.read_rooms(), oracle_rooms_as_views(orc, ref), f"{game} n={n} one launch per turn")
+            else:
+                assert_views_equal(b.read_rooms(), want_v, f"{game} n={n} fused")
+                assert b.turn == t0 + turns
+
+
+@pytest.mark.parametrize("game,n", [("werewolf-(mafia)", 8), ("two-truths-and-a-lie", 4)])
+def test_game_counter_saturates_like_the_oracle(game, n):
+    """`games` (how many games a slot has completed; keys the role deal) is a 16-bit field that stops at 0xFFFF: slots
+    written with counters just below it, stepped in steady state through several games, every room against the oracle."""
+    from parity_util import oracle_rooms_as_views
+    dsl = load_dsl(game)
+    orc = _oracle(dsl, n)
+    R, seed, turns = 3000, 7, 400
+    rooms = orc.init_rooms(R)
+    rooms["games"] = 0xFFFF - 2 - (np.arange(R) % 3)
+    with RoomBatch([(GameTable(dsl), n, R)], seed=seed, restart=True) as b:
+        b.write_rooms(0, oracle_rooms_as_views(orc, rooms))
+        b.step(turns)
+        got = b.read_rooms()
+    orc.run(rooms, seed, 0, 0, turns, threads=0, restart=True)
+    assert int(rooms["games"].max()) == 0xFFFF and int(rooms["games"].min()) == 0xFFFF
+    assert_views_equal(got, oracle_rooms_as_views(orc, rooms), f"{game} n={n}")
