@@ -62,3 +62,36 @@ def test_product_does_not_import_the_oracle():
                 src = open(os.path.join(d, f), encoding="utf-8").read()
                 for bad in ("import oracle", "from oracle", "libge_oracle", "ge_oracle", "orc_run", "refharness"):
                     assert bad not in src, (os.path.join(d, f), bad)
+
+
+def test_header_is_plain_c_and_links(tmp_path):
+    """include/ge_step.h is the boundary: it must compile as C99 (-pedantic) and a C program must link against the
+    in-tree library and call it (no GPU needed for the table compiler and the version / error-string entry points)."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc is not available")
+    from conftest import ROOT
+    src = tmp_path / "consumer.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include <string.h>
+#include "ge_step.h"
+int main(void) {
+    static ge_game_table t;
+    char err[256];
+    const char *bad = "{\"declaration\": {}, \"phases\": {}}";
+    if (ge_abi_version() != GE_ABI_VERSION) return 2;
+    if (ge_table_compile_json(bad, strlen(bad), 1, &t, err, sizeof err) != GE_ERR_DSL) return 3;
+    if (!ge_strerror(GE_ERR_DSL) || !strlen(err)) return 4;
+    printf("%d %s\n", ge_device_count(), err);
+    return 0;
+}
+''')
+    exe = tmp_path / "consumer"
+    libdir = os.path.join(ROOT, "game_engine_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"), str(src),
+                           "-L", libdir, "-lge_step", "-Wl,-rpath," + libdir, "-o", str(exe)])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, (out.returncode, out.stderr)
+    assert "needs top-level" in out.stdout
