@@ -173,6 +173,7 @@ class RoomBatch:
         _check(lib.ge_batch_create(C.byref(d), C.byref(h)), "ge_batch_create")
         self._h = h
         self._lib = lib
+        self._seed, self._first_room, self._max_fuse, self._restart, self._trace = seed, first_room, max_fuse, restart, trace
         self.n_rooms = sum(s[2] for s in segments)
 
     def close(self):
@@ -264,6 +265,32 @@ class RoomBatch:
         s = _lib.Summary()
         _check(self._lib.ge_batch_summary(self._h, C.byref(s)), "ge_batch_summary")
         return np.frombuffer(bytes(s), dtype="<u8").copy()
+
+    # ---- checkpoint / resume (the reference delegates this to LangGraph thread persistence; here a batch
+    # ---- is its room records + the turn counter, and the RNG is counter-based, so a resumed batch continues bit-exact)
+    def save_checkpoint(self, path: str) -> None:
+        """Self-contained, layout-independent checkpoint: every room as a ge_room_view, the turn counter, the batch
+        description and the games' DSLs (numpy .npz; `load_checkpoint` rebuilds the batch from it alone)."""
+        meta = {"abi": _lib.GE_ABI_VERSION, "seed": self._seed, "first_room": self._first_room, "turn": self.turn,
+                "max_fuse": self._max_fuse, "restart": self._restart, "trace": self._trace,
+                "segments": [{"dsl": seg[0].dsl, "rounds": int(seg[0].c.rounds), "n_players": int(seg[1]), "n_rooms": int(seg[2]),
+                              "human_mask": int(seg[3]) if len(seg) > 3 else 0} for seg in self.segments]}
+        with open(path, "wb") as f:
+            np.savez_compressed(f, views=self.read_rooms(), meta=np.frombuffer(json.dumps(meta).encode("utf-8"), dtype=np.uint8))
+
+    @classmethod
+    def load_checkpoint(cls, path: str, device: int = 0) -> "RoomBatch":
+        with np.load(path, allow_pickle=False) as z:
+            meta = json.loads(bytes(z["meta"]).decode("utf-8"))
+            views = np.ascontiguousarray(z["views"])
+        if meta["abi"] != _lib.GE_ABI_VERSION:
+            raise GeError(-1, f"checkpoint written by ABI {meta['abi']}, this library is ABI {_lib.GE_ABI_VERSION}")
+        segs = [(GameTable(sg["dsl"], sg["rounds"]), sg["n_players"], sg["n_rooms"], sg["human_mask"]) for sg in meta["segments"]]
+        b = cls(segs, seed=meta["seed"], first_room=meta["first_room"], device=device, max_fuse=meta["max_fuse"],
+                restart=meta["restart"], trace=meta["trace"])
+        b.write_rooms(0, views.astype(ROOM_VIEW_DTYPE, copy=False))
+        b.set_turn(meta["turn"])
+        return b
 
     def state(self, segment: int = 0) -> Tuple[int, int, int]:
         p, nbytes, bpr = C.c_void_p(), C.c_size_t(), C.c_uint32()
