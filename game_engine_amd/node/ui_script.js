@@ -39,7 +39,16 @@ function splitOutside(expr, word) {
  * phase target conditions (dsl_phases_generation_prompt.txt:120-132): == != < <= > >=, in [..] / not in [..], terms joined
  * by `and`, alternatives by `or` (and binds tighter; no parentheses).  Same semantics as game_engine_amd/ui_script.py.
  */
+const criteriaCache = new Map();                 // a DSL's criteria are compiled once, not once per turn
 function compileCriteria(expr) {
+  let f = criteriaCache.get(expr);
+  if (!f) {
+    f = compileCriteriaUncached(expr);
+    if (criteriaCache.size < 1024) criteriaCache.set(expr, f);
+  }
+  return f;
+}
+function compileCriteriaUncached(expr) {
   const flat = expr.split(/\s+/).filter((x) => x).join(' ');
   if (/[()]/.test(flat.replace(/'[^']*'|"[^"]*"/g, ''))) throw new Error(`unsupported selection criterion (parentheses): ${expr}`);
   const clauses = splitOutside(flat, 'or').map((alt) => splitOutside(alt, 'and').map((part) => {

@@ -27,6 +27,7 @@ from __future__ import annotations
 
 import json
 import os
+import functools
 import re
 from typing import Any, Callable, Dict, List, Optional
 
@@ -69,6 +70,7 @@ def _split_outside(expr: str, word: str) -> List[str]:
     return out
 
 
+@functools.lru_cache(maxsize=1024)                  # a DSL's criteria are compiled once, not once per turn
 def compile_criteria(expr: str) -> Callable[[Dict[str, Any]], bool]:
     """`player.team == 'werewolves' and player.is_alive == true` -> predicate over one player's state dict.
     The same grammar as phase target conditions (dsl_phases_generation_prompt.txt:120-132): == != < <= > >=,

@@ -29,3 +29,24 @@ for game, n in (("werewolf-(mafia)", 8), ("two-truths-and-a-lie", 4)):
         q = lambda v, p: sorted(v)[int(p * (len(v) - 1))]
         print(f"{game} x{n}: step+sync median {statistics.median(step_t):.1f} us (p95 {q(step_t, .95):.1f}); "
               f"step + read view + read event + render tool calls median {statistics.median(full_t):.1f} us (p95 {q(full_t, .95):.1f})")
+
+# the whole graph-run replacement: RoomService.continue_room = step + read-back + backend tool calls + log fold
+# (playerActions / game_notes / phase_history) + the phase's frontend tool calls (ui_script)
+from game_engine_amd import RoomService
+for game, n in (("werewolf-(mafia)", 8), ("two-truths-and-a-lie", 4)):
+    with open(os.path.join(ROOT, "tests", "golden", "dsl", f"{game}.json"), encoding="utf-8") as f:
+        dsl = json.load(f)
+    svc = RoomService(seed=7)
+    svc.create_room("t", game, [{"name": f"Player {i + 1}"} for i in range(n)], dsl=dsl)
+    ts = []
+    for t in range(turns):
+        t0 = time.perf_counter()
+        out = svc.continue_room("t")
+        ts.append((time.perf_counter() - t0) * 1e6)
+        if out["state"].get("end_turn", -1) >= 0 and t < turns - 1:          # next game on a fresh thread
+            svc.close("t")
+            svc.create_room("t", game, [{"name": f"Player {i + 1}"} for i in range(n)], dsl=dsl)
+    ts = ts[20:]
+    print(f"{game} x{n}: RoomService.continue_room (state + toolCalls + uiCalls) median {statistics.median(ts):.1f} us "
+          f"(p95 {sorted(ts)[int(.95 * (len(ts) - 1))]:.1f})")
+    svc.close("t")
