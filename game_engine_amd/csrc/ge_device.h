@@ -462,15 +462,21 @@ template <int NB, int FB, typename arr_t> __device__ __forceinline__ uint32_t ra
     return m;
 }
 
-template <typename LITMASK> __device__ __forceinline__ uint32_t eval_clauses(const DevCond &c, uint32_t all, LITMASK lit_mask) {
+// `shape` (DevTable::cond_shape, wave-uniform): the largest clause count [2:0] and clause length [6:4] among the table's
+// generic rows, and whether any of their literals is a base set [8] / a numeric range [9] - the loops stop there and the
+// literal kind nobody uses is not evaluated (a typical generated condition has two clauses of two or three literals)
+template <typename LITMASK> __device__ __forceinline__ uint32_t eval_clauses(const DevCond &c, uint32_t all, uint32_t shape, LITMASK lit_mask) {
     const uint32_t ncl = c.meta & 7u;
+    const uint32_t max_ncl = shape & 7u, max_len = (shape >> 4) & 7u;
     uint32_t T = ncl ? 0u : all;                              // no condition: everybody
 #pragma unroll
     for (int k = 0; k < 4; k++) {
+        if ((uint32_t)k >= max_ncl) break;                    // wave-uniform
         const uint32_t len = (c.meta >> (4 + 4 * k)) & 7u;
         uint32_t m = all;
 #pragma unroll
         for (int l = 0; l < 4; l++) {
+            if ((uint32_t)l >= max_len) break;                // wave-uniform
             const uint32_t w = c.lit[k][l];
             const uint32_t x = lit_mask(w) ^ ((w >> 30) & 1u ? all : 0u);
             m &= (uint32_t)l < len ? x : all;
@@ -480,15 +486,63 @@ template <typename LITMASK> __device__ __forceinline__ uint32_t eval_clauses(con
     return T & all;
 }
 
-template <int NB> __device__ __forceinline__ uint32_t ww_cond_generic(const WWR<NB> &s, const DevCond &c, uint32_t all) {
-    return eval_clauses(c, all, [&](uint32_t w) -> uint32_t {
-        if (((w >> 28) & 3u) == 1u) return ww_base_mask<NB>(s, w & 0xFFFFu);
-        return range_mask<NB, 4>(s.sel, w & 0xFFu, (w >> 8) & 0xFFu);        // GE_NUM_SELECTED_TARGET is the pack's only numeric field
+// N <= 8: literals prepared for the packed predicate words (DevCond::prep, built by to_dev_cond)
+__device__ __forceinline__ uint32_t ww8_cond_generic(const WWR<8> &s, const DevCond &c, uint32_t all, uint32_t shape) {
+    const bool any_base = (shape >> 8) & 1u, any_num = (shape >> 9) & 1u;       // wave-uniform
+    const uint32_t ncl = c.meta & 7u;
+    const uint32_t max_ncl = shape & 7u, max_len = (shape >> 4) & 7u;
+    // the selected-target nibbles of the even / odd players, one per byte
+    const uint32_t ev = s.sel & 0x0F0F0F0Fu, od = (s.sel >> 4) & 0x0F0F0F0Fu;
+    uint32_t T = ncl ? 0u : all;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if ((uint32_t)k >= max_ncl) break;                    // wave-uniform
+        const uint32_t len = (c.meta >> (4 + 4 * k)) & 7u;
+        uint32_t m = all;
+#pragma unroll
+        for (int l = 0; l < 4; l++) {
+            if ((uint32_t)l >= max_len) break;                // wave-uniform
+            const DevLit q = c.prep[k][l];                    // one 16-byte load
+            const uint32_t w = q.w, a0 = q.a0, a1 = q.a1;
+            uint32_t x = 0;
+            if (any_base) {                                   // gather the set's fields, OR-fold the four bytes
+                uint32_t g = __builtin_amdgcn_perm(s.W[1], s.W[0], a0) | __builtin_amdgcn_perm(s.W[2], s.W[2], a1);
+                g |= g >> 16; g |= g >> 8;
+                x = g & 0xFFu;
+            }
+            if (any_num) {                                    // lo <= v <= hi, four players per word: bit 7 of a byte = in range
+                const uint32_t ie = ((ev | 0x80808080u) - a0) & (a1 - ev) & 0x80808080u;
+                const uint32_t io = ((od | 0x80808080u) - a0) & (a1 - od) & 0x80808080u;
+                const uint32_t p = (ie >> 7) | (io >> 6);     // bits 0 / 1 of every byte = the byte's even / odd player
+                const uint32_t r = (p | (p >> 6) | (p >> 12) | (p >> 18)) & 0xFFu;
+                x = ((w >> 28) & 3u) == 1u ? x : r;
+            }
+            x ^= (w >> 30) & 1u ? all : 0u;
+            m &= (uint32_t)l < len ? x : all;
+        }
+        T |= (uint32_t)k < ncl ? m : 0u;
+    }
+    return T & all;
+}
+
+template <int NB> __device__ __forceinline__ uint32_t ww_cond_generic(const WWR<NB> &s, const DevCond &c, uint32_t all, uint32_t shape) {
+    if constexpr (NB <= 8) {
+        if (!(c.meta >> 31)) return ww8_cond_generic(s, c, all, shape);
+    }
+    const bool any_base = (shape >> 8) & 1u, any_num = (shape >> 9) & 1u;       // wave-uniform
+    return eval_clauses(c, all, shape, [&](uint32_t w) -> uint32_t {
+        uint32_t m = 0;
+        if (any_base) m = ww_base_mask<NB>(s, w & 0xFFFFu);
+        if (any_num) {
+            const uint32_t r = range_mask<NB, 4>(s.sel, w & 0xFFu, (w >> 8) & 0xFFu);   // GE_NUM_SELECTED_TARGET is the pack's only numeric field
+            m = ((w >> 28) & 3u) == 1u ? m : r;
+        }
+        return m;
     });
 }
 
-template <int NB> __device__ __forceinline__ uint32_t tt_cond_generic(const TT<NB> &s, const DevCond &c, uint32_t all) {
-    return eval_clauses(c, all, [&](uint32_t w) -> uint32_t {
+template <int NB> __device__ __forceinline__ uint32_t tt_cond_generic(const TT<NB> &s, const DevCond &c, uint32_t all, uint32_t shape) {
+    return eval_clauses(c, all, shape, [&](uint32_t w) -> uint32_t {
         if (((w >> 28) & 3u) == 1u) {
             const uint32_t set = w & 0xFFFFu;
             return ((set & 1u) ? s.speaker : 0u) | ((set & 2u) ? s.submitted : 0u) | ((set & 4u) ? s.revealed : 0u) |
@@ -515,7 +569,7 @@ template <int NB> __device__ __forceinline__ uint32_t tt_cond_generic(const TT<N
 // DEAL: 1 / 0 = this instantiation is for the turns that do / do not prepare role deals (the lone-wavefront build compiles
 // the turn twice rather than test a wave-uniform flag inside an exec-mask region every turn); 2 = `deal_now` decides
 template <int NB, bool QUEUE, bool LOWOCC, bool GENERIC = false, int DEAL = 2>
-__device__ __forceinline__ void ww_turn(WWR<NB> &s, DevRow &row, const DevRow *rows, const DevCond *conds, void *wave_lds, const uint8_t *nth8, const uint32_t *ord8, bool valid, uint32_t n,
+__device__ __forceinline__ void ww_turn(WWR<NB> &s, DevRow &row, const DevRow *rows, const DevCond *conds, uint32_t cshape, void *wave_lds, const uint8_t *nth8, const uint32_t *ord8, bool valid, uint32_t n,
                                         uint32_t nw, uint32_t phase0_idx, uint32_t rkey, uint32_t turn, uint32_t &tk_io,
                                         bool trace, uint32_t human, Deal &deal, bool deal_now, uint32_t &ev_newly, uint64_t &ev_choice, Stamps *stamps = nullptr) {
     // human: players the host drives (never acted for here)
@@ -569,7 +623,7 @@ __device__ __forceinline__ void ww_turn(WWR<NB> &s, DevRow &row, const DevRow *r
         T = X & alive & (comp == COMP_ACTION ? ALL : 0u);
     }
     if (GENERIC && (row.r0 & ROW_GENERIC) && comp == COMP_ACTION)        // or / in [..] / numeric comparisons: the clause form
-        T = ww_cond_generic<NB>(s, conds[s.phase], ALL) & alive;
+        T = ww_cond_generic<NB>(s, conds[s.phase], ALL, cshape) & alive;
     if (GE_STAMPS && stamps) { asm volatile("" :: "v"(T)); stamps->mark(0); }        // [end of previous turn .. row in registers]
 
     // ---- PhaseNode, the part that does not depend on this turn's actions (nobody dies before the Referee):
@@ -891,7 +945,7 @@ __device__ __forceinline__ uint32_t even_bits(uint32_t x) {
 // QUEUE: bot actions through the wavefront work queue (see ww_turn) - pays from 8 players on, where the
 // first turn of a vote has 7-11 due bots in some room of every wavefront; TABLE: n-th-set-bit from LDS
 template <int NB, bool QUEUE, bool TABLE, bool GENERIC = false>
-__device__ __forceinline__ void tt_turn(TT<NB> &s, uint32_t &done, DevRow &row, const DevRow *rows, const DevCond *conds, void *wave_lds, const uint8_t *nth8,
+__device__ __forceinline__ void tt_turn(TT<NB> &s, uint32_t &done, DevRow &row, const DevRow *rows, const DevCond *conds, uint32_t cshape, void *wave_lds, const uint8_t *nth8,
                                         bool valid, uint32_t n, uint32_t rounds,
                                         uint32_t phase0_idx, uint32_t rkey, uint32_t turn,
                                         bool trace, uint32_t human, uint32_t &ev_newly, uint64_t &ev_choice) {
@@ -922,7 +976,7 @@ __device__ __forceinline__ void tt_turn(TT<NB> &s, uint32_t &done, DevRow &row, 
         T = X & ALL;
     }
     if (GENERIC && (row.r0 & ROW_GENERIC) && comp == COMP_ACTION)        // the clause form (see ww_turn)
-        T = tt_cond_generic<NB>(s, conds[s.phase], ALL);
+        T = tt_cond_generic<NB>(s, conds[s.phase], ALL, cshape);
 
     uint32_t newly = 0;
     {

@@ -246,11 +246,18 @@ constexpr uint32_t ROW_GENERIC = 1u << 21;
 // conjunction of base predicates.  lit[c][l]: bits 0..15 = base-predicate bit set, or lo | hi << 8 of a numeric
 // range; 16..18 = numeric field (GE_NUM_*); 28..29 = kind (1 base set, 2 numeric); 30 = negated.
 // meta: n_clauses [2:0], length of clause c [4 + 4c +: 3].
-struct DevCond { uint32_t lit[4][4]; uint32_t meta, pad[3]; };
+// prep[][].a0 / .a1 (werewolf N <= 8 only): the same literal prepared for the packed predicate words - a base set as two
+// v_perm_b32 selectors that gather its fields' bytes out of (W1:W0) and (W2:W2) (0x0C = zero byte where it has none; OR-fold
+// of the gathered bytes = "has any of them"); a numeric range over the selected-target nibbles as lo in every byte and
+// hi | 0x80 in every byte (two byte-wise subtractions answer lo <= v <= hi for four players at once).
+// prep[k][l] = {lit, aux0, aux1, 0}: one 16-byte load per literal.
+struct DevLit { uint32_t w, a0, a1, pad; };
+struct DevCond { uint32_t lit[4][4]; uint32_t meta, pad[3]; DevLit prep[4][4]; };
 
 struct DevTable {
     DevRow rows[32];
-    int32_t n_phases, rounds, n_players, pad;
+    int32_t n_phases, rounds, n_players;
+    uint32_t cond_shape;     // generic rows: largest clause count [2:0] and clause length [6:4], any base-set literal [8], any numeric literal [9]
     uint8_t nth8[2048];      // n-th-set-bit table (ge_device.h), copied to LDS by the large-batch build
     uint32_t ord8[256];      // ord8[mask] = the positions of the set bits of an 8-bit mask, ascending, one nibble each
     DevCond conds[32];       // clause form of the generic rows (read from global memory by the generic kernel builds only)

@@ -154,6 +154,7 @@ __device__ __forceinline__ void run_ww(const SegDev *__restrict__ sgp, const Ste
     }
     const DevRow row0 = rows[sg.phase0_idx];
     const uint32_t turn0 = a.turn0 + (a.turn_dev ? *a.turn_dev : 0u);   // uniform (scalar load)
+    const uint32_t cshape = GENERIC ? __builtin_amdgcn_readfirstlane(tables[sg.table_idx].cond_shape) : 0u;
     // Role deals are keyed by (room, game index), so they can be prepared before the turn that applies
     // them.  Entering the role-assignment phase is rare per room (once a game) but in a wavefront of 64
     // rooms some room does it on ~80 % of the turns; instead of running the deal for that one lane, every
@@ -187,12 +188,12 @@ __device__ __forceinline__ void run_ww(const SegDev *__restrict__ sgp, const Ste
             const bool deal_now = ahead && (t & (GE_DEAL_PERIOD - 1u)) == 0u;        // wave-uniform
             Stamps *const stp = (GE_STAMPS && a.stamps) ? &stamps : nullptr;
             if (LOWOCC && GE_TPL_DEAL) {                                              // two copies of the turn, a scalar branch between them
-                if (deal_now) ww_turn<NB, GE_WAVE_QUEUE, LOWOCC, GENERIC, 1>(s, row, rows, tables[sg.table_idx].conds, lw, nth8, ord8, valid, sg.n_players, sg.nw, sg.phase0_idx, rk, turn0 + t, tk,
+                if (deal_now) ww_turn<NB, GE_WAVE_QUEUE, LOWOCC, GENERIC, 1>(s, row, rows, tables[sg.table_idx].conds, cshape, lw, nth8, ord8, valid, sg.n_players, sg.nw, sg.phase0_idx, rk, turn0 + t, tk,
                                                                               trace, sg.human_mask, deal, true, ev_newly, ev_choice, stp);
-                else ww_turn<NB, GE_WAVE_QUEUE, LOWOCC, GENERIC, 0>(s, row, rows, tables[sg.table_idx].conds, lw, nth8, ord8, valid, sg.n_players, sg.nw, sg.phase0_idx, rk, turn0 + t, tk,
+                else ww_turn<NB, GE_WAVE_QUEUE, LOWOCC, GENERIC, 0>(s, row, rows, tables[sg.table_idx].conds, cshape, lw, nth8, ord8, valid, sg.n_players, sg.nw, sg.phase0_idx, rk, turn0 + t, tk,
                                                                     trace, sg.human_mask, deal, false, ev_newly, ev_choice, stp);
             } else {
-                ww_turn<NB, GE_WAVE_QUEUE, LOWOCC, GENERIC, 2>(s, row, rows, tables[sg.table_idx].conds, lw, nth8, ord8, valid, sg.n_players, sg.nw, sg.phase0_idx, rk, turn0 + t, tk,
+                ww_turn<NB, GE_WAVE_QUEUE, LOWOCC, GENERIC, 2>(s, row, rows, tables[sg.table_idx].conds, cshape, lw, nth8, ord8, valid, sg.n_players, sg.nw, sg.phase0_idx, rk, turn0 + t, tk,
                                                                trace, sg.human_mask, deal, deal_now, ev_newly, ev_choice, stp);
             }
             if (trace && valid) store_event(sg.trace, sg.rooms_padded, t, room, turn0 + t, p, s.phase, restarted, ev_newly, ev_choice);
@@ -245,6 +246,7 @@ __device__ __forceinline__ void run_tt(const SegDev *__restrict__ sgp, const Ste
     L::unpack(iw, s0);
     const DevRow row0 = rows[sg.phase0_idx];
     const uint32_t turn0 = a.turn0 + (a.turn_dev ? *a.turn_dev : 0u);
+    const uint32_t cshape = GENERIC ? __builtin_amdgcn_readfirstlane(tables[sg.table_idx].cond_shape) : 0u;
     uint32_t done = tt_done_mask<NB>(s.rounds, sg.rounds);   // who has spoken all agreed rounds (ge_device.h)
     const uint32_t done0 = tt_done_mask<NB>(s0.rounds, sg.rounds);
     for (uint32_t t = 0; t < a.n_turns; t++) {
@@ -260,7 +262,7 @@ __device__ __forceinline__ void run_tt(const SegDev *__restrict__ sgp, const Ste
         const uint32_t p = s.phase;
         uint32_t ev_newly = 0;
         uint64_t ev_choice = 0;
-        tt_turn<NB, QUEUE, !LOWOCC, GENERIC>(s, done, row, rows, tables[sg.table_idx].conds, lw, nth8, valid, sg.n_players, sg.rounds, sg.phase0_idx, rk, turn0 + t, a.trace != 0u, sg.human_mask, ev_newly, ev_choice);
+        tt_turn<NB, QUEUE, !LOWOCC, GENERIC>(s, done, row, rows, tables[sg.table_idx].conds, cshape, lw, nth8, valid, sg.n_players, sg.rounds, sg.phase0_idx, rk, turn0 + t, a.trace != 0u, sg.human_mask, ev_newly, ev_choice);
         if (a.trace && valid) store_event(sg.trace, sg.rooms_padded, t, room, turn0 + t, p, s.phase, restarted, ev_newly, ev_choice);
     }
     if (!valid) return;
@@ -685,7 +687,7 @@ DevRow to_dev_row(const ge_game_table &tb, const ge_phase_row &r, uint32_t kind)
     return d;
 }
 
-DevCond to_dev_cond(const ge_phase_row &r) {
+DevCond to_dev_cond(const ge_phase_row &r, bool ww8 = false) {
     DevCond c;
     memset(&c, 0, sizeof c);
     const uint32_t ncl = r.n_clauses <= GE_MAX_CLAUSES ? r.n_clauses : GE_MAX_CLAUSES;
@@ -697,6 +699,22 @@ DevCond to_dev_cond(const ge_phase_row &r) {
             const ge_literal &x = r.clause[k][l];
             const uint32_t payload = x.kind == GE_LIT_NUM ? ((uint32_t)x.lo | ((uint32_t)x.hi << 8)) : x.bases;
             c.lit[k][l] = payload | ((uint32_t)(x.num_field & 7u) << 16) | ((uint32_t)(x.kind & 3u) << 28) | (x.neg ? 1u << 30 : 0u);
+            c.prep[k][l].w = c.lit[k][l];
+            if (!ww8) continue;
+            if (x.kind == GE_LIT_NUM) {
+                const uint32_t lo = x.lo > 15 ? 15u : x.lo, hi = x.hi > 15 ? 15u : x.hi;
+                c.prep[k][l].a0 = lo * 0x01010101u;
+                c.prep[k][l].a1 = (hi * 0x01010101u) | 0x80808080u;
+                if (x.lo > x.hi) { c.prep[k][l].a0 = 0x7F7F7F7Fu; c.prep[k][l].a1 = 0x80808080u; }      // empty range: lo above every value
+            } else {
+                uint32_t sa = 0x0C0C0C0Cu, sb = 0x0C0C0C0Cu, na = 0, nb = 0;          // 0x0C: constant zero byte
+                for (uint32_t f = 0; f < 8; f++)
+                    if ((x.bases >> f) & 1u) { if (na < 4) sa = (sa & ~(0xFFu << (8 * na))) | (f << (8 * na)); na++; }
+                for (uint32_t f = 8; f < 12; f++)
+                    if ((x.bases >> f) & 1u) { sb = (sb & ~(0xFFu << (8 * nb))) | ((f - 8u) << (8 * nb)); nb++; }
+                c.prep[k][l].a0 = sa; c.prep[k][l].a1 = sb;
+                if (na > 4) c.meta |= 1u << 31;                                       // (no grammar produces this) - marks the row for the mask form
+            }
         }
     }
     return c;
@@ -1020,8 +1038,19 @@ static int create_impl(const ge_batch_desc *desc, ge_batch **out) {
                 memset(&dt, 0, sizeof dt);
                 for (int r = 0; r < s.table.n_phases; r++) {
                     dt.rows[r] = to_dev_row(s.table, s.table.rows[r], s.dev.kind);
-                    dt.conds[r] = to_dev_cond(s.table.rows[r]);
-                    if (s.table.rows[r].generic) b->generic = true;
+                    dt.conds[r] = to_dev_cond(s.table.rows[r], s.dev.kind == K_WW8);
+                    if (s.table.rows[r].generic) {
+                        b->generic = true;
+                        const ge_phase_row &pr = s.table.rows[r];
+                        uint32_t ncl = dt.cond_shape & 7u, len = (dt.cond_shape >> 4) & 7u, kinds = dt.cond_shape & 0x300u;
+                        ncl = pr.n_clauses > ncl ? pr.n_clauses : ncl;
+                        for (uint32_t k = 0; k < pr.n_clauses && k < GE_MAX_CLAUSES; k++) {
+                            len = pr.clause_len[k] > len ? pr.clause_len[k] : len;
+                            for (uint32_t l = 0; l < pr.clause_len[k] && l < GE_MAX_TERMS; l++)
+                                kinds |= pr.clause[k][l].kind == GE_LIT_NUM ? 0x200u : 0x100u;
+                        }
+                        dt.cond_shape = (ncl > 4u ? 4u : ncl) | ((len > 4u ? 4u : len) << 4) | kinds;
+                    }
                 }
                 dt.n_phases = s.table.n_phases; dt.rounds = s.table.rounds; dt.n_players = (int32_t)s.dev.n_players;
                 fill_nth8_host(dt.nth8);

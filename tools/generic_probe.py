@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""What a DSL with generic target conditions (or / in [..] / numeric comparisons: the GENERIC kernel builds)
+costs against the shipped game whose conditions are plain conjunctions.  The re-conditioned Werewolf below is the one
+the reference-run goldens traj_variant_ww_generic_* were produced with.  python tools/generic_probe.py"""
+import copy, json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from game_engine_amd import GameTable, RoomBatch
+
+with open(os.path.join(ROOT, "tests", "golden", "dsl", "werewolf-(mafia).json"), encoding="utf-8") as f:
+    base = json.load(f)
+gen = copy.deepcopy(base)
+def cond(pid, c):
+    gen["phases"][str(pid)]["completion_criteria"]["target_players"]["condition"] = c
+for pid in (2, 10):
+    cond(pid, "player.role in ['Werewolf'] and player.is_alive == true and player.team != 'villagers'")
+for pid in (3, 11):
+    cond(pid, "player.role in ['Doctor', 'Medic'] and player.is_alive != false")
+for pid in (4, 12):
+    cond(pid, "player.role == 'Detective' and player.is_alive == true and player.selected_target_id == 0 "
+              "or player.role == 'Detective' and player.selected_target_id > 0")
+for pid in (7, 15):
+    cond(pid, "player.can_vote == true and player.is_alive == true and player.selected_target_id < 5")
+for rooms in (65536, 1048576):
+    res = {}
+    for name, dsl in (("shipped", base), ("generic", gen)):
+        tb = GameTable(dsl)
+        with RoomBatch([(tb, 8, rooms)], seed=0xC0FFEE, max_fuse=64, restart=True) as b:
+            b.step(256); b.sync()
+            b.set_timing(True); b.kernel_time(reset=True)
+            b.step(512); b.sync()
+            ms, _ = b.kernel_time(reset=True)
+            res[name] = ms * 1e3 / 512
+    print(f"werewolf x8, {rooms:>8} rooms: shipped conditions {res['shipped']:7.3f} us/turn ({rooms / res['shipped'] * 1e6:.3e} steps/s)   "
+          f"generic conditions {res['generic']:7.3f} us/turn ({rooms / res['generic'] * 1e6:.3e} steps/s, x{res['generic'] / res['shipped']:.2f})", flush=True)
