@@ -487,8 +487,8 @@ template <typename LITMASK> __device__ __forceinline__ uint32_t eval_clauses(con
 }
 
 // N <= 8: literals prepared for the packed predicate words (DevCond::prep, built by to_dev_cond)
-__device__ __forceinline__ uint32_t ww8_cond_generic(const WWR<8> &s, const DevCond &c, uint32_t all, uint32_t shape) {
-    const bool any_base = (shape >> 8) & 1u, any_num = (shape >> 9) & 1u;       // wave-uniform
+// `slots` (DevTable::cond_slots, wave-uniform): which (clause, literal) slots hold a base set / a numeric range in some row
+__device__ __forceinline__ uint32_t ww8_cond_generic(const WWR<8> &s, const DevCond &c, uint32_t all, uint32_t shape, uint32_t slots) {
     const uint32_t ncl = c.meta & 7u;
     const uint32_t max_ncl = shape & 7u, max_len = (shape >> 4) & 7u;
     // the selected-target nibbles of the even / odd players, one per byte
@@ -505,6 +505,7 @@ __device__ __forceinline__ uint32_t ww8_cond_generic(const WWR<8> &s, const DevC
             const DevLit q = c.prep[k][l];                    // one 16-byte load
             const uint32_t w = q.w, a0 = q.a0, a1 = q.a1;
             uint32_t x = 0;
+            const bool any_base = (slots >> (4 * k + l)) & 1u, any_num = (slots >> (16 + 4 * k + l)) & 1u;   // wave-uniform
             if (any_base) {                                   // gather the set's fields, OR-fold the four bytes
                 uint32_t g = __builtin_amdgcn_perm(s.W[1], s.W[0], a0) | __builtin_amdgcn_perm(s.W[2], s.W[2], a1);
                 g |= g >> 16; g |= g >> 8;
@@ -515,7 +516,7 @@ __device__ __forceinline__ uint32_t ww8_cond_generic(const WWR<8> &s, const DevC
                 const uint32_t io = ((od | 0x80808080u) - a0) & (a1 - od) & 0x80808080u;
                 const uint32_t p = (ie >> 7) | (io >> 6);     // bits 0 / 1 of every byte = the byte's even / odd player
                 const uint32_t r = (p | (p >> 6) | (p >> 12) | (p >> 18)) & 0xFFu;
-                x = ((w >> 28) & 3u) == 1u ? x : r;
+                x = (any_base && ((w >> 28) & 3u) == 1u) ? x : r;
             }
             x ^= (w >> 30) & 1u ? all : 0u;
             m &= (uint32_t)l < len ? x : all;
@@ -525,9 +526,9 @@ __device__ __forceinline__ uint32_t ww8_cond_generic(const WWR<8> &s, const DevC
     return T & all;
 }
 
-template <int NB> __device__ __forceinline__ uint32_t ww_cond_generic(const WWR<NB> &s, const DevCond &c, uint32_t all, uint32_t shape) {
+template <int NB> __device__ __forceinline__ uint32_t ww_cond_generic(const WWR<NB> &s, const DevCond &c, uint32_t all, uint32_t shape, uint32_t slots) {
     if constexpr (NB <= 8) {
-        if (!(c.meta >> 31)) return ww8_cond_generic(s, c, all, shape);
+        if (!(c.meta >> 31)) return ww8_cond_generic(s, c, all, shape, slots);
     }
     const bool any_base = (shape >> 8) & 1u, any_num = (shape >> 9) & 1u;       // wave-uniform
     return eval_clauses(c, all, shape, [&](uint32_t w) -> uint32_t {
@@ -569,7 +570,7 @@ template <int NB> __device__ __forceinline__ uint32_t tt_cond_generic(const TT<N
 // DEAL: 1 / 0 = this instantiation is for the turns that do / do not prepare role deals (the lone-wavefront build compiles
 // the turn twice rather than test a wave-uniform flag inside an exec-mask region every turn); 2 = `deal_now` decides
 template <int NB, bool QUEUE, bool LOWOCC, bool GENERIC = false, int DEAL = 2>
-__device__ __forceinline__ void ww_turn(WWR<NB> &s, DevRow &row, const DevRow *rows, const DevCond *conds, uint32_t cshape, void *wave_lds, const uint8_t *nth8, const uint32_t *ord8, bool valid, uint32_t n,
+__device__ __forceinline__ void ww_turn(WWR<NB> &s, DevRow &row, const DevRow *rows, const DevCond *conds, uint32_t cshape, uint32_t cslots, void *wave_lds, const uint8_t *nth8, const uint32_t *ord8, bool valid, uint32_t n,
                                         uint32_t nw, uint32_t phase0_idx, uint32_t rkey, uint32_t turn, uint32_t &tk_io,
                                         bool trace, uint32_t human, Deal &deal, bool deal_now, uint32_t &ev_newly, uint64_t &ev_choice, Stamps *stamps = nullptr) {
     // human: players the host drives (never acted for here)
@@ -623,7 +624,7 @@ __device__ __forceinline__ void ww_turn(WWR<NB> &s, DevRow &row, const DevRow *r
         T = X & alive & (comp == COMP_ACTION ? ALL : 0u);
     }
     if (GENERIC && (row.r0 & ROW_GENERIC) && comp == COMP_ACTION)        // or / in [..] / numeric comparisons: the clause form
-        T = ww_cond_generic<NB>(s, conds[s.phase], ALL, cshape) & alive;
+        T = ww_cond_generic<NB>(s, conds[s.phase], ALL, cshape, cslots) & alive;
     if (GE_STAMPS && stamps) { asm volatile("" :: "v"(T)); stamps->mark(0); }        // [end of previous turn .. row in registers]
 
     // ---- PhaseNode, the part that does not depend on this turn's actions (nobody dies before the Referee):
@@ -945,7 +946,7 @@ __device__ __forceinline__ uint32_t even_bits(uint32_t x) {
 // QUEUE: bot actions through the wavefront work queue (see ww_turn) - pays from 8 players on, where the
 // first turn of a vote has 7-11 due bots in some room of every wavefront; TABLE: n-th-set-bit from LDS
 template <int NB, bool QUEUE, bool TABLE, bool GENERIC = false>
-__device__ __forceinline__ void tt_turn(TT<NB> &s, uint32_t &done, DevRow &row, const DevRow *rows, const DevCond *conds, uint32_t cshape, void *wave_lds, const uint8_t *nth8,
+__device__ __forceinline__ void tt_turn(TT<NB> &s, uint32_t &done, DevRow &row, const DevRow *rows, const DevCond *conds, uint32_t cshape, uint32_t cslots, void *wave_lds, const uint8_t *nth8,
                                         bool valid, uint32_t n, uint32_t rounds,
                                         uint32_t phase0_idx, uint32_t rkey, uint32_t turn,
                                         bool trace, uint32_t human, uint32_t &ev_newly, uint64_t &ev_choice) {

@@ -258,6 +258,7 @@ struct DevTable {
     DevRow rows[32];
     int32_t n_phases, rounds, n_players;
     uint32_t cond_shape;     // generic rows: largest clause count [2:0] and clause length [6:4], any base-set literal [8], any numeric literal [9]
+    uint32_t cond_slots;     // generic rows: bit 4k + l = some row has a base-set literal in slot l of clause k; bit 16 + 4k + l = a numeric one
     uint8_t nth8[2048];      // n-th-set-bit table (ge_device.h), copied to LDS by the large-batch build
     uint32_t ord8[256];      // ord8[mask] = the positions of the set bits of an 8-bit mask, ascending, one nibble each
     DevCond conds[32];       // clause form of the generic rows (read from global memory by the generic kernel builds only)

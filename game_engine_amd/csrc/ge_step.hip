@@ -155,6 +155,7 @@ __device__ __forceinline__ void run_ww(const SegDev *__restrict__ sgp, const Ste
     const DevRow row0 = rows[sg.phase0_idx];
     const uint32_t turn0 = a.turn0 + (a.turn_dev ? *a.turn_dev : 0u);   // uniform (scalar load)
     const uint32_t cshape = GENERIC ? __builtin_amdgcn_readfirstlane(tables[sg.table_idx].cond_shape) : 0u;
+    const uint32_t cslots = GENERIC ? __builtin_amdgcn_readfirstlane(tables[sg.table_idx].cond_slots) : 0u;
     // Role deals are keyed by (room, game index), so they can be prepared before the turn that applies
     // them.  Entering the role-assignment phase is rare per room (once a game) but in a wavefront of 64
     // rooms some room does it on ~80 % of the turns; instead of running the deal for that one lane, every
@@ -188,12 +189,12 @@ __device__ __forceinline__ void run_ww(const SegDev *__restrict__ sgp, const Ste
             const bool deal_now = ahead && (t & (GE_DEAL_PERIOD - 1u)) == 0u;        // wave-uniform
             Stamps *const stp = (GE_STAMPS && a.stamps) ? &stamps : nullptr;
             if (LOWOCC && GE_TPL_DEAL) {                                              // two copies of the turn, a scalar branch between them
-                if (deal_now) ww_turn<NB, GE_WAVE_QUEUE, LOWOCC, GENERIC, 1>(s, row, rows, tables[sg.table_idx].conds, cshape, lw, nth8, ord8, valid, sg.n_players, sg.nw, sg.phase0_idx, rk, turn0 + t, tk,
+                if (deal_now) ww_turn<NB, GE_WAVE_QUEUE, LOWOCC, GENERIC, 1>(s, row, rows, tables[sg.table_idx].conds, cshape, cslots, lw, nth8, ord8, valid, sg.n_players, sg.nw, sg.phase0_idx, rk, turn0 + t, tk,
                                                                               trace, sg.human_mask, deal, true, ev_newly, ev_choice, stp);
-                else ww_turn<NB, GE_WAVE_QUEUE, LOWOCC, GENERIC, 0>(s, row, rows, tables[sg.table_idx].conds, cshape, lw, nth8, ord8, valid, sg.n_players, sg.nw, sg.phase0_idx, rk, turn0 + t, tk,
+                else ww_turn<NB, GE_WAVE_QUEUE, LOWOCC, GENERIC, 0>(s, row, rows, tables[sg.table_idx].conds, cshape, cslots, lw, nth8, ord8, valid, sg.n_players, sg.nw, sg.phase0_idx, rk, turn0 + t, tk,
                                                                     trace, sg.human_mask, deal, false, ev_newly, ev_choice, stp);
             } else {
-                ww_turn<NB, GE_WAVE_QUEUE, LOWOCC, GENERIC, 2>(s, row, rows, tables[sg.table_idx].conds, cshape, lw, nth8, ord8, valid, sg.n_players, sg.nw, sg.phase0_idx, rk, turn0 + t, tk,
+                ww_turn<NB, GE_WAVE_QUEUE, LOWOCC, GENERIC, 2>(s, row, rows, tables[sg.table_idx].conds, cshape, cslots, lw, nth8, ord8, valid, sg.n_players, sg.nw, sg.phase0_idx, rk, turn0 + t, tk,
                                                                trace, sg.human_mask, deal, deal_now, ev_newly, ev_choice, stp);
             }
             if (trace && valid) store_event(sg.trace, sg.rooms_padded, t, room, turn0 + t, p, s.phase, restarted, ev_newly, ev_choice);
@@ -247,6 +248,7 @@ __device__ __forceinline__ void run_tt(const SegDev *__restrict__ sgp, const Ste
     const DevRow row0 = rows[sg.phase0_idx];
     const uint32_t turn0 = a.turn0 + (a.turn_dev ? *a.turn_dev : 0u);
     const uint32_t cshape = GENERIC ? __builtin_amdgcn_readfirstlane(tables[sg.table_idx].cond_shape) : 0u;
+    const uint32_t cslots = GENERIC ? __builtin_amdgcn_readfirstlane(tables[sg.table_idx].cond_slots) : 0u;
     uint32_t done = tt_done_mask<NB>(s.rounds, sg.rounds);   // who has spoken all agreed rounds (ge_device.h)
     const uint32_t done0 = tt_done_mask<NB>(s0.rounds, sg.rounds);
     for (uint32_t t = 0; t < a.n_turns; t++) {
@@ -262,7 +264,7 @@ __device__ __forceinline__ void run_tt(const SegDev *__restrict__ sgp, const Ste
         const uint32_t p = s.phase;
         uint32_t ev_newly = 0;
         uint64_t ev_choice = 0;
-        tt_turn<NB, QUEUE, !LOWOCC, GENERIC>(s, done, row, rows, tables[sg.table_idx].conds, cshape, lw, nth8, valid, sg.n_players, sg.rounds, sg.phase0_idx, rk, turn0 + t, a.trace != 0u, sg.human_mask, ev_newly, ev_choice);
+        tt_turn<NB, QUEUE, !LOWOCC, GENERIC>(s, done, row, rows, tables[sg.table_idx].conds, cshape, cslots, lw, nth8, valid, sg.n_players, sg.rounds, sg.phase0_idx, rk, turn0 + t, a.trace != 0u, sg.human_mask, ev_newly, ev_choice);
         if (a.trace && valid) store_event(sg.trace, sg.rooms_padded, t, room, turn0 + t, p, s.phase, restarted, ev_newly, ev_choice);
     }
     if (!valid) return;
@@ -299,8 +301,8 @@ extern __shared__ __align__(16) unsigned char ge_lds[];
 
 // single-kind batch (the benchmark configurations): one instantiation per record layout, so each
 // gets its own register allocation
-// GENERIC: some row of the table has a generic target condition (DevCond); those builds exist for the large-batch
-// form only and serve every batch size of such a table
+// GENERIC: some row of the table has a generic target condition (DevCond); single-game batches get both forms of those
+// builds as well, a mixed batch with a generic table runs the large-batch form at every size
 // minimum wavefronts per SIMD asked of the register allocator for the large-batch Werewolf builds (see GE_SHADOW_HI)
 #ifndef GE_WW12_WAVES
 #define GE_WW12_WAVES 6
@@ -1046,8 +1048,10 @@ static int create_impl(const ge_batch_desc *desc, ge_batch **out) {
                         ncl = pr.n_clauses > ncl ? pr.n_clauses : ncl;
                         for (uint32_t k = 0; k < pr.n_clauses && k < GE_MAX_CLAUSES; k++) {
                             len = pr.clause_len[k] > len ? pr.clause_len[k] : len;
-                            for (uint32_t l = 0; l < pr.clause_len[k] && l < GE_MAX_TERMS; l++)
+                            for (uint32_t l = 0; l < pr.clause_len[k] && l < GE_MAX_TERMS; l++) {
                                 kinds |= pr.clause[k][l].kind == GE_LIT_NUM ? 0x200u : 0x100u;
+                                dt.cond_slots |= 1u << ((pr.clause[k][l].kind == GE_LIT_NUM ? 16u : 0u) + 4u * k + l);
+                            }
                         }
                         dt.cond_shape = (ncl > 4u ? 4u : ncl) | ((len > 4u ? 4u : len) << 4) | kinds;
                     }
@@ -1108,15 +1112,16 @@ static int reset_impl(ge_batch *b) {
 static hipError_t launch_step(const ge_batch *b, const StepArgs &a, hipStream_t st) {
     const dim3 grid(b->n_blocks), block(b->block_threads);
 #define GE_LAUNCH(KERNEL, QUEUE, LOW) hipLaunchKernelGGL(KERNEL, grid, block, step_lds_bytes(QUEUE, LOW, b->block_threads), st, a, b->segs_dev, b->tables)
-    const bool low = a.lowocc != 0u && !b->generic;           // generic tables: the large-batch build serves every size
+    const bool low = a.lowocc != 0u && !(b->generic && b->segs.size() > 1);   // mixed batches with generic tables: the large-batch build serves every size
     if (b->generic) {
+        // generic target conditions: single-game batches get both forms too; mixed batches the large-batch one
         if (b->segs.size() > 1) GE_LAUNCH((ge_step_kernel_mixed<false, true>), true, false);
         else switch (b->segs[0].dev.kind) {
-        case K_WW8: GE_LAUNCH((ge_step_kernel<K_WW8, false, true>), true, false); break;
-        case K_WW12: GE_LAUNCH((ge_step_kernel<K_WW12, false, true>), true, false); break;
-        case K_TT4: GE_LAUNCH((ge_step_kernel<K_TT4, false, true>), true, false); break;
-        case K_TT8: GE_LAUNCH((ge_step_kernel<K_TT8, false, true>), true, false); break;
-        default: GE_LAUNCH((ge_step_kernel<K_TT12, false, true>), true, false); break;
+        case K_WW8: if (low) GE_LAUNCH((ge_step_kernel<K_WW8, true, true>), true, true); else GE_LAUNCH((ge_step_kernel<K_WW8, false, true>), true, false); break;
+        case K_WW12: if (low) GE_LAUNCH((ge_step_kernel<K_WW12, true, true>), true, true); else GE_LAUNCH((ge_step_kernel<K_WW12, false, true>), true, false); break;
+        case K_TT4: if (low) GE_LAUNCH((ge_step_kernel<K_TT4, true, true>), tt_uses_queue(4, true), true); else GE_LAUNCH((ge_step_kernel<K_TT4, false, true>), true, false); break;
+        case K_TT8: if (low) GE_LAUNCH((ge_step_kernel<K_TT8, true, true>), tt_uses_queue(8, true), true); else GE_LAUNCH((ge_step_kernel<K_TT8, false, true>), true, false); break;
+        default: if (low) GE_LAUNCH((ge_step_kernel<K_TT12, true, true>), tt_uses_queue(12, true), true); else GE_LAUNCH((ge_step_kernel<K_TT12, false, true>), true, false); break;
         }
     } else if (b->segs.size() > 1) {
         if (low) GE_LAUNCH(ge_step_kernel_mixed<true>, true, true); else GE_LAUNCH(ge_step_kernel_mixed<false>, true, false);
