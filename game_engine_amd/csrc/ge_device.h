@@ -478,7 +478,7 @@ template <typename LITMASK> __device__ __forceinline__ uint32_t eval_clauses(con
         for (int l = 0; l < 4; l++) {
             if ((uint32_t)l >= max_len) break;                // wave-uniform
             const uint32_t w = c.lit[k][l];
-            const uint32_t x = lit_mask(w) ^ ((w >> 30) & 1u ? all : 0u);
+            const uint32_t x = lit_mask(w, k, l) ^ ((w >> 30) & 1u ? all : 0u);
             m &= (uint32_t)l < len ? x : all;
         }
         T |= (uint32_t)k < ncl ? m : 0u;
@@ -526,38 +526,49 @@ __device__ __forceinline__ uint32_t ww8_cond_generic(const WWR<8> &s, const DevC
     return T & all;
 }
 
-template <int NB> __device__ __forceinline__ uint32_t ww_cond_generic(const WWR<NB> &s, const DevCond &c, uint32_t all, uint32_t shape, uint32_t slots) {
+template <int NB> __device__ __forceinline__ uint32_t ww_cond_generic(const WWR<NB> &s, const DevCond &c, uint32_t all, CondShape cs) {
     if constexpr (NB <= 8) {
-        if (!(c.meta >> 31)) return ww8_cond_generic(s, c, all, shape, slots);
+        if (!(c.meta >> 31)) return ww8_cond_generic(s, c, all, cs.shape, cs.slots);
     }
-    const bool any_base = (shape >> 8) & 1u, any_num = (shape >> 9) & 1u;       // wave-uniform
-    return eval_clauses(c, all, shape, [&](uint32_t w) -> uint32_t {
+    return eval_clauses(c, all, cs.shape, [&](uint32_t w, int k, int l) -> uint32_t {
+        const bool any_base = (cs.slots >> (4 * k + l)) & 1u, any_num = (cs.slots >> (16 + 4 * k + l)) & 1u;   // wave-uniform
         uint32_t m = 0;
         if (any_base) m = ww_base_mask<NB>(s, w & 0xFFFFu);
         if (any_num) {
             const uint32_t r = range_mask<NB, 4>(s.sel, w & 0xFFu, (w >> 8) & 0xFFu);   // GE_NUM_SELECTED_TARGET is the pack's only numeric field
-            m = ((w >> 28) & 3u) == 1u ? m : r;
+            m = (any_base && ((w >> 28) & 3u) == 1u) ? m : r;
         }
         return m;
     });
 }
 
-template <int NB> __device__ __forceinline__ uint32_t tt_cond_generic(const TT<NB> &s, const DevCond &c, uint32_t all, uint32_t shape) {
-    return eval_clauses(c, all, shape, [&](uint32_t w) -> uint32_t {
-        if (((w >> 28) & 3u) == 1u) {
+template <int NB> __device__ __forceinline__ uint32_t tt_cond_generic(const TT<NB> &s, const DevCond &c, uint32_t all, CondShape cs) {
+    return eval_clauses(c, all, cs.shape, [&](uint32_t w, int k, int l) -> uint32_t {
+        // wave-uniform: what slot (k, l) holds in some row of the table - a base set, and / or a range over which fields
+        const bool any_base = (cs.slots >> (4 * k + l)) & 1u;
+        const uint32_t flds = ((4 * k + l) < 8 ? cs.f0 >> (4 * ((4 * k + l) & 7)) : cs.f1 >> (4 * ((4 * k + l) & 7))) & 15u;
+        uint32_t m = 0;
+        if (any_base) {
             const uint32_t set = w & 0xFFFFu;
-            return ((set & 1u) ? s.speaker : 0u) | ((set & 2u) ? s.submitted : 0u) | ((set & 4u) ? s.revealed : 0u) |
-                   ((set & 8u) ? s.can_vote : 0u) | ((set & 16u) ? s.has_voted : 0u);
+            m = ((set & 1u) ? s.speaker : 0u) | ((set & 2u) ? s.submitted : 0u) | ((set & 4u) ? s.revealed : 0u) |
+                ((set & 8u) ? s.can_vote : 0u) | ((set & 16u) ? s.has_voted : 0u);
         }
-        const uint32_t lo = w & 0xFFu, hi = (w >> 8) & 0xFFu, f = (w >> 16) & 7u;
-        if (f == 1u) return range_mask<NB, 2>(s.lie, lo, hi);                   // GE_NUM_LIE_INDEX
-        if (f == 2u) return range_mask<NB, 2>(s.vote, lo, hi);                  // GE_NUM_VOTE_CHOICE
-        if (f == 4u) return range_mask<NB, 4>(s.rounds, lo, hi);                // GE_NUM_ROUNDS_AS_SPEAKER
-        uint32_t m = 0;                                                         // GE_NUM_TOTAL_SCORE: a byte per player
+        if (flds) {
+            const uint32_t lo = w & 0xFFu, hi = (w >> 8) & 0xFFu, f = (w >> 16) & 7u;
+            uint32_t r = 0;
+            if (flds & 1u) r = f == 1u ? range_mask<NB, 2>(s.lie, lo, hi) : r;                    // GE_NUM_LIE_INDEX
+            if (flds & 2u) r = f == 2u ? range_mask<NB, 2>(s.vote, lo, hi) : r;                   // GE_NUM_VOTE_CHOICE
+            if (flds & 8u) r = f == 4u ? range_mask<NB, 4>(s.rounds, lo, hi) : r;                 // GE_NUM_ROUNDS_AS_SPEAKER
+            if (flds & 4u) {                                                                      // GE_NUM_TOTAL_SCORE: a byte per player
+                uint32_t q = 0;
 #pragma unroll
-        for (int i = 0; i < NB; i++) {
-            const uint32_t v = (s.score[i / 4] >> (8 * (i % 4))) & 255u;
-            m |= (v >= lo && v <= hi ? 1u : 0u) << i;
+                for (int i = 0; i < NB; i++) {
+                    const uint32_t v = (s.score[i / 4] >> (8 * (i % 4))) & 255u;
+                    q |= (v >= lo && v <= hi ? 1u : 0u) << i;
+                }
+                r = f == 3u ? q : r;
+            }
+            m = (any_base && ((w >> 28) & 3u) == 1u) ? m : r;
         }
         return m;
     });
@@ -570,7 +581,7 @@ template <int NB> __device__ __forceinline__ uint32_t tt_cond_generic(const TT<N
 // DEAL: 1 / 0 = this instantiation is for the turns that do / do not prepare role deals (the lone-wavefront build compiles
 // the turn twice rather than test a wave-uniform flag inside an exec-mask region every turn); 2 = `deal_now` decides
 template <int NB, bool QUEUE, bool LOWOCC, bool GENERIC = false, int DEAL = 2>
-__device__ __forceinline__ void ww_turn(WWR<NB> &s, DevRow &row, const DevRow *rows, const DevCond *conds, uint32_t cshape, uint32_t cslots, void *wave_lds, const uint8_t *nth8, const uint32_t *ord8, bool valid, uint32_t n,
+__device__ __forceinline__ void ww_turn(WWR<NB> &s, DevRow &row, const DevRow *rows, const DevCond *conds, CondShape cs, void *wave_lds, const uint8_t *nth8, const uint32_t *ord8, bool valid, uint32_t n,
                                         uint32_t nw, uint32_t phase0_idx, uint32_t rkey, uint32_t turn, uint32_t &tk_io,
                                         bool trace, uint32_t human, Deal &deal, bool deal_now, uint32_t &ev_newly, uint64_t &ev_choice, Stamps *stamps = nullptr) {
     // human: players the host drives (never acted for here)
@@ -624,7 +635,7 @@ __device__ __forceinline__ void ww_turn(WWR<NB> &s, DevRow &row, const DevRow *r
         T = X & alive & (comp == COMP_ACTION ? ALL : 0u);
     }
     if (GENERIC && (row.r0 & ROW_GENERIC) && comp == COMP_ACTION)        // or / in [..] / numeric comparisons: the clause form
-        T = ww_cond_generic<NB>(s, conds[s.phase], ALL, cshape, cslots) & alive;
+        T = ww_cond_generic<NB>(s, conds[s.phase], ALL, cs) & alive;
     if (GE_STAMPS && stamps) { asm volatile("" :: "v"(T)); stamps->mark(0); }        // [end of previous turn .. row in registers]
 
     // ---- PhaseNode, the part that does not depend on this turn's actions (nobody dies before the Referee):
@@ -946,7 +957,7 @@ __device__ __forceinline__ uint32_t even_bits(uint32_t x) {
 // QUEUE: bot actions through the wavefront work queue (see ww_turn) - pays from 8 players on, where the
 // first turn of a vote has 7-11 due bots in some room of every wavefront; TABLE: n-th-set-bit from LDS
 template <int NB, bool QUEUE, bool TABLE, bool GENERIC = false>
-__device__ __forceinline__ void tt_turn(TT<NB> &s, uint32_t &done, DevRow &row, const DevRow *rows, const DevCond *conds, uint32_t cshape, uint32_t cslots, void *wave_lds, const uint8_t *nth8,
+__device__ __forceinline__ void tt_turn(TT<NB> &s, uint32_t &done, DevRow &row, const DevRow *rows, const DevCond *conds, CondShape cs, void *wave_lds, const uint8_t *nth8,
                                         bool valid, uint32_t n, uint32_t rounds,
                                         uint32_t phase0_idx, uint32_t rkey, uint32_t turn,
                                         bool trace, uint32_t human, uint32_t &ev_newly, uint64_t &ev_choice) {
@@ -977,7 +988,7 @@ __device__ __forceinline__ void tt_turn(TT<NB> &s, uint32_t &done, DevRow &row, 
         T = X & ALL;
     }
     if (GENERIC && (row.r0 & ROW_GENERIC) && comp == COMP_ACTION)        // the clause form (see ww_turn)
-        T = tt_cond_generic<NB>(s, conds[s.phase], ALL, cshape);
+        T = tt_cond_generic<NB>(s, conds[s.phase], ALL, cs);
 
     uint32_t newly = 0;
     {

@@ -154,8 +154,9 @@ __device__ __forceinline__ void run_ww(const SegDev *__restrict__ sgp, const Ste
     }
     const DevRow row0 = rows[sg.phase0_idx];
     const uint32_t turn0 = a.turn0 + (a.turn_dev ? *a.turn_dev : 0u);   // uniform (scalar load)
-    const uint32_t cshape = GENERIC ? __builtin_amdgcn_readfirstlane(tables[sg.table_idx].cond_shape) : 0u;
-    const uint32_t cslots = GENERIC ? __builtin_amdgcn_readfirstlane(tables[sg.table_idx].cond_slots) : 0u;
+    CondShape cs = {0u, 0u, 0u, 0u};
+    if (GENERIC) cs = CondShape{(uint32_t)__builtin_amdgcn_readfirstlane(tables[sg.table_idx].cond_shape), (uint32_t)__builtin_amdgcn_readfirstlane(tables[sg.table_idx].cond_slots),
+                               (uint32_t)__builtin_amdgcn_readfirstlane(tables[sg.table_idx].cond_fields[0]), (uint32_t)__builtin_amdgcn_readfirstlane(tables[sg.table_idx].cond_fields[1])};
     // Role deals are keyed by (room, game index), so they can be prepared before the turn that applies
     // them.  Entering the role-assignment phase is rare per room (once a game) but in a wavefront of 64
     // rooms some room does it on ~80 % of the turns; instead of running the deal for that one lane, every
@@ -189,12 +190,12 @@ __device__ __forceinline__ void run_ww(const SegDev *__restrict__ sgp, const Ste
             const bool deal_now = ahead && (t & (GE_DEAL_PERIOD - 1u)) == 0u;        // wave-uniform
             Stamps *const stp = (GE_STAMPS && a.stamps) ? &stamps : nullptr;
             if (LOWOCC && GE_TPL_DEAL) {                                              // two copies of the turn, a scalar branch between them
-                if (deal_now) ww_turn<NB, GE_WAVE_QUEUE, LOWOCC, GENERIC, 1>(s, row, rows, tables[sg.table_idx].conds, cshape, cslots, lw, nth8, ord8, valid, sg.n_players, sg.nw, sg.phase0_idx, rk, turn0 + t, tk,
+                if (deal_now) ww_turn<NB, GE_WAVE_QUEUE, LOWOCC, GENERIC, 1>(s, row, rows, tables[sg.table_idx].conds, cs, lw, nth8, ord8, valid, sg.n_players, sg.nw, sg.phase0_idx, rk, turn0 + t, tk,
                                                                               trace, sg.human_mask, deal, true, ev_newly, ev_choice, stp);
-                else ww_turn<NB, GE_WAVE_QUEUE, LOWOCC, GENERIC, 0>(s, row, rows, tables[sg.table_idx].conds, cshape, cslots, lw, nth8, ord8, valid, sg.n_players, sg.nw, sg.phase0_idx, rk, turn0 + t, tk,
+                else ww_turn<NB, GE_WAVE_QUEUE, LOWOCC, GENERIC, 0>(s, row, rows, tables[sg.table_idx].conds, cs, lw, nth8, ord8, valid, sg.n_players, sg.nw, sg.phase0_idx, rk, turn0 + t, tk,
                                                                     trace, sg.human_mask, deal, false, ev_newly, ev_choice, stp);
             } else {
-                ww_turn<NB, GE_WAVE_QUEUE, LOWOCC, GENERIC, 2>(s, row, rows, tables[sg.table_idx].conds, cshape, cslots, lw, nth8, ord8, valid, sg.n_players, sg.nw, sg.phase0_idx, rk, turn0 + t, tk,
+                ww_turn<NB, GE_WAVE_QUEUE, LOWOCC, GENERIC, 2>(s, row, rows, tables[sg.table_idx].conds, cs, lw, nth8, ord8, valid, sg.n_players, sg.nw, sg.phase0_idx, rk, turn0 + t, tk,
                                                                trace, sg.human_mask, deal, deal_now, ev_newly, ev_choice, stp);
             }
             if (trace && valid) store_event(sg.trace, sg.rooms_padded, t, room, turn0 + t, p, s.phase, restarted, ev_newly, ev_choice);
@@ -247,8 +248,9 @@ __device__ __forceinline__ void run_tt(const SegDev *__restrict__ sgp, const Ste
     L::unpack(iw, s0);
     const DevRow row0 = rows[sg.phase0_idx];
     const uint32_t turn0 = a.turn0 + (a.turn_dev ? *a.turn_dev : 0u);
-    const uint32_t cshape = GENERIC ? __builtin_amdgcn_readfirstlane(tables[sg.table_idx].cond_shape) : 0u;
-    const uint32_t cslots = GENERIC ? __builtin_amdgcn_readfirstlane(tables[sg.table_idx].cond_slots) : 0u;
+    CondShape cs = {0u, 0u, 0u, 0u};
+    if (GENERIC) cs = CondShape{(uint32_t)__builtin_amdgcn_readfirstlane(tables[sg.table_idx].cond_shape), (uint32_t)__builtin_amdgcn_readfirstlane(tables[sg.table_idx].cond_slots),
+                               (uint32_t)__builtin_amdgcn_readfirstlane(tables[sg.table_idx].cond_fields[0]), (uint32_t)__builtin_amdgcn_readfirstlane(tables[sg.table_idx].cond_fields[1])};
     uint32_t done = tt_done_mask<NB>(s.rounds, sg.rounds);   // who has spoken all agreed rounds (ge_device.h)
     const uint32_t done0 = tt_done_mask<NB>(s0.rounds, sg.rounds);
     for (uint32_t t = 0; t < a.n_turns; t++) {
@@ -264,7 +266,7 @@ __device__ __forceinline__ void run_tt(const SegDev *__restrict__ sgp, const Ste
         const uint32_t p = s.phase;
         uint32_t ev_newly = 0;
         uint64_t ev_choice = 0;
-        tt_turn<NB, QUEUE, !LOWOCC, GENERIC>(s, done, row, rows, tables[sg.table_idx].conds, cshape, cslots, lw, nth8, valid, sg.n_players, sg.rounds, sg.phase0_idx, rk, turn0 + t, a.trace != 0u, sg.human_mask, ev_newly, ev_choice);
+        tt_turn<NB, QUEUE, !LOWOCC, GENERIC>(s, done, row, rows, tables[sg.table_idx].conds, cs, lw, nth8, valid, sg.n_players, sg.rounds, sg.phase0_idx, rk, turn0 + t, a.trace != 0u, sg.human_mask, ev_newly, ev_choice);
         if (a.trace && valid) store_event(sg.trace, sg.rooms_padded, t, room, turn0 + t, p, s.phase, restarted, ev_newly, ev_choice);
     }
     if (!valid) return;
@@ -1051,6 +1053,10 @@ static int create_impl(const ge_batch_desc *desc, ge_batch **out) {
                             for (uint32_t l = 0; l < pr.clause_len[k] && l < GE_MAX_TERMS; l++) {
                                 kinds |= pr.clause[k][l].kind == GE_LIT_NUM ? 0x200u : 0x100u;
                                 dt.cond_slots |= 1u << ((pr.clause[k][l].kind == GE_LIT_NUM ? 16u : 0u) + 4u * k + l);
+                                if (pr.clause[k][l].kind == GE_LIT_NUM && pr.clause[k][l].num_field >= 1 && pr.clause[k][l].num_field <= 4) {
+                                    const uint32_t slot = 4u * k + l;
+                                    dt.cond_fields[slot >> 3] |= 1u << (4u * (slot & 7u) + (pr.clause[k][l].num_field - 1u));
+                                }
                             }
                         }
                         dt.cond_shape = (ncl > 4u ? 4u : ncl) | ((len > 4u ? 4u : len) << 4) | kinds;

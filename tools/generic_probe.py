@@ -21,15 +21,24 @@ for pid in (4, 12):
               "or player.role == 'Detective' and player.selected_target_id > 0")
 for pid in (7, 15):
     cond(pid, "player.can_vote == true and player.is_alive == true and player.selected_target_id < 5")
-for rooms in (65536, 1048576):
+with open(os.path.join(ROOT, "tests", "golden", "dsl", "two-truths-and-a-lie.json"), encoding="utf-8") as f:
+    tt_base = json.load(f)
+tt_gen = copy.deepcopy(tt_base)                        # the tt_generic variant of the goldens
+def tcond(pid, c):
+    tt_gen["phases"][str(pid)]["completion_criteria"]["target_players"]["condition"] = c
+tcond(2, "player.is_speaker == true and player.statements_submitted != true")
+tcond(3, "player.is_speaker in [true] and player.lie_index not in [1, 2, 3]")
+tcond(5, "player.is_speaker == false and player.total_score <= 1 or player.is_speaker == false and player.rounds_as_speaker >= 1")
+for game, n, rooms, b0, g0, rounds in (("werewolf", 8, 65536, base, gen, 1), ("werewolf", 8, 1048576, base, gen, 1), ("werewolf", 12, 1048576, base, gen, 1),
+                                       ("two-truths", 4, 1048576, tt_base, tt_gen, 2)):
     res = {}
-    for name, dsl in (("shipped", base), ("generic", gen)):
-        tb = GameTable(dsl)
-        with RoomBatch([(tb, 8, rooms)], seed=0xC0FFEE, max_fuse=64, restart=True) as b:
+    for name, dsl in (("shipped", b0), ("generic", g0)):
+        tb = GameTable(dsl, rounds)
+        with RoomBatch([(tb, n, rooms)], seed=0xC0FFEE, max_fuse=64, restart=True) as b:
             b.step(256); b.sync()
             b.set_timing(True); b.kernel_time(reset=True)
             b.step(512); b.sync()
             ms, _ = b.kernel_time(reset=True)
             res[name] = ms * 1e3 / 512
-    print(f"werewolf x8, {rooms:>8} rooms: shipped conditions {res['shipped']:7.3f} us/turn ({rooms / res['shipped'] * 1e6:.3e} steps/s)   "
+    print(f"{game} x{n}, {rooms:>8} rooms: shipped conditions {res['shipped']:7.3f} us/turn ({rooms / res['shipped'] * 1e6:.3e} steps/s)   "
           f"generic conditions {res['generic']:7.3f} us/turn ({rooms / res['generic'] * 1e6:.3e} steps/s, x{res['generic'] / res['shipped']:.2f})", flush=True)
