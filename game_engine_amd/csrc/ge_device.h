@@ -146,11 +146,13 @@ template <int NB> __device__ __forceinline__ uint32_t nth_set_bit(uint32_t m, ui
 // NB <= 8, the same from nibble prefix counts: spread the mask to one bit per nibble; (x + 7 - n) * 0x11111111 puts
 // (number of set bits at positions <= j) + 7 - n into nibble j (<= 15: no carry), whose bit 3 says "more than n set bits
 // up to here"; the lowest such nibble is the n-th set bit.  12 instructions (one quarter-rate) instead of 22.
+// (the bit may not exist - a stale queue slot, a deal pick that is not taken - and the caller drops the result then: the
+// sentinel keeps the count-trailing-zeros defined; it folds into the AND as one v_and_or_b32)
 __device__ __forceinline__ uint32_t nth_set_bit_swar8(uint32_t m, uint32_t n) {
     uint32_t x = m & 0xFFu;
     x = (x | (x << 12)) & 0x000F000Fu; x = (x | (x << 6)) & 0x03030303u; x = (x | (x << 3)) & 0x11111111u;
     const uint32_t t = (x + 7u - n) * 0x11111111u;
-    return (uint32_t)__builtin_ctz(t & 0x88888888u) >> 2;      // the n-th set bit exists: never zero
+    return (uint32_t)__builtin_ctz((t & 0x88888888u) | 0x80000000u) >> 2;
 }
 
 // the same through a 2 KB LDS table nth8[mask][n] (mask: 8 bits): one LDS read instead of ~15 VALU
@@ -400,7 +402,8 @@ __device__ __forceinline__ void deal_roles(Deal &d, uint32_t dk, uint32_t game, 
         const uint32_t k = popc(rem);
         const bool on = j < nw + 2u && k != 0u;            // selects, not branches (see LOWOCC)
         const uint32_t idx = pick(draw(dk, 16u + j), k | (k == 0u));
-        const uint32_t pos = LOWOCC ? nth_set_bit<NB>(rem | (1u << 31), idx) : nth_set_bit_lds<NB>(nth8, rem, idx);
+        const uint32_t pos = LOWOCC ? ((GE_NTH_SWAR && NB <= 8) ? nth_set_bit_swar8(rem, idx) : nth_set_bit<NB>(rem | (1u << 31), idx))
+                                    : nth_set_bit_lds<NB>(nth8, rem, idx);
         const uint32_t bit = on ? (1u << (pos & 15u)) : 0u;
         rem &= ~bit;
         wolves |= j < nw ? bit : 0u;
