@@ -11,6 +11,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_${TAG}_${KEY}
 mkdir -p "$OUT"
 B="--no-cpu-baseline --no-other-shapes --no-from-init --no-unfused"
+# (run on a warm GPU: on a fresh box the first launch is taken at idle clocks and skews the kernel-trace average)
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -- python3 bench.py $B "$@" > "$OUT/bench_kt.json" 2> "$OUT/kt.err" || echo "kt failed"
 echo "[$KEY] kernel-trace done"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -- python3 bench.py $B "$@" > "$OUT/bench_fetch.json" 2> "$OUT/fetch.err" || echo "fetch failed"
