@@ -11,7 +11,9 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_${TAG}_${KEY}
 mkdir -p "$OUT"
 B="--no-cpu-baseline --no-other-shapes --no-from-init --no-unfused"
-# (run on a warm GPU: on a fresh box the first launch is taken at idle clocks and skews the kernel-trace average)
+# warm the GPU up first: on a fresh box the first launch is taken at idle clocks (~1.56 ms instead of ~1.13 for C2)
+# and skews the kernel-trace average
+python3 bench.py $B --steps 2 --warmup 1 "$@" > /dev/null 2>&1 || true
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -- python3 bench.py $B "$@" > "$OUT/bench_kt.json" 2> "$OUT/kt.err" || echo "kt failed"
 echo "[$KEY] kernel-trace done"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -- python3 bench.py $B "$@" > "$OUT/bench_fetch.json" 2> "$OUT/fetch.err" || echo "fetch failed"
