@@ -39,6 +39,8 @@ CASES = [                                # (game, n_players, rooms, turns, round
     ("draft-werewolf-(mafia)", 8, [0, 3, 65535], 90, 1),
     ("draft-werewolf-(mafia)", 5, [1], 60, 1),
     ("draft-werewolf-(mafia)", 12, [2], 120, 1),
+    ("draft-werewolf-(mafia)", 4, [0], 40, 1),
+    ("draft-werewolf-(mafia)", 9, [4], 110, 1),
 ]
 
 
