@@ -6,10 +6,11 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libge_step.so")
+# GE_LIB_PATH: another build of the same library (A/B runs, tools/abn.sh): the product .so is never overwritten
+LIB_PATH = os.environ.get("GE_LIB_PATH") or os.path.join(_HERE, "libge_step.so")
 
 GE_MAX_PHASES, GE_MAX_SEGMENTS, GE_NAME_LEN, GE_MAX_SLOTS = 32, 4, 64, 12
-GE_ABI_VERSION = 3
+GE_ABI_VERSION = 4
 
 
 class Literal(C.Structure):
@@ -57,7 +58,8 @@ SUMMARY_WORDS = C.sizeof(Summary) // 8
 SYMBOLS = ["ge_table_compile_json", "ge_batch_create", "ge_batch_step", "ge_batch_reset", "ge_batch_set_turn", "ge_batch_inject_actions", "ge_batch_sync", "ge_batch_turn",
            "ge_batch_n_rooms", "ge_batch_read_rooms", "ge_batch_write_rooms", "ge_batch_read_events", "ge_batch_inject_action", "ge_batch_summary",
            "ge_batch_state", "ge_batch_set_timing", "ge_batch_kernel_time", "ge_batch_destroy",
-           "ge_strerror", "ge_last_hip_error", "ge_abi_version", "ge_device_count"]
+           "ge_group_create", "ge_group_size", "ge_group_shard", "ge_group_step", "ge_group_sync", "ge_group_summary", "ge_group_destroy",
+           "ge_strerror", "ge_last_hip_error", "ge_last_comm_error", "ge_abi_version", "ge_device_count"]
 
 _lib = None
 
@@ -97,6 +99,14 @@ def load() -> C.CDLL:
     lib.ge_batch_kernel_time.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(u64)]
     lib.ge_batch_destroy.argtypes = [vp]
     lib.ge_batch_destroy.restype = None
+    lib.ge_group_create.argtypes = [C.POINTER(BatchDesc), C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]
+    lib.ge_group_size.argtypes = [vp]
+    lib.ge_group_shard.argtypes = [vp, C.c_int, C.POINTER(vp)]
+    lib.ge_group_step.argtypes = [vp, u32]
+    lib.ge_group_sync.argtypes = [vp]
+    lib.ge_group_summary.argtypes = [vp, C.POINTER(Summary)]
+    lib.ge_group_destroy.argtypes = [vp]
+    lib.ge_group_destroy.restype = None
     lib.ge_strerror.argtypes = [C.c_int]
     lib.ge_strerror.restype = C.c_char_p
     if lib.ge_abi_version() != GE_ABI_VERSION:

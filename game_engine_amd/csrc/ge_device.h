@@ -23,90 +23,39 @@ enum { RES_ALWAYS = 0, RES_WOLVES_ZERO, RES_WOLVES_GE_VILLAGERS, RES_FOLLOWS_DAY
        RES_ALL_ROUNDS_DONE, RES_OTHERWISE };
 
 constexpr uint32_t GOLDEN = 0x9E3779B9u;
-#ifndef GE_DPP_SCAN
-#define GE_DPP_SCAN 1
-#endif
-// A/B switches (tools/ab.sh): GE_SHADOW = action-independent work placed in the shadows of the action queue's two
-// LDS round trips; GE_ORD = queue slots find their player through the ord8 table (werewolf N <= 8)
-#ifndef GE_SHADOW
-#define GE_SHADOW 1
-#endif
-#ifndef GE_ORD
-#define GE_ORD 1
-#endif
-// the shadows (and the pins that keep their values live across the queue) in the large-batch build too.  Measured
-// (profiles/r02_ab_occupancy.txt): Werewolf x 8 gains 1.7 % from them at 1 M rooms (68 -> 71 VGPRs, still 7 wavefronts per
-// SIMD); Werewolf x 12 is better off without them and held to 80 VGPRs = 6 wavefronts per SIMD (2 spilled registers):
-// 21.96 -> 21.53 us/turn at 2 M rooms
-#ifndef GE_SHADOW_HI
-#define GE_SHADOW_HI 1
-#endif
-// diagnostic build (-DGE_STAMPS=1, tools/stamps.py): s_memtime stamps at points of the werewolf turn where no LDS
-// operation is outstanding anyway, accumulated per wavefront; never in the product build
+
+// Compile-time switches.  Every one selects between shipped builds or is a tuning constant; tools/ab_switches.sh builds
+// the non-default value of each and runs the parity subset on it.  (What used to be A/B switches for measured-and-rejected
+// variants is gone from the source: the numbers live in profiles/r02_ab_*.txt and in git history.)
+// GE_STAMPS=1: diagnostic build (tools/stamps.py) - s_memtime stamps at points of the werewolf turn where no LDS operation
+//   is outstanding anyway, accumulated per wavefront; never in the product build
 #ifndef GE_STAMPS
 #define GE_STAMPS 0
 #endif
-// branch diet of the lone-wavefront build, A/B on MI355X at 65 536 rooms (gpurun_out/abn_branch.txt, us/turn at fuse 64):
-// none 1.442; GE_TPL_TRACE (turn loop compiled per trace setting: two always-taken wave-uniform branches less) 1.420;
-// GE_GO_BRANCHLESS (every queue slot ORs a result, zeros if it does not act) 1.468 - worse, the extra LDS atomics cost
-// more than the branch; GE_UNLIKELY (fallback role deal hinted out of line) 1.446; GE_UNROLL2 (two turns per trip) 1.439
-#ifndef GE_TPL_TRACE
-#define GE_TPL_TRACE 1
-#endif
-#ifndef GE_GO_BRANCHLESS
-#define GE_GO_BRANCHLESS 0
-#endif
-#ifndef GE_UNLIKELY
-#define GE_UNLIKELY 0
-#endif
-#ifndef GE_UNROLL2
-#define GE_UNROLL2 0
-#endif
-// role deals are prepared ahead every GE_DEAL_PERIOD-th turn (a power of two; a game is longer, and a room whose deal
-// is not ready when it needs one deals on the spot)
+// GE_DEAL_PERIOD: role deals are prepared ahead every GE_DEAL_PERIOD-th turn (a power of two; a game is longer, and a room
+//   whose deal is not ready when it needs one deals on the spot).  8 / 16 / 32 measured: profiles/r02_ab_deal_shadow.txt
 #ifndef GE_DEAL_PERIOD
 #define GE_DEAL_PERIOD 16
 #endif
-// werewolf N <= 8: a queue slot returns its result with ONE LDS atomic (the choice into the actor's nibble); the room derives
-// who acted from the non-zero nibbles instead of receiving a second, go-mask atomic
-#ifndef GE_ONE_ATOMIC
-#define GE_ONE_ATOMIC 1
-#endif
-// more of the lone-wavefront build's exec-mask regions turned into data flow (profiles/r02_ab_sel_pin.txt): the victim /
-// protection selects of a resolution (GE_SEL_RESOLVE: no effect, off); the choice computed outside the `acts this turn`
-// region of a queue slot (GE_PIN_CHOICE: Werewolf x 12 1.787 -> 1.751 us/turn at 65 536 rooms, x 8 1.313 -> 1.327: on for N > 8)
-#ifndef GE_SEL_RESOLVE
-#define GE_SEL_RESOLVE 0
-#endif
-#ifndef GE_PIN_CHOICE
-#define GE_PIN_CHOICE 1
-#endif
-// GE_SEL_OPEN: the completion test without short-circuit evaluation (&& / || had become three nested exec-mask regions):
-// C2 1.308 -> 1.282 us/turn (profiles/r02_ab_open_tpldeal.txt); GE_SEL_NEED: the same for the fallback-deal test, no effect
-#ifndef GE_SEL_OPEN
-#define GE_SEL_OPEN 1
-#endif
-#ifndef GE_SEL_NEED
-#define GE_SEL_NEED 0
-#endif
 
-// Round 3 of the lone-wavefront diet (werewolf N <= 8 only; every instruction of a lone wavefront is a >= 4-cycle issue slot,
-// and gfx950 needs two wait states between a VALU write of VCC / an SGPR and a VALU read of it - a dependent
-// v_cmp -> v_cndmask pair costs a third slot for the s_nop the compiler has to put between them):
-// GE_ACT_ONEHOT: a queue slot carries the action kind one-hot; selects by v_bfe_i32 masks + v_bfi instead of compares
-// GE_NTH_SWAR:   n-th set bit of the candidate mask from nibble prefix counts (one multiply) instead of a binary search
-// GE_PK_KEYS:    the plurality's max over (count << 4 | 15 - id) keys with packed 16-bit max
-// profiles/r02_ab_onehot_swar_pk.txt, us/turn at 64 fused turns, 65 536 / 1 048 576 rooms: none 1.280 / 8.50; one-hot 1.257 / 8.49;
-// SWAR n-th bit 1.266 / 8.48; packed keys 1.288 / 8.39; all three 1.222 / 8.33 (alone the packed keys lose 0.6 % at C2, together with the others they gain 1 %)
-#ifndef GE_ACT_ONEHOT
-#define GE_ACT_ONEHOT 1
-#endif
-#ifndef GE_NTH_SWAR
-#define GE_NTH_SWAR 1
-#endif
-#ifndef GE_PK_KEYS
-#define GE_PK_KEYS 1
-#endif
+// What distinguishes the two shipped builds of the werewolf turn (chosen per launch from the batch size, ge_step.hip
+// fill_args): LOWOCC = at most one wavefront per SIMD (C2).  A lone wavefront pays an issue slot of >= 4 cycles for
+// every instruction whatever its type, a bubble for every branch and the full latency of every dependent LDS round trip,
+// so that build is branch-lean and computes; with many wavefronts per SIMD the kernel is VALU-bound and prefers LDS
+// tables and skip-branches.  Each entry was an A/B on MI355X (profiles/r02_ab_*.txt):
+// SINGLE = the launch advances every room by exactly one turn (max_fuse = 1: interactive / traced stepping, and the
+// launch that really streams the state through HBM every turn): no turn loop, nothing prepared for a next turn.
+template <int NB, bool LOWOCC, bool SINGLE = false> struct WwBuild {
+    static constexpr bool ORD = NB <= 8;                    // queue slots find their player through the ord8 table (r02_ab_shadow_ord)
+    static constexpr bool ONE_ATOMIC = NB <= 8 && LOWOCC;   // one result atomic per slot; the room derives who acted from the non-zero choice nibbles (r02_ab_choose_one_atomic)
+    static constexpr bool SHADOW = LOWOCC || NB <= 8;       // action-independent work inside the queue's two LDS round trips (r02_ab_occupancy: N > 8 large-batch is better off without)
+    static constexpr bool ONEHOT = LOWOCC && NB <= 8;       // queue slots carry the action kind one-hot: selects by v_bfe_i32 masks + v_bfi, no compares (r02_ab_onehot_swar_pk)
+    static constexpr bool PIN_CHOICE = LOWOCC && NB > 8;    // the slot's choice computed outside its `acts this turn` region (r02_ab_sel_pin)
+    static constexpr bool SEL_OPEN = LOWOCC;                // completion test without short-circuit evaluation (r02_ab_open_tpldeal)
+    static constexpr bool TPL_TRACE = LOWOCC;               // the turn loop compiled once per trace setting (r02_ab_branch_diet)
+    static constexpr int DEAL_FORM = SINGLE ? 2 : LOWOCC ? 0 : NB <= 8 ? 1 : 2;   // DEAL_PACKED / DEAL_MASKS / DEAL_WORDS, see struct Deal
+    static constexpr bool TABLE = !LOWOCC;                  // n-th-set-bit through the 2 KB LDS table instead of ~15 VALU instructions
+};
 
 // ---- POLICY.md §RNG: stateless 32-bit counter hash
 GE_HD uint32_t mix32(uint32_t x) {
@@ -199,7 +148,7 @@ __device__ __forceinline__ uint64_t nib_fill(uint64_t x) { x |= x << 1; asm("" :
 // 1-based id with the most votes among `voters`, ties -> lowest id, 0 if nobody voted.
 // votes: one nibble per player (1-based target id, 0 = none).  Counters are nibbles too
 // (<= 12 voters), so the whole tally is one or two registers.
-template <int NB, typename nib_t, bool PK = false>
+template <int NB, typename nib_t>
 __device__ __forceinline__ uint32_t plurality(nib_t votes, uint32_t voters) {
     // keep only the voters' nibbles: spread the voter bits to nibble position 0, times 15
     nib_t vm;
@@ -223,7 +172,7 @@ __device__ __forceinline__ uint32_t plurality(nib_t votes, uint32_t voters) {
         uint32_t tally = 0;
 #pragma unroll
         for (int i = 0; i < NB; i++) tally += 1u << ((4u * ((v32 >> (4 * i)) & 15u)) & 31u);
-        if (PK && NB == 8) {
+        {
             // two keys per register, 16 bits each: counters 1 / 5 sit at bits 4..7 of the two halves already (count << 4),
             // 2 / 6, 3 / 7 and 4 after a shift; player 8's count comes from bit 3 of the vote nibbles
             typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
@@ -235,12 +184,6 @@ __device__ __forceinline__ uint32_t plurality(nib_t votes, uint32_t voters) {
             const uint32_t d = ((tally >> 12) & 0x000000F0u) | (c8 << 20) | 0x0007000Bu;   // ids 4, 8
             const u16x2 m = __builtin_elementwise_max(__builtin_elementwise_max(pk(a), pk(b)), __builtin_elementwise_max(pk(c), pk(d)));
             key = m.x > m.y ? m.x : m.y;
-        } else
-#pragma unroll
-        for (int k = 1; k <= NB; k++) {
-            const uint32_t cnt = k < 8 ? (tally >> (4 * k)) & 15u : popc(v32 & 0x88888888u);
-            const uint32_t kk = (cnt << 4) | (uint32_t)(15 - k);
-            key = kk > key ? kk : key;
         }
     } else {
         uint64_t tally = 0;
@@ -284,28 +227,17 @@ __device__ __forceinline__ void wave_sync() {
 
 // exclusive prefix sum of a small per-lane count over the wavefront, and the wave total (uniform)
 __device__ __forceinline__ void wave_excl_scan(uint32_t cnt, uint32_t &off, uint32_t &total) {
-    if (GE_DPP_SCAN) {
-        // inclusive scan by DPP: inside each row of 16 lanes (row_shr 1, 2, 4, 8), then
-        // row 0 -> 1 and 2 -> 3 (row_bcast:15), then rows 0-1 -> 2-3 (row_bcast:31)
-        uint32_t v = cnt;
-        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
-        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
-        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
-        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
-        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
-        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
-        off = v - cnt;
-        total = (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
-    } else {
-        // one ballot per bit of the count (<= 15), mbcnt for the lanes below
-        off = 0; total = 0;
-#pragma unroll
-        for (int b = 0; b < 4; b++) {
-            const unsigned long long m = __ballot((cnt >> b) & 1u);
-            off += __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)) << b;
-            total += (uint32_t)__popcll(m) << b;
-        }
-    }
+    // inclusive scan by DPP: inside each row of 16 lanes (row_shr 1, 2, 4, 8), then
+    // row 0 -> 1 and 2 -> 3 (row_bcast:15), then rows 0-1 -> 2-3 (row_bcast:31)
+    uint32_t v = cnt;
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
+    off = v - cnt;
+    total = (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
 struct Stamps {
@@ -345,7 +277,7 @@ __device__ __forceinline__ uint32_t ww_choose(uint32_t act, uint32_t i, uint32_t
         cand = cand ? cand : alive;
     }
     const uint32_t idx = pick(d, popc(cand));
-    return (TABLE ? nth_set_bit_lds<NB>(nth8, cand, idx) : (GE_NTH_SWAR && NB <= 8) ? nth_set_bit_swar8(cand, idx) : nth_set_bit<NB>(cand, idx)) + 1u;
+    return (TABLE ? nth_set_bit_lds<NB>(nth8, cand, idx) : NB <= 8 ? nth_set_bit_swar8(cand, idx) : nth_set_bit<NB>(cand, idx)) + 1u;
 }
 
 // 0 / ~0 from bit `pos` of x (v_bfe_i32), and a select by such a mask (v_bfi_b32): no compare, no VCC
@@ -358,7 +290,7 @@ __device__ __forceinline__ uint32_t bit_mask(uint32_t x, uint32_t pos) {
 }
 __device__ __forceinline__ uint32_t bfi(uint32_t m, uint32_t a, uint32_t b) { return (m & a) | (~m & b); }
 
-// ww_choose for a queue slot of the lone-wavefront build, N <= 8 (GE_ACT_ONEHOT).  x = alive | team_w << 16 | kind << 28 with
+// ww_choose for a queue slot of the lone-wavefront build, N <= 8 (WwBuild::ONEHOT).  x = alive | team_w << 16 | kind << 28 with
 // the action kind ONE-HOT (bit 28 wolf target, 29 doctor, 30 detective, 31 day vote); `det_voter`: by day, the Detective's
 // bit if it knows a living werewolf (else 0) - the owning room resolves that, so the slot needs no compare for it.
 __device__ __forceinline__ uint32_t ww_choose_onehot8(uint32_t x, uint32_t i, uint32_t d, uint32_t known, uint32_t lo_kw, uint32_t det_voter) {
@@ -374,7 +306,7 @@ __device__ __forceinline__ uint32_t ww_choose_onehot8(uint32_t x, uint32_t i, ui
     cand = bfi(bit_mask(x, 31), vote, cand);
     cand = sel32(cand != 0u, cand, alive);
     const uint32_t idx = pick(d, popc(cand));
-    return (GE_NTH_SWAR ? nth_set_bit_swar8(cand, idx) : nth_set_bit<8>(cand, idx)) + 1u;
+    return nth_set_bit_swar8(cand, idx) + 1u;
 }
 
 // nibble mask (0xF per player) of the non-zero nibbles of x
@@ -385,58 +317,120 @@ __device__ __forceinline__ uint64_t nib_nonzero(uint64_t x) {
     uint64_t m = x | (x >> 1); m |= m >> 2; m &= 0x1111111111111111ull; return nib_fill(m);
 }
 
-// A room's role deal (POLICY.md §3 ASSIGN_ROLES): nw werewolves, then a Doctor, then a Detective, by
-// repeated n-th-set-bit sampling of the players not yet dealt; `rem` = the Villagers.
-// Large-batch build, N <= 8: kept as the three packed predicate words a role assignment writes (WWR::W, see deal_words) -
-// turning the four masks into those words is then paid once per deal, not once per turn (1 M x 8: 8.33 -> 8.10 us/turn).
-// The lone-wavefront build keeps the masks: there that work sits in an LDS wait shadow and costs nothing (C2: 1.220 -> 1.229
-// with the words).  profiles/r02_ab_onehot_swar_pk.txt
-struct Deal { uint32_t wolves, doc, det, rem, game, valid; };      // words form: wolves / doc / det hold W[0] / W[1] / W[2], rem is unused
-template <int NB, bool LOWOCC> constexpr bool deal_as_words() { return NB <= 8 && !LOWOCC; }
+// A room's role deal (POLICY.md §3 ASSIGN_ROLES): nw werewolves, then a Doctor, then a Detective, by repeated
+// n-th-set-bit sampling of the players not yet dealt; the rest are Villagers.  Picks are keyed by (room, game index), not by
+// the turn that applies them, so a deal can be prepared ahead - in registers during a fused launch, and for N <= 8 across
+// launches in the record's spare half-word (ge_layout.h, WWLayout<8>).  Three in-register forms (WwBuild::DEAL_FORM):
+//   DEAL_MASKS   a / b / c / rem = werewolves / Doctor / Detective / Villagers as player masks - the lone-wavefront build,
+//                where turning them into predicate words sits in an LDS wait shadow and costs nothing;
+//   DEAL_WORDS   a / b / c = the three packed predicate words an assignment writes (N <= 8, large-batch fused build:
+//                the conversion is paid once per deal, not once per turn; profiles/r02_ab_onehot_swar_pk.txt);
+//   DEAL_PACKED  a = DealPk, one register - Werewolf x 12 large-batch (register pressure: that build is held to 80 VGPRs)
+//                and every single-turn build; expanded only by the lanes that assign.
+// gv = game index | 1 << 31 while the deal is valid, else 0: "ready for this game" is one compare.
+enum { DEAL_MASKS = 0, DEAL_WORDS = 1, DEAL_PACKED = 2 };
+struct Deal { uint32_t a, b, c, rem, gv; };
+constexpr uint32_t DEAL_VALID = 1u << 31;
 
-template <int NB, bool LOWOCC>
+// werewolves mask | Doctor's index << WB | Detective's index << (WB + IB) | 1 << OK_SH.  16 bits for N <= 8 (the record's cache)
+template <int NB> struct DealPk {
+    static constexpr uint32_t WB = NB <= 8 ? 8 : 12, IB = NB <= 8 ? 3 : 4;
+    static constexpr uint32_t WM = (1u << WB) - 1u, IM = (1u << IB) - 1u, DOC_SH = WB, DET_SH = WB + IB, OK_SH = WB + 2 * IB;
+    static __device__ __forceinline__ uint32_t pack(uint32_t wolves, uint32_t doc, uint32_t det) {
+        return wolves | (ctz(doc | 0x80000000u) & IM) << DOC_SH | (ctz(det | 0x80000000u) & IM) << DET_SH | 1u << OK_SH;
+    }
+    static __device__ __forceinline__ void unpack(uint32_t pk, uint32_t all, uint32_t &wolves, uint32_t &doc, uint32_t &det, uint32_t &rem) {
+        wolves = pk & WM; doc = 1u << ((pk >> DOC_SH) & IM); det = 1u << ((pk >> DET_SH) & IM);
+        rem = all & ~(wolves | doc | det);
+    }
+};
+
+// the packed predicate words a role assignment writes, from the four masks
+template <int NB> __device__ __forceinline__ void role_words(uint32_t wolves, uint32_t doc, uint32_t det, uint32_t rem, uint32_t all, WWR<NB> &w) {
+    const uint32_t special = all & ~rem;
+#pragma unroll
+    for (int k = 0; k < WWR<NB>::NW; k++) w.W[k] = 0;
+    w.template set<F_VIL>(rem); w.template set<F_WOLF>(wolves); w.template set<F_DOC>(doc); w.template set<F_DET>(det);
+    w.template set<F_TEAM_W>(wolves); w.template set<F_TEAM_V>(all & ~wolves);
+    w.template set<F_SECRET>(special); w.template set<F_ELIG>(special);
+}
+
+template <int NB, int FORM>
+__device__ __forceinline__ void deal_set(Deal &d, uint32_t wolves, uint32_t doc, uint32_t det, uint32_t rem, uint32_t all, uint32_t game) {
+    if (FORM == DEAL_WORDS) {
+        WWR<NB> w;
+        role_words<NB>(wolves, doc, det, rem, all, w);
+        d.a = w.W[0]; d.b = w.W[1]; d.c = w.W[2]; d.rem = 0u;
+    } else if (FORM == DEAL_PACKED) {
+        d.a = DealPk<NB>::pack(wolves, doc, det); d.b = d.c = d.rem = 0u;
+    } else {
+        d.a = wolves; d.b = doc; d.c = det; d.rem = rem;
+    }
+    d.gv = game | DEAL_VALID;
+}
+
+// TABLE: n-th-set-bit from the LDS table (large-batch builds)
+template <int NB, bool TABLE, int FORM>
 __device__ __forceinline__ void deal_roles(Deal &d, uint32_t dk, uint32_t game, uint32_t n, uint32_t nw, const uint8_t *nth8) {
     uint32_t rem = (1u << n) - 1u, wolves = 0, doc = 0, det = 0;
 #pragma unroll
     for (uint32_t j = 0; j < (NB > 8 ? 5u : 4u); j++) {           // nw + 2 picks, nw <= NB / 4
         const uint32_t k = popc(rem);
-        const bool on = j < nw + 2u && k != 0u;            // selects, not branches (see LOWOCC)
+        const bool on = j < nw + 2u && k != 0u;            // selects, not branches (see WwBuild)
         const uint32_t idx = pick(draw(dk, 16u + j), k | (k == 0u));
-        const uint32_t pos = LOWOCC ? ((GE_NTH_SWAR && NB <= 8) ? nth_set_bit_swar8(rem, idx) : nth_set_bit<NB>(rem | (1u << 31), idx))
-                                    : nth_set_bit_lds<NB>(nth8, rem, idx);
+        const uint32_t pos = TABLE ? nth_set_bit_lds<NB>(nth8, rem, idx)
+                                   : (NB <= 8 ? nth_set_bit_swar8(rem, idx) : nth_set_bit<NB>(rem | (1u << 31), idx));
         const uint32_t bit = on ? (1u << (pos & 15u)) : 0u;
         rem &= ~bit;
         wolves |= j < nw ? bit : 0u;
         doc = j == nw ? bit : doc;
         det = j == nw + 1u ? bit : det;
     }
-    if (deal_as_words<NB, LOWOCC>()) {
-        WWR<NB> w;
-        const uint32_t all = (1u << n) - 1u, special = all & ~rem;
-#pragma unroll
-        for (int k = 0; k < WWR<NB>::NW; k++) w.W[k] = 0;
-        w.template set<F_VIL>(rem); w.template set<F_WOLF>(wolves); w.template set<F_DOC>(doc); w.template set<F_DET>(det);
-        w.template set<F_TEAM_W>(wolves); w.template set<F_TEAM_V>(all & ~wolves);
-        w.template set<F_SECRET>(special); w.template set<F_ELIG>(special);
-        d.wolves = w.W[0]; d.doc = w.W[1]; d.det = w.W[2]; d.rem = 0u;
-    } else {
-        d.wolves = wolves; d.doc = doc; d.det = det; d.rem = rem;
-    }
-    d.game = game; d.valid = 1u;
+    deal_set<NB, FORM>(d, wolves, doc, det, rem, (1u << n) - 1u, game);
 }
 
 // the packed predicate words a role assignment writes, from the prepared deal
-template <int NB, bool LOWOCC> __device__ __forceinline__ void deal_words(const Deal &deal, uint32_t all, WWR<NB> &dealt) {
-    if (deal_as_words<NB, LOWOCC>()) {
-        dealt.W[0] = deal.wolves; dealt.W[1] = deal.doc; dealt.W[2] = deal.det;
-        return;
+template <int NB, int FORM> __device__ __forceinline__ void deal_words(const Deal &deal, uint32_t all, WWR<NB> &dealt) {
+    if (FORM == DEAL_WORDS) {
+        dealt.W[0] = deal.a; dealt.W[1] = deal.b; dealt.W[2] = deal.c;
+    } else if (FORM == DEAL_PACKED) {
+        uint32_t wolves, doc, det, rem;
+        DealPk<NB>::unpack(deal.a, all, wolves, doc, det, rem);
+        role_words<NB>(wolves, doc, det, rem, all, dealt);
+    } else {
+        role_words<NB>(deal.a, deal.b, deal.c, deal.rem, all, dealt);
     }
-#pragma unroll
-    for (int k = 0; k < WWR<NB>::NW; k++) dealt.W[k] = 0;
-    const uint32_t special = all & ~deal.rem;
-    dealt.template set<F_VIL>(deal.rem); dealt.template set<F_WOLF>(deal.wolves); dealt.template set<F_DOC>(deal.doc); dealt.template set<F_DET>(deal.det);
-    dealt.template set<F_TEAM_W>(deal.wolves); dealt.template set<F_TEAM_V>(all & ~deal.wolves);
-    dealt.template set<F_SECRET>(special); dealt.template set<F_ELIG>(special);
+}
+
+// the game whose deal a room needs next: this game's while it has no roles yet, else the next game's
+template <int NB> __device__ __forceinline__ uint32_t deal_next_game(const WWR<NB> &s) {
+    const bool has_roles = (NB <= 8 ? s.W[2] : (s.W[WWR<NB>::NW - 2] | s.W[WWR<NB>::NW - 1])) != 0u;
+    return has_roles ? (s.games < 0xFFFFu ? s.games + 1u : s.games) : s.games;
+}
+
+// record cache <-> registers (N <= 8; Werewolf x 12 records have no spare bits: nothing is kept across launches).  The
+// cache is written only when it is the deal of deal_next_game(the stored state), so the loader need not store the game.
+template <int NB, int FORM> __device__ __forceinline__ void deal_from_cache(uint32_t cache, const WWR<NB> &s, uint32_t all, Deal &d) {
+    d.a = d.b = d.c = d.rem = d.gv = 0u;
+    if (NB > 8) return;
+    const uint32_t g = deal_next_game<NB>(s);
+    const bool ok = (cache >> DealPk<NB>::OK_SH) & 1u;
+    if (FORM == DEAL_PACKED) {
+        d.a = cache;
+    } else {
+        uint32_t wolves, doc, det, rem;
+        DealPk<NB>::unpack(cache, all, wolves, doc, det, rem);
+        deal_set<NB, FORM>(d, wolves, doc, det, rem, all, g);
+    }
+    d.gv = ok ? (g | DEAL_VALID) : 0u;
+}
+template <int NB, int FORM> __device__ __forceinline__ uint32_t deal_to_cache(const Deal &d, const WWR<NB> &s) {
+    if (NB > 8) return 0u;
+    uint32_t pk;
+    if (FORM == DEAL_PACKED) pk = d.a;
+    else if (FORM == DEAL_WORDS) pk = DealPk<NB>::pack((d.c >> 8) & 0xFFu, (d.c >> 16) & 0xFFu, d.c >> 24);   // W[2] = r_vil | r_wolf | r_doc | r_det
+    else pk = DealPk<NB>::pack(d.a, d.b, d.c);
+    return d.gv == (deal_next_game<NB>(s) | DEAL_VALID) ? (pk & 0xFFFFu) : 0u;
 }
 
 // ------------------------------------------------------------------ generic target conditions
@@ -578,38 +572,36 @@ template <int NB> __device__ __forceinline__ uint32_t tt_cond_generic(const TT<N
 }
 
 // ------------------------------------------------------------------ werewolf
-// LOWOCC: the launch has fewer than ~3 wavefronts per SIMD (e.g. 65 536 rooms): a lone wavefront
-// stalls on every branch instruction and every dependent LDS access, so that build is branch-lean
-// and computes; the other build (many wavefronts, VALU-bound) prefers LDS tables and skip-branches.
-// DEAL: 1 / 0 = this instantiation is for the turns that do / do not prepare role deals (the lone-wavefront build compiles
-// the turn twice rather than test a wave-uniform flag inside an exec-mask region every turn); 2 = `deal_now` decides
-template <int NB, bool QUEUE, bool LOWOCC, bool GENERIC = false, int DEAL = 2>
-__device__ __forceinline__ void ww_turn(WWR<NB> &s, DevRow &row, const DevRow *rows, const DevCond *conds, CondShape cs, void *wave_lds, const uint8_t *nth8, const uint32_t *ord8, bool valid, uint32_t n,
-                                        uint32_t nw, uint32_t phase0_idx, uint32_t rkey, uint32_t turn, uint32_t &tk_io,
-                                        bool trace, uint32_t human, Deal &deal, bool deal_now, uint32_t &ev_newly, uint64_t &ev_choice, Stamps *stamps = nullptr) {
-    // human: players the host drives (never acted for here)
-    // ev_*: this turn's logged actions (who acted, what they chose) for the optional event trace
-    // `row` is the table row of s.phase, kept in registers across turns: LDS is read only on a transition
-    // tk_io: in = turn_key(rkey, turn), out = the next turn's key
-    // deal_now (wave-uniform, every GE_DEAL_PERIOD-th turn of a long launch): lanes without a prepared role deal
-    // compute their next one - in the shadow of the queue's result round trip
-    using nib_t = typename WWR<NB>::nib_t;
-    using R = WWR<NB>;
-    constexpr bool ORD = GE_ORD && NB <= 8;                    // queue slots find their player through the ord8 table
-    constexpr bool ONE = GE_ONE_ATOMIC && NB <= 8 && LOWOCC;   // one result atomic per slot (C2 1.331 -> 1.312 us/turn; the large-batch build loses 1.4 %)
-    constexpr bool SHADOW = GE_SHADOW && (LOWOCC || (GE_SHADOW_HI && NB <= 8));   // action-independent work inside the queue's LDS round trips
-    constexpr bool ONEHOT = GE_ACT_ONEHOT && LOWOCC && ORD;    // queue slots carry the action kind one-hot (ww_choose_onehot8)
-    auto *lw = static_cast<typename WaveLdsOf<LOWOCC>::type *>(wave_lds);
-    const uint32_t ALL = (1u << n) - 1u;
-    const uint32_t comp = row.r0 & 3u, act = (row.r0 >> 2) & 7u, p_eff = (row.r0 >> 5) & 7u;
-    const uint32_t nterms = (row.r0 >> 8) & 7u;
-    const uint32_t tk = tk_io;
-    const uint32_t alive = s.template get<F_ALIVE>(), team_w = s.template get<F_TEAM_W>(), r_det = s.template get<F_DET>();
+// One turn of a room (= one graph run of the reference, v2:1571-1587) is
+//   ww_targets()        who must act (PhaseNode's reading of completion_criteria.target_players, v2:1087-1103)
+//   ww_queue_actions()  BotBehaviorNode (v2:468) + the Referee's record of each action (bt:204-225), through the wavefront
+//                       work queue; ww_phase_branch() and ww_prepare_deal() run in the shadows of its two LDS round trips
+//   ww_decide()         PhaseNode (v2:987): phase-0 guard, completion, first matching branch
+//   ww_apply_effect()   RefereeNode (v2:619): the entry effect of the phase the room moves to
+// WwBuild<NB, LOWOCC> (top of this file) says what differs between the lone-wavefront and the large-batch build.
 
-    // ---- who must act: target_players.condition AND alive, all players at once.
-    // The 12 base predicates live packed in s.W; the row carries byte-permute selectors that pull each
-    // term's mask out of the word pairs (0xFF where the term is elsewhere / absent), so the condition
-    // is 2-3 v_perm + AND, XOR with the negation mask, and a fold of the term bytes (ge_layout.h DevRow).
+// what a launch keeps constant for a lane's turns
+struct WwCtx {
+    const DevRow *rows;        // phase table in LDS
+    const DevCond *conds;      // clause forms of the generic rows (global memory; GENERIC builds only)
+    CondShape cs;
+    void *wave_lds;            // this wavefront's WaveLds / WaveLdsLow
+    const uint8_t *nth8;       // LDS n-th-set-bit table (large-batch build)
+    const uint32_t *ord8;      // LDS slot -> player table (N <= 8)
+    bool valid;                // the lane holds a real room (lanes past the end of a segment shadow room 0 and never act)
+    uint32_t n, nw, phase0_idx, rkey;
+    uint32_t human;            // players the host drives (never acted for here)
+    uint32_t term_mask;        // bit r = row r is terminal (no next_phase branch): all a single-turn launch needs of the row it moves to
+};
+
+// ---- who must act: target_players.condition AND alive, all players at once.
+// The 12 base predicates live packed in s.W; the row carries byte-permute selectors that pull each term's mask out of
+// the word pairs (0xFF where the term is elsewhere / absent), so the condition is 2-3 v_perm + AND, XOR with the
+// negation mask, and a fold of the term bytes (ge_layout.h DevRow).
+template <int NB, bool LOWOCC, bool GENERIC>
+__device__ __forceinline__ uint32_t ww_targets(const WWR<NB> &s, const DevRow &row, const WwCtx &c, uint32_t alive, uint32_t ALL) {
+    using R = WWR<NB>;
+    const uint32_t comp = row.r0 & 3u, nterms = (row.r0 >> 8) & 7u;
     uint32_t T = 0;
     if (LOWOCC || comp == COMP_ACTION) {                       // LOWOCC: always evaluated, masked below (no branch)
         uint32_t X;
@@ -638,274 +630,230 @@ __device__ __forceinline__ void ww_turn(WWR<NB> &s, DevRow &row, const DevRow *r
         T = X & alive & (comp == COMP_ACTION ? ALL : 0u);
     }
     if (GENERIC && (row.r0 & ROW_GENERIC) && comp == COMP_ACTION)        // or / in [..] / numeric comparisons: the clause form
-        T = ww_cond_generic<NB>(s, conds[s.phase], ALL, cs) & alive;
-    if (GE_STAMPS && stamps) { asm volatile("" :: "v"(T)); stamps->mark(0); }        // [end of previous turn .. row in registers]
+        T = ww_cond_generic<NB>(s, c.conds[s.phase], ALL, c.cs) & alive;
+    return T;
+}
 
-    // ---- PhaseNode, the part that does not depend on this turn's actions (nobody dies before the Referee):
-    // phase-0 guard, resolver bitset, first matching branch.  With the action queue it runs in the shadow
-    // of the queue's first LDS round trip (a lone wavefront has nothing else to cover it with).
-    bool pre_open = false;
-    uint32_t qe_cand = 0;
-    auto phase_precompute = [&]() {
-        const bool guard = s.phase == phase0_idx && !(s.flags & FLAG_PHASE0_DONE);
-        pre_open = !guard;
-        const uint32_t w = popc(alive & team_w), g = popc(alive & s.template get<F_TEAM_V>());
-        const uint32_t prev_eff = (s.flags >> 1) & 7u;
-        const uint32_t C = 1u | ((w == 0u) << RES_WOLVES_ZERO) | ((w >= g) << RES_WOLVES_GE_VILLAGERS) |
-                           ((prev_eff == EFF_DAY_RESOLVE) << RES_FOLLOWS_DAY) |
-                           ((prev_eff == EFF_NIGHT_RESOLVE) << RES_FOLLOWS_NIGHT) | (1u << RES_OTHERWISE);
-        // first branch (DSL order) whose resolver holds: row.r2 has one byte per branch with the bit of
-        // its resolver set (0 for absent branches), so the lowest non-zero byte of r2 & (C in every byte) wins
-        const uint32_t hit = row.r2 & __builtin_amdgcn_perm(C, C, 0u);   // C (< 256) in every byte
-        const uint32_t sh = ctz(hit) & 24u;
-        qe_cand = hit != 0u ? ((row.r3 >> sh) & 255u) : s.phase;         // next row index | its entry effect << 5
-    };
-    // the role-assignment values of the prepared deal (what `assign` writes), also shadow work
-    R dealt;
-    auto deal_precompute = [&]() {
-        if ((DEAL == 2 ? deal_now : DEAL == 1) && !deal.valid) {
-            // this game already has roles: prepare the next game's
-            const bool has_roles = (NB <= 8 ? s.W[2] : (s.W[R::NW - 2] | s.W[R::NW - 1])) != 0u;
-            const uint32_t g = has_roles ? (s.games < 0xFFFFu ? s.games + 1u : s.games) : s.games;
-            deal_roles<NB, LOWOCC>(deal, deal_key(rkey, g), g, n, nw, nth8);
-        }
-        deal_words<NB, LOWOCC>(deal, ALL, dealt);
-    };
-    uint32_t tk_next = 0;
+// ---- PhaseNode, the part that does not depend on this turn's actions (nobody dies before the Referee): phase-0 guard
+// (v2:1025-1052), resolver bitset, first matching branch.
+struct WwBranch {
+    bool open;                 // not the guard turn
+    uint32_t qe;               // next row index | its entry effect << 5 (the current row if no branch matches)
+};
+template <int NB>
+__device__ __forceinline__ void ww_phase_branch(const WWR<NB> &s, const DevRow &row, uint32_t phase0_idx, uint32_t alive, uint32_t team_w, WwBranch &b) {
+    const bool guard = s.phase == phase0_idx && !(s.flags & FLAG_PHASE0_DONE);
+    b.open = !guard;
+    const uint32_t w = popc(alive & team_w), g = popc(alive & s.template get<F_TEAM_V>());
+    const uint32_t prev_eff = (s.flags >> 1) & 7u;
+    const uint32_t C = 1u | ((w == 0u) << RES_WOLVES_ZERO) | ((w >= g) << RES_WOLVES_GE_VILLAGERS) |
+                       ((prev_eff == EFF_DAY_RESOLVE) << RES_FOLLOWS_DAY) |
+                       ((prev_eff == EFF_NIGHT_RESOLVE) << RES_FOLLOWS_NIGHT) | (1u << RES_OTHERWISE);
+    // first branch (DSL order) whose resolver holds: row.r2 has one byte per branch with the bit of
+    // its resolver set (0 for absent branches), so the lowest non-zero byte of r2 & (C in every byte) wins
+    const uint32_t hit = row.r2 & __builtin_amdgcn_perm(C, C, 0u);   // C (< 256) in every byte
+    const uint32_t sh = ctz(hit) & 24u;
+    b.qe = hit != 0u ? ((row.r3 >> sh) & 255u) : s.phase;
+}
 
-    // ---- BotBehaviorNode: every due bot acts with probability 3/4, one action per visit
-    uint32_t newly = 0, new_det_v = 0, new_det_w = 0;
-    const bool night = act >= ACT_WOLF_TARGET && act <= ACT_DETECTIVE;
-    {
-        uint32_t todo = valid ? (T & ~s.acted & ~human) : 0u;
-        const uint32_t known = s.det_v | s.det_w;
-        const uint32_t kw_alive = s.det_w & alive;
-        const uint32_t lo_kw = kw_alive & (0u - kw_alive);       // lowest known living werewolf
-        if (!QUEUE) {
-            phase_precompute();
-            deal_precompute();
-            tk_next = turn_key(rkey, turn + 1u);
-            while (todo) {
-                const uint32_t i = ctz(todo);
-                todo &= todo - 1u;
-                const uint32_t d = draw(tk, i);
-                const bool go = (d & 3u) != 0u;
-                const uint32_t c = ww_choose<NB, false>(act, i, d, alive, team_w, known, lo_kw, r_det, nullptr);
-                const uint32_t sh = 4u * i;
-                const nib_t clr = ~(nib_t(15) << sh), put = nib_t(c) << sh;
-                s.choice = go ? ((s.choice & clr) | put) : s.choice;
-                newly |= go ? (1u << i) : 0u;
-                // RefereeNode (A): record the action (bt:204-225 update_player_state)
-                s.sel = (go && night) ? ((s.sel & clr) | put) : s.sel;
-                const uint32_t tb = (go && act == ACT_DETECTIVE) ? (1u << (c - 1u)) : 0u;
-                new_det_w |= tb & team_w;
-                new_det_v |= tb & ~team_w;
-            }
-        } else {
-            const uint32_t lane = __lane_id();
-            const uint32_t cnt = popc(todo);
-            // NB <= 8: the room's slot -> player map (nibble r = its r-th due bot) from the ord8 table; the read is
-            // in flight during the scan, and a slot then needs a shift instead of an n-th-set-bit search
-            uint32_t ord = 0;
-            if (ORD) ord = ord8[todo & 0xFFu];
-            uint32_t off, total;
-            wave_excl_scan(cnt, off, total);
-            if (LOWOCC || total != 0u) {                        // wave-uniform; LOWOCC: some room almost always has a due bot
-                // per-room context of an action; `ky`: what the acting role knows (the Detective's memory
-                // at night, who the Detective is by day - ww_choose reads only one of the two per kind)
-                const uint32_t ky = night ? known : (ONEHOT ? (lo_kw != 0u ? r_det : 0u) : r_det);
-                const uint32_t kind = ONEHOT ? ((1u << act) >> 1) : act;          // one-hot: ACT_WOLF_TARGET = 1 -> bit 0 ...
-                const uint4 ctx = ORD ? make_uint4(alive | (team_w << 16) | (kind << 28), ky | (lo_kw << 8) | (off << 16) | (lane << 26), ord, tk)
-                                      : make_uint4(alive | (team_w << 16) | (act << 28), ky | (lo_kw << 16), todo | (off << 16) | (lane << 26), tk);
-                if (NB <= 8) *reinterpret_cast<uint2 *>(&lw->res[lane]) = make_uint2(0u, 0u);     // only x, y come back
-                else lw->res[lane] = make_uint4(0u, 0u, 0u, 0u);
-                // Queue slot -> owning room.  A room with cnt due bots owns slots [off, off + cnt); it writes
-                // NB slots from `off` on, highest first (immediate offsets, no per-slot address or
-                // predicate).  The surplus writes land in the ranges of the rooms after it and are
-                // overwritten by their owners: an owner's write to its r-th slot is issued at step r,
-                // any intruder's at a step > r, i.e. earlier.  Rooms without a due bot do not write
-                // (they would tie with the next owner inside one instruction).
-                if (LOWOCC) {
-                    auto *lo = reinterpret_cast<WaveLdsLow *>(lw);
-                    // no predicate here either: a room without a due bot writes to a scratch range behind the queue
-                    uint4 *qp = lo->slot + (cnt != 0u ? off : 64u * 13u + lane);
-#pragma unroll
-                    for (int j = NB - 1; j >= 0; j--) {
-                        qp[j] = ctx;
-                        asm volatile("" ::: "memory");             // the stores must issue in this order
-                    }
-                } else {
-                    auto *hi = reinterpret_cast<WaveLds *>(lw);
-                    hi->ctx[lane] = ctx;
-                    if (cnt != 0u) {
-                        uint8_t *qp = hi->queue + off;
-#pragma unroll
-                        for (int j = NB - 1; j >= 0; j--) {
-                            qp[j] = (uint8_t)lane;
-                            asm volatile("" ::: "memory");
-                        }
-                    }
-                }
-                wave_sync();
-                // slot k -> the owning room's context (slots past `total` hold stale entries: computed like the
-                // others, result dropped).  The first round's read is issued BEFORE the shadow work below.
-                auto fetch = [&](uint32_t k) -> uint4 {
-                    if (LOWOCC) return reinterpret_cast<WaveLdsLow *>(lw)->slot[k];
-                    auto *hi = reinterpret_cast<WaveLds *>(lw);
-                    return hi->ctx[hi->queue[k] & 63u];
-                };
-                uint4 c4 = fetch(lane);
-                if (SHADOW) {
-                    phase_precompute();
-                    asm volatile("" : "+v"(qe_cand));              // stays here: not sunk below the loop
-                }
-                // at least one round (total == 0: every slot is stale and dropped): the loop is left BEFORE the next
-                // round's read is issued, so nothing of the queue is in flight behind it
-                for (uint32_t base = 0;; base += 64u) {
-                    const uint32_t k = base + lane;
-                    if (GE_STAMPS && stamps && base == 0u) { asm volatile("" :: "v"(c4.x)); stamps->mark(1); }   // [.. first slot in registers]
-                    uint32_t L, i, know, lokw;
-                    if (ORD) {
-                        L = c4.y >> 26;
-                        const uint32_t rank = (k - ((c4.y >> 16) & 0x3FFu)) & 7u;       // this slot = the rank-th due bot of room L
-                        i = (c4.z >> (4u * rank)) & 7u;
-                        know = c4.y & 0xFFu; lokw = (c4.y >> 8) & 0xFFu;
-                    } else {
-                        L = c4.z >> 26;
-                        const uint32_t due = c4.z & 0xFFFFu, rank = (k - ((c4.z >> 16) & 0x3FFu)) & 15u;
-                        i = (LOWOCC ? nth_set_bit<NB>(due | (1u << 31), rank) : nth_set_bit_lds<NB>(nth8, due, rank)) & 15u;
-                        know = c4.y & 0xFFFFu; lokw = c4.y >> 16;
-                    }
-                    const uint32_t d = draw(c4.w, i);
-                    const bool go = k < total && (d & 3u) != 0u;
-                    if (LOWOCC) {
-                        // the choice is computed for every slot and only the result is predicated: a
-                        // conditional block would split the slot read in two dependent LDS round trips
-                        uint32_t c = ONEHOT ? ww_choose_onehot8(c4.x, i, d, know, lokw, know)
-                                            : ww_choose<NB, false>(c4.x >> 28, i, d, c4.x & 0xFFFFu, (c4.x >> 16) & 0xFFFu,
-                                                                   know, lokw, know, nth8);
-                        if (GE_PIN_CHOICE && NB > 8) asm volatile("" : "+v"(c));   // stays outside the exec-masked block below
-                        if (GE_GO_BRANCHLESS) {
-                            // every slot ORs into its room's result (L is a lane index even for a stale slot), zeros if it does not act
-                            uint32_t *r = reinterpret_cast<uint32_t *>(&lw->res[L]);
-                            atomicOr(r, go ? (1u << i) : 0u);
-                            atomicOr(r + 1 + (i >> 3), go ? (c << (4u * (i & 7u))) : 0u);
-                        } else if (go) {
-                            uint32_t *r = reinterpret_cast<uint32_t *>(&lw->res[L]);
-                            if (!ONE) atomicOr(r, 1u << i);
-                            atomicOr(r + 1 + (i >> 3), c << (4u * (i & 7u)));
-                        }
-                    } else if (go) {
-                        const uint32_t c = ww_choose<NB, true>(c4.x >> 28, i, d, c4.x & 0xFFFFu, (c4.x >> 16) & 0xFFFu,
-                                                               know, lokw, know, nth8);
-                        uint32_t *r = reinterpret_cast<uint32_t *>(&lw->res[L]);
-                        if (!ONE) atomicOr(r, 1u << i);
-                        atomicOr(r + 1 + (i >> 3), c << (4u * (i & 7u)));
-                    }
-                    if (base + 64u >= total) break;                // wave-uniform
-                    c4 = fetch(k + 64u);
-                }
-                wave_sync();
-                const uint4 r = NB <= 8 ? make_uint4(reinterpret_cast<const uint2 *>(&lw->res[lane])->x, reinterpret_cast<const uint2 *>(&lw->res[lane])->y, 0u, 0u)
-                                        : lw->res[lane];
-                if (SHADOW) {                                      // shadow of the result read
-                    tk_next = turn_key(rkey, turn + 1u);
-                    deal_precompute();
-                    asm volatile("" : "+v"(tk_next));
-#pragma unroll
-                    for (int k = 0; k < R::NW; k++) asm volatile("" : "+v"(dealt.W[k]));
-                    // keeps the slot registers reserved up to here: reusing them for the work above would make the
-                    // compiler wait for the queue's LDS traffic first (a read into them may be in flight)
-                    asm volatile("" :: "v"(c4.x), "v"(c4.y), "v"(c4.z), "v"(c4.w));
-                }
-                newly = r.x;
-                if (GE_STAMPS && stamps) { asm volatile("" :: "v"(newly)); stamps->mark(2); }                 // [.. results in registers]
-                const nib_t got = NB > 8 ? (nib_t)(((uint64_t)r.z << 32) | r.y) : (nib_t)r.y;
-                const nib_t m15 = nib_nonzero(got);              // c >= 1, so a nibble is set iff that player acted
-                if (ONE) {                                       // bit i = nibble i is non-zero
-                    uint32_t x = (uint32_t)m15 & 0x11111111u;
-                    x = (x | (x >> 3)) & 0x03030303u; x = (x | (x >> 6)) & 0x000F000Fu;
-                    newly = (x | (x >> 12)) & 0xFFu;
-                }
-                s.choice = (s.choice & ~m15) | got;
-                // RefereeNode (A): record the action (bt:204-225 update_player_state)
-                s.sel = night ? ((s.sel & ~m15) | got) : s.sel;
-                {
-                    const uint32_t c = (uint32_t)(got >> (4u * ctz(newly | 0x80000000u))) & 15u;
-                    const uint32_t tb = (act == ACT_DETECTIVE && newly) ? (1u << ((c - 1u) & 15u)) : 0u;
-                    new_det_w = tb & team_w;
-                    new_det_v = tb & ~team_w;
-                }
-                if (!SHADOW) { phase_precompute(); tk_next = turn_key(rkey, turn + 1u); deal_precompute(); }
-            } else {
-                phase_precompute();
-                deal_precompute();
-                tk_next = turn_key(rkey, turn + 1u);
-            }
-        }
+// ---- `deal_now` (wave-uniform, every GE_DEAL_PERIOD-th turn): lanes without a prepared deal compute their next one; then the
+// role-assignment values of the prepared deal (what an assignment writes) - except in the packed form, which only the
+// assigning lanes expand (ww_apply_effect)
+template <int NB, bool LOWOCC, bool SINGLE>
+__device__ __forceinline__ void ww_prepare_deal(const WWR<NB> &s, const WwCtx &c, Deal &deal, bool deal_now, uint32_t ALL, WWR<NB> &dealt) {
+    using B = WwBuild<NB, LOWOCC, SINGLE>;
+    if (deal_now && !(deal.gv & DEAL_VALID)) {
+        const uint32_t g = deal_next_game<NB>(s);
+        deal_roles<NB, B::TABLE, B::DEAL_FORM>(deal, deal_key(c.rkey, g), g, c.n, c.nw, c.nth8);
     }
-    tk_io = tk_next;
-    s.acted |= newly;
-    s.template set<F_SUB>(night ? newly : 0u);                 // night_action_submitted
-    ev_newly = newly;
-    if (trace) {                                              // wave-uniform
-        uint32_t x = newly;                                   // nibble mask of the new actors
-        uint64_t m = 0;
-#pragma unroll
-        for (int i = 0; i < NB; i++) m |= (uint64_t)((x >> i) & 1u) << (4 * i);
-        ev_choice = (uint64_t)s.choice & nib_fill(m);
-    }
+    if (B::DEAL_FORM != DEAL_PACKED) deal_words<NB, B::DEAL_FORM>(deal, ALL, dealt);
+}
 
-    // ---- PhaseNode: phase-0 guard (v2:1025-1052): first turn only records phase 0, Referee skipped;
-    // completion: every target player has acted in this visit
-    s.flags |= FLAG_PHASE0_DONE;                               // set by the guard turn; already set afterwards
-    uint32_t qe;
-    if (LOWOCC && GE_SEL_OPEN) {
-        // no short-circuit evaluation: && / || became three nested exec-mask regions here (see ww_choose)
-        const uint32_t open = (uint32_t)pre_open & ((uint32_t)(comp != COMP_ACTION) | (uint32_t)((T & ~s.acted) == 0u));
-        qe = sel32(open != 0u, qe_cand, s.phase);
+// ---- BotBehaviorNode: every due bot acts with probability 3/4, one action per visit (POLICY.md §3).
+// Lane = room leaves this step badly balanced, so the wavefront compacts all due (room, player) actions of its 64 rooms
+// into one queue in LDS (WaveLds), every lane takes one slot per round, results return by LDS atomic OR.
+// shadow1 / shadow2: work that does not depend on this turn's actions, placed behind the first slot read / the result
+// read (WwBuild::SHADOW), else run after the queue.
+struct WwActs { uint32_t newly, det_v, det_w; };   // who acted now; the Detective's new knowledge (villager / werewolf)
+
+template <int NB, bool LOWOCC, typename S1, typename S2>
+__device__ __forceinline__ void ww_queue_actions(WWR<NB> &s, const WwCtx &c, uint32_t T, uint32_t act, bool night, uint32_t alive, uint32_t team_w,
+                                                 uint32_t r_det, uint32_t tk, WwActs &out, S1 &&shadow1, S2 &&shadow2, Stamps *stamps) {
+    using nib_t = typename WWR<NB>::nib_t;
+    using B = WwBuild<NB, LOWOCC>;
+    auto *lw = static_cast<typename WaveLdsOf<LOWOCC>::type *>(c.wave_lds);
+    const uint32_t todo = c.valid ? (T & ~s.acted & ~c.human) : 0u;
+    const uint32_t known = s.det_v | s.det_w;
+    const uint32_t kw_alive = s.det_w & alive;
+    const uint32_t lo_kw = kw_alive & (0u - kw_alive);       // lowest known living werewolf
+    const uint32_t lane = __lane_id();
+    const uint32_t cnt = popc(todo);
+    // N <= 8: the room's slot -> player map (nibble r = its r-th due bot) from the ord8 table; the read is
+    // in flight during the scan, and a slot then needs a shift instead of an n-th-set-bit search
+    uint32_t ord = 0;
+    if (B::ORD) ord = c.ord8[todo & 0xFFu];
+    uint32_t off, total;
+    wave_excl_scan(cnt, off, total);
+    out.newly = 0; out.det_v = 0; out.det_w = 0;
+    if (!(LOWOCC || total != 0u)) {                         // wave-uniform; LOWOCC: some room almost always has a due bot
+        shadow1();
+        shadow2();
+        return;
+    }
+    // per-room context of an action; `ky`: what the acting role knows (the Detective's memory
+    // at night, who the Detective is by day - ww_choose reads only one of the two per kind)
+    const uint32_t ky = night ? known : (B::ONEHOT ? (lo_kw != 0u ? r_det : 0u) : r_det);
+    const uint32_t kind = B::ONEHOT ? ((1u << act) >> 1) : act;          // one-hot: ACT_WOLF_TARGET = 1 -> bit 0 ...
+    const uint4 ctx = B::ORD ? make_uint4(alive | (team_w << 16) | (kind << 28), ky | (lo_kw << 8) | (off << 16) | (lane << 26), ord, tk)
+                             : make_uint4(alive | (team_w << 16) | (act << 28), ky | (lo_kw << 16), todo | (off << 16) | (lane << 26), tk);
+    if (NB <= 8) *reinterpret_cast<uint2 *>(&lw->res[lane]) = make_uint2(0u, 0u);     // only x, y come back
+    else lw->res[lane] = make_uint4(0u, 0u, 0u, 0u);
+    // Queue slot -> owning room.  A room with cnt due bots owns slots [off, off + cnt); it writes
+    // NB slots from `off` on, highest first (immediate offsets, no per-slot address or
+    // predicate).  The surplus writes land in the ranges of the rooms after it and are
+    // overwritten by their owners: an owner's write to its r-th slot is issued at step r,
+    // any intruder's at a step > r, i.e. earlier.  Rooms without a due bot do not write
+    // (they would tie with the next owner inside one instruction).
+    if (LOWOCC) {
+        auto *lo = reinterpret_cast<WaveLdsLow *>(lw);
+        // no predicate here either: a room without a due bot writes to a scratch range behind the queue
+        uint4 *qp = lo->slot + (cnt != 0u ? off : 64u * 13u + lane);
+#pragma unroll
+        for (int j = NB - 1; j >= 0; j--) {
+            qp[j] = ctx;
+            asm volatile("" ::: "memory");             // the stores must issue in this order
+        }
     } else {
-        const bool open = pre_open && (comp != COMP_ACTION || (T & ~s.acted) == 0u);
-        qe = open ? qe_cand : s.phase;
+        auto *hi = reinterpret_cast<WaveLds *>(lw);
+        hi->ctx[lane] = ctx;
+        if (cnt != 0u) {
+            uint8_t *qp = hi->queue + off;
+#pragma unroll
+            for (int j = NB - 1; j >= 0; j--) {
+                qp[j] = (uint8_t)lane;
+                asm volatile("" ::: "memory");
+            }
+        }
     }
-    const uint32_t q = qe & 31u;
-    {   // investigated_alignments[c] = team(c): an assignment, so a stale entry is replaced
-        // (the guard turn has no actions: both masks are 0)
-        const uint32_t seen = new_det_v | new_det_w;
-        s.det_v = (s.det_v & ~seen) | new_det_v;
-        s.det_w = (s.det_w & ~seen) | new_det_w;
+    wave_sync();
+    // slot k -> the owning room's context (slots past `total` hold stale entries: computed like the
+    // others, result dropped).  The first round's read is issued BEFORE the shadow work below.
+    auto fetch = [&](uint32_t k) -> uint4 {
+        if (LOWOCC) return reinterpret_cast<WaveLdsLow *>(lw)->slot[k];
+        auto *hi = reinterpret_cast<WaveLds *>(lw);
+        return hi->ctx[hi->queue[k] & 63u];
+    };
+    uint4 c4 = fetch(lane);
+    if (B::SHADOW) shadow1();
+    // at least one round (total == 0: every slot is stale and dropped): the loop is left BEFORE the next
+    // round's read is issued, so nothing of the queue is in flight behind it
+    for (uint32_t base = 0;; base += 64u) {
+        const uint32_t k = base + lane;
+        if (GE_STAMPS && stamps && base == 0u) { asm volatile("" :: "v"(c4.x)); stamps->mark(1); }   // [.. first slot in registers]
+        uint32_t L, i, know, lokw;
+        if (B::ORD) {
+            L = c4.y >> 26;
+            const uint32_t rank = (k - ((c4.y >> 16) & 0x3FFu)) & 7u;       // this slot = the rank-th due bot of room L
+            i = (c4.z >> (4u * rank)) & 7u;
+            know = c4.y & 0xFFu; lokw = (c4.y >> 8) & 0xFFu;
+        } else {
+            L = c4.z >> 26;
+            const uint32_t due = c4.z & 0xFFFFu, rank = (k - ((c4.z >> 16) & 0x3FFu)) & 15u;
+            i = (LOWOCC ? nth_set_bit<NB>(due | (1u << 31), rank) : nth_set_bit_lds<NB>(c.nth8, due, rank)) & 15u;
+            know = c4.y & 0xFFFFu; lokw = c4.y >> 16;
+        }
+        const uint32_t d = draw(c4.w, i);
+        const bool go = k < total && (d & 3u) != 0u;
+        if (LOWOCC) {
+            // the choice is computed for every slot and only the result is predicated: a
+            // conditional block would split the slot read in two dependent LDS round trips
+            uint32_t ch = B::ONEHOT ? ww_choose_onehot8(c4.x, i, d, know, lokw, know)
+                                    : ww_choose<NB, false>(c4.x >> 28, i, d, c4.x & 0xFFFFu, (c4.x >> 16) & 0xFFFu, know, lokw, know, c.nth8);
+            if (B::PIN_CHOICE) asm volatile("" : "+v"(ch));   // stays outside the exec-masked block below
+            if (go) {
+                uint32_t *r = reinterpret_cast<uint32_t *>(&lw->res[L]);
+                if (!B::ONE_ATOMIC) atomicOr(r, 1u << i);
+                atomicOr(r + 1 + (i >> 3), ch << (4u * (i & 7u)));
+            }
+        } else if (go) {
+            const uint32_t ch = ww_choose<NB, true>(c4.x >> 28, i, d, c4.x & 0xFFFFu, (c4.x >> 16) & 0xFFFu, know, lokw, know, c.nth8);
+            uint32_t *r = reinterpret_cast<uint32_t *>(&lw->res[L]);
+            atomicOr(r, 1u << i);
+            atomicOr(r + 1 + (i >> 3), ch << (4u * (i & 7u)));
+        }
+        if (base + 64u >= total) break;                // wave-uniform
+        c4 = fetch(k + 64u);
     }
-    if (q == s.phase) return;
+    wave_sync();
+    const uint4 r = NB <= 8 ? make_uint4(reinterpret_cast<const uint2 *>(&lw->res[lane])->x, reinterpret_cast<const uint2 *>(&lw->res[lane])->y, 0u, 0u)
+                            : lw->res[lane];
+    if (B::SHADOW) {                                       // shadow of the result read
+        shadow2();
+        // keeps the slot registers reserved up to here: reusing them for the work above would make the
+        // compiler wait for the queue's LDS traffic first (a read into them may be in flight)
+        asm volatile("" :: "v"(c4.x), "v"(c4.y), "v"(c4.z), "v"(c4.w));
+    }
+    uint32_t newly = r.x;
+    if (GE_STAMPS && stamps) { asm volatile("" :: "v"(newly)); stamps->mark(2); }                 // [.. results in registers]
+    const nib_t got = NB > 8 ? (nib_t)(((uint64_t)r.z << 32) | r.y) : (nib_t)r.y;
+    const nib_t m15 = nib_nonzero(got);              // a choice is >= 1, so a nibble is set iff that player acted
+    if (B::ONE_ATOMIC) {                             // bit i = nibble i is non-zero
+        uint32_t x = (uint32_t)m15 & 0x11111111u;
+        x = (x | (x >> 3)) & 0x03030303u; x = (x | (x >> 6)) & 0x000F000Fu;
+        newly = (x | (x >> 12)) & 0xFFu;
+    }
+    s.choice = (s.choice & ~m15) | got;
+    // RefereeNode (A): record the action (bt:204-225 update_player_state)
+    s.sel = night ? ((s.sel & ~m15) | got) : s.sel;
+    {
+        const uint32_t ch = (uint32_t)(got >> (4u * ctz(newly | 0x80000000u))) & 15u;
+        const uint32_t tb = (act == ACT_DETECTIVE && newly) ? (1u << ((ch - 1u) & 15u)) : 0u;
+        out.det_w = tb & team_w;
+        out.det_v = tb & ~team_w;
+    }
+    out.newly = newly;
+    if (!B::SHADOW) { shadow1(); shadow2(); }
+}
 
-    // ---- RefereeNode (B): effect of entering q
-    const DevRow qrow = rows[q];                               // LDS read in flight during the effect: first used at the end
-    const uint32_t eff = qe >> 5;
+// ---- PhaseNode: completion (every target player has acted in this visit) and the chosen branch
+template <int NB, bool LOWOCC>
+__device__ __forceinline__ uint32_t ww_decide(const WWR<NB> &s, uint32_t comp, uint32_t T, const WwBranch &b) {
+    if (WwBuild<NB, LOWOCC>::SEL_OPEN) {
+        // no short-circuit evaluation: && / || became three nested exec-mask regions here (see ww_choose)
+        const uint32_t open = (uint32_t)b.open & ((uint32_t)(comp != COMP_ACTION) | (uint32_t)((T & ~s.acted) == 0u));
+        return sel32(open != 0u, b.qe, s.phase);
+    }
+    const bool open = b.open && (comp != COMP_ACTION || (T & ~s.acted) == 0u);
+    return open ? b.qe : s.phase;
+}
+
+// ---- RefereeNode (B): the effect of entering row q = qe & 31 (qe >> 5 = its entry effect), then the move itself
+template <int NB, bool LOWOCC, bool SINGLE>
+__device__ __forceinline__ void ww_apply_effect(WWR<NB> &s, DevRow &row, const WwCtx &c, uint32_t qe, uint32_t alive, uint32_t ALL, uint32_t turn,
+                                                Deal &deal, WWR<NB> &dealt) {
+    using R = WWR<NB>;
+    using nib_t = typename R::nib_t;
+    using B = WwBuild<NB, LOWOCC, SINGLE>;
+    const uint32_t q = qe & 31u, eff = qe >> 5, p_eff = (row.r0 >> 5) & 7u;
+    DevRow qrow = row;
+    if (!SINGLE) qrow = c.rows[q];                             // LDS read in flight during the effect: first used at the end
     // night / day resolution: the plurality victim dies unless the (highest-id living) Doctor guards it
     auto resolve = [&](bool on, bool day) {
         const uint32_t voters = day ? (alive & s.acted) : (alive & s.template get<F_WOLF>());
-        const uint32_t victim = plurality<NB, nib_t, GE_PK_KEYS != 0>(day ? s.choice : s.sel, voters);
+        const uint32_t victim = plurality<NB, nib_t>(day ? s.choice : s.sel, voters);
         const uint32_t docs = alive & s.template get<F_DOC>();
         const uint32_t guarded = (uint32_t)(s.sel >> (4u * (31u - (uint32_t)__clz((int)(docs | 1u))))) & 15u;
-        uint32_t protect, bit;
-        if (LOWOCC && GE_SEL_RESOLVE) {                        // data flow, no exec-mask region (see ww_choose)
-            protect = guarded & (0u - (uint32_t)(!day && docs != 0u));
-            bit = (1u << ((victim - 1u) & 15u)) & (0u - (uint32_t)(on && victim != 0u && victim != protect));
-        } else {
-            protect = (!day && docs) ? guarded : 0u;
-            bit = (on && victim != 0u && victim != protect) ? (1u << ((victim - 1u) & 15u)) : 0u;
-        }
+        const uint32_t protect = (!day && docs) ? guarded : 0u;
+        const uint32_t bit = (on && victim != 0u && victim != protect) ? (1u << ((victim - 1u) & 15u)) : 0u;
         s.template clear<F_ALIVE>(bit); s.template clear<F_CAN_VOTE>(bit); s.template clear<F_ELIG>(bit);
         s.template set<F_REVEALED>(bit);
     };
-    // role assignment: the deal of this game was normally prepared ahead (run loop, every 8th turn, for
-    // all lanes of the wavefront at once); fall back to dealing here if it was not
+    // role assignment: the deal of this game was normally prepared ahead (ww_prepare_deal, every GE_DEAL_PERIOD-th turn,
+    // for all lanes of the wavefront at once); fall back to dealing here if it was not
     const bool is_assign = eff == EFF_ASSIGN_ROLES;
-    // (bitwise, not && : one exec-mask region instead of two nested ones in the lone-wavefront build)
-    const bool deal_missing = GE_SEL_NEED ? (bool)((uint32_t)is_assign & ((uint32_t)(deal.valid == 0u) | (uint32_t)(deal.game != s.games)))
-                                          : (is_assign && !(deal.valid && deal.game == s.games));
-    if (GE_UNLIKELY ? __builtin_expect(deal_missing, 0) : deal_missing) {
-        deal_roles<NB, LOWOCC>(deal, deal_key(rkey, s.games), s.games, n, nw, nth8);
-        deal_precompute();
+    if (is_assign && deal.gv != (s.games | DEAL_VALID)) {
+        deal_roles<NB, B::TABLE, B::DEAL_FORM>(deal, deal_key(c.rkey, s.games), s.games, c.n, c.nw, c.nth8);
+        if (B::DEAL_FORM != DEAL_PACKED) deal_words<NB, B::DEAL_FORM>(deal, ALL, dealt);
     }
     // the fields a deal replaces, as masks over the packed predicate words
     R dmask;
@@ -917,14 +865,16 @@ __device__ __forceinline__ void ww_turn(WWR<NB> &s, DevRow &row, const DevRow *r
         // lone wavefront: every divergent block costs an exec-mask sequence and a branch bubble, and both
         // effects are entered by some room of the wavefront on most turns anyway - so both are evaluated
         // for every lane and applied by selects
+        if (B::DEAL_FORM == DEAL_PACKED) deal_words<NB, B::DEAL_FORM>(deal, ALL, dealt);
 #pragma unroll
         for (int k = 0; k < R::NW; k++) s.W[k] = is_assign ? ((s.W[k] & ~dmask.W[k]) | dealt.W[k]) : s.W[k];
-        deal.valid = is_assign ? 0u : deal.valid;
+        deal.gv = is_assign ? 0u : deal.gv;
         resolve(eff == EFF_NIGHT_RESOLVE || eff == EFF_DAY_RESOLVE, eff == EFF_DAY_RESOLVE);
     } else if (is_assign) {
+        if (B::DEAL_FORM == DEAL_PACKED) deal_words<NB, B::DEAL_FORM>(deal, ALL, dealt);
 #pragma unroll
         for (int k = 0; k < R::NW; k++) s.W[k] = (s.W[k] & ~dmask.W[k]) | dealt.W[k];
-        deal.valid = 0u;
+        deal.gv = 0u;
     } else if (eff == EFF_NIGHT_RESOLVE || eff == EFF_DAY_RESOLVE) {
         resolve(true, eff == EFF_DAY_RESOLVE);
     }
@@ -935,8 +885,68 @@ __device__ __forceinline__ void ww_turn(WWR<NB> &s, DevRow &row, const DevRow *r
     s.flags = (s.flags & FLAG_PHASE0_DONE) | (p_eff << 1);
     s.prev = s.phase;
     s.phase = q;
-    row = qrow;
-    s.end_turn = (((qrow.r0 >> 11) & 7u) == 0u && s.end_turn == END_NONE) ? (turn < 0xFFFEu ? turn : 0xFFFEu) : s.end_turn;
+    const bool terminal = SINGLE ? ((c.term_mask >> q) & 1u) != 0u : ((qrow.r0 >> 11) & 7u) == 0u;
+    if (!SINGLE) row = qrow;
+    s.end_turn = (terminal && s.end_turn == END_NONE) ? (turn < 0xFFFEu ? turn : 0xFFFEu) : s.end_turn;
+}
+
+// `row` is the table row of s.phase, kept in registers across turns: LDS is read only on a transition (a single-turn
+// build leaves it as it is: nobody reads it after the turn).
+// tk_io: in = turn_key(rkey, turn), out = the next turn's key (computed in an LDS wait shadow; not in a single-turn build).
+// ev_*: this turn's logged actions (who acted, what they chose) for the optional event trace.
+template <int NB, bool LOWOCC, bool GENERIC = false, bool SINGLE = false>
+__device__ __forceinline__ void ww_turn(WWR<NB> &s, DevRow &row, const WwCtx &c, uint32_t turn, uint32_t &tk_io, bool trace, Deal &deal, bool deal_now,
+                                        uint32_t &ev_newly, uint64_t &ev_choice, Stamps *stamps = nullptr) {
+    using R = WWR<NB>;
+    using B = WwBuild<NB, LOWOCC, SINGLE>;
+    const uint32_t ALL = (1u << c.n) - 1u;
+    const uint32_t comp = row.r0 & 3u, act = (row.r0 >> 2) & 7u;
+    const uint32_t alive = s.template get<F_ALIVE>(), team_w = s.template get<F_TEAM_W>(), r_det = s.template get<F_DET>();
+    const bool night = act >= ACT_WOLF_TARGET && act <= ACT_DETECTIVE;
+
+    const uint32_t T = ww_targets<NB, LOWOCC, GENERIC>(s, row, c, alive, ALL);
+    if (GE_STAMPS && stamps) { asm volatile("" :: "v"(T)); stamps->mark(0); }        // [end of previous turn .. row in registers]
+
+    WwBranch br;
+    R dealt;
+    uint32_t tk_next = 0;
+    WwActs acts;
+    ww_queue_actions<NB, LOWOCC>(s, c, T, act, night, alive, team_w, r_det, tk_io, acts,
+        [&]() {
+            ww_phase_branch<NB>(s, row, c.phase0_idx, alive, team_w, br);
+            if (B::SHADOW) asm volatile("" : "+v"(br.qe));     // stays in the shadow: not sunk below the queue loop
+        },
+        [&]() {
+            if (!SINGLE) tk_next = turn_key(c.rkey, turn + 1u);
+            ww_prepare_deal<NB, LOWOCC, SINGLE>(s, c, deal, deal_now, ALL, dealt);
+            if (B::SHADOW) {
+                if (!SINGLE) asm volatile("" : "+v"(tk_next));
+                if (B::DEAL_FORM != DEAL_PACKED) {
+#pragma unroll
+                    for (int k = 0; k < R::NW; k++) asm volatile("" : "+v"(dealt.W[k]));
+                }
+            }
+        }, stamps);
+    s.acted |= acts.newly;
+    s.template set<F_SUB>(night ? acts.newly : 0u);            // night_action_submitted
+    ev_newly = acts.newly;
+    if (trace) {                                              // wave-uniform
+        uint64_t m = 0;                                       // nibble mask of the new actors
+#pragma unroll
+        for (int i = 0; i < NB; i++) m |= (uint64_t)((acts.newly >> i) & 1u) << (4 * i);
+        ev_choice = (uint64_t)s.choice & nib_fill(m);
+    }
+
+    tk_io = tk_next;
+    s.flags |= FLAG_PHASE0_DONE;                               // set by the guard turn; already set afterwards
+    const uint32_t qe = ww_decide<NB, LOWOCC>(s, comp, T, br);
+    {   // investigated_alignments[c] = team(c): an assignment, so a stale entry is replaced
+        // (the guard turn has no actions: both masks are 0)
+        const uint32_t seen = acts.det_v | acts.det_w;
+        s.det_v = (s.det_v & ~seen) | acts.det_v;
+        s.det_w = (s.det_w & ~seen) | acts.det_w;
+    }
+    if ((qe & 31u) != s.phase) ww_apply_effect<NB, LOWOCC, SINGLE>(s, row, c, qe, alive, ALL, turn, deal, dealt);
 }
 
 // ------------------------------------------------------------------ two truths and a lie
@@ -959,11 +969,12 @@ __device__ __forceinline__ uint32_t even_bits(uint32_t x) {
 
 // QUEUE: bot actions through the wavefront work queue (see ww_turn) - pays from 8 players on, where the
 // first turn of a vote has 7-11 due bots in some room of every wavefront; TABLE: n-th-set-bit from LDS
-template <int NB, bool QUEUE, bool TABLE, bool GENERIC = false>
+// SINGLE: a one-turn launch - the row the room moves to is not fetched (only whether it is terminal: term_mask)
+template <int NB, bool QUEUE, bool TABLE, bool GENERIC = false, bool SINGLE = false>
 __device__ __forceinline__ void tt_turn(TT<NB> &s, uint32_t &done, DevRow &row, const DevRow *rows, const DevCond *conds, CondShape cs, void *wave_lds, const uint8_t *nth8,
                                         bool valid, uint32_t n, uint32_t rounds,
                                         uint32_t phase0_idx, uint32_t rkey, uint32_t turn,
-                                        bool trace, uint32_t human, uint32_t &ev_newly, uint64_t &ev_choice) {
+                                        bool trace, uint32_t human, uint32_t term_mask, uint32_t &ev_newly, uint64_t &ev_choice) {
     // done: tt_done_mask of s.rounds, maintained here (the caller derives it when it loads or replaces s)
     const uint32_t ALL = (1u << n) - 1u;
     const uint32_t comp = row.r0 & 3u, act = (row.r0 >> 2) & 7u, p_eff = (row.r0 >> 5) & 7u;
@@ -1083,7 +1094,8 @@ __device__ __forceinline__ void tt_turn(TT<NB> &s, uint32_t &done, DevRow &row, 
     const uint32_t q = qe & 31u;
     if (q == s.phase) return;
 
-    const DevRow qrow = rows[q];                               // in flight during the effect (see ww_turn)
+    DevRow qrow = row;
+    if (!SINGLE) qrow = rows[q];                               // in flight during the effect (see ww_turn)
     const uint32_t eff = qe >> 5;
     if (eff == EFF_TT_ROUND_START) {
         const uint32_t cand = ALL & ~done;                     // lowest id that has not spoken R rounds yet
@@ -1116,8 +1128,9 @@ __device__ __forceinline__ void tt_turn(TT<NB> &s, uint32_t &done, DevRow &row, 
     s.flags = (s.flags & FLAG_PHASE0_DONE) | (p_eff << 1);
     s.prev = s.phase;
     s.phase = q;
-    row = qrow;
-    if (((qrow.r0 >> 11) & 7u) == 0u && s.end_turn == END_NONE) s.end_turn = turn < 0xFFFEu ? turn : 0xFFFEu;
+    const bool terminal = SINGLE ? ((term_mask >> q) & 1u) != 0u : ((qrow.r0 >> 11) & 7u) == 0u;
+    if (!SINGLE) row = qrow;
+    if (terminal && s.end_turn == END_NONE) s.end_turn = turn < 0xFFFEu ? turn : 0xFFFEu;
 }
 #endif  // __HIPCC__
 

@@ -43,34 +43,47 @@ template <int NB> struct WW {
     nib_t sel, choice;                              // selected_target_id / latest action choice
     uint32_t phase, prev, flags, end_turn;
     uint32_t games;                                 // games this slot has completed (restart mode), 16 bits
+    uint32_t deal_cache;                            // N <= 8: the prepared role deal of the room's next assignment (DealPk), 0 = none
 };
 
 template <int NB> struct WWLayout;
 
+// N <= 8: the record IS the kernels' in-register form (WWR<8> below) - words 0..2 are the three packed predicate words
+// (roles one-hot per class), so a launch neither converts roles on load nor on store:
+//   w0 alive | can_vote | revealed | secret        w1 elig | sub | team_v | team_w       w2 r_vil | r_wolf | r_doc | r_det
+//   w3 det_v | det_w | phase | prev                w4 selected_target nibbles            w5 choice nibbles
+//   w6 end_turn (16) | flags (8) | acted (8)       w7 games (16) | prepared deal (16)
+// The prepared deal (ge_device.h DealPk) is a cache of a pure function of (seed, room, games): it lets un-fused launches
+// (one turn each) prepare role deals ahead like a fused launch does in registers.  It is not part of the room's state:
+// ge_room_view does not show it, ge_batch_write_rooms clears it, the summary checksum skips it.
 template <> struct WWLayout<8> {
     static constexpr int WORDS = 8;
+    static constexpr uint32_t CHECKSUM_MASK7 = 0x0000FFFFu;   // word 7 without the deal cache
     static GE_HD void unpack(const uint32_t *w, WW<8> &s) {
         s.alive = w[0] & 0xFF; s.can_vote = (w[0] >> 8) & 0xFF; s.revealed = (w[0] >> 16) & 0xFF; s.secret = w[0] >> 24;
         s.elig = w[1] & 0xFF; s.sub = (w[1] >> 8) & 0xFF; s.team_v = (w[1] >> 16) & 0xFF; s.team_w = w[1] >> 24;
-        s.acted = w[2] & 0xFF; s.rb0 = (w[2] >> 8) & 0xFF; s.rb1 = (w[2] >> 16) & 0xFF; s.rb2 = w[2] >> 24;
+        const uint32_t vil = w[2] & 0xFF, wolf = (w[2] >> 8) & 0xFF, doc = (w[2] >> 16) & 0xFF, det = w[2] >> 24;
+        s.rb0 = vil | doc; s.rb1 = wolf | doc; s.rb2 = det;             // role class 1 / 2 / 3 / 4 as bit-planes
         s.det_v = w[3] & 0xFF; s.det_w = (w[3] >> 8) & 0xFF; s.phase = (w[3] >> 16) & 0xFF; s.prev = w[3] >> 24;
         s.sel = w[4]; s.choice = w[5];
-        s.end_turn = w[6] & 0xFFFF; s.flags = (w[6] >> 16) & 0xFF;
-        s.games = w[7] & 0xFFFF;
+        s.end_turn = w[6] & 0xFFFF; s.flags = (w[6] >> 16) & 0xFF; s.acted = w[6] >> 24;
+        s.games = w[7] & 0xFFFF; s.deal_cache = w[7] >> 16;
     }
     static GE_HD void pack(const WW<8> &s, uint32_t *w) {
         w[0] = s.alive | (s.can_vote << 8) | (s.revealed << 16) | (s.secret << 24);
         w[1] = s.elig | (s.sub << 8) | (s.team_v << 16) | (s.team_w << 24);
-        w[2] = s.acted | (s.rb0 << 8) | (s.rb1 << 16) | (s.rb2 << 24);
+        const uint32_t n2 = ~s.rb2 & 0xFFu;
+        w[2] = (s.rb0 & ~s.rb1 & n2) | ((~s.rb0 & s.rb1 & n2) << 8) | ((s.rb0 & s.rb1 & n2) << 16) | ((s.rb2 & ~s.rb1 & ~s.rb0 & 0xFFu) << 24);
         w[3] = s.det_v | (s.det_w << 8) | (s.phase << 16) | (s.prev << 24);
         w[4] = s.sel; w[5] = s.choice;
-        w[6] = s.end_turn | (s.flags << 16);
-        w[7] = s.games;
+        w[6] = s.end_turn | (s.flags << 16) | (s.acted << 24);
+        w[7] = (s.games & 0xFFFF) | (s.deal_cache << 16);
     }
 };
 
 template <> struct WWLayout<12> {
     static constexpr int WORDS = 10;
+    static constexpr uint32_t CHECKSUM_MASK7 = 0xFFFFFFFFu;
     // words 0..6: mask(12) | mask(12)<<12 | byte<<24 ; bytes: phase prev flags end_lo end_hi games_lo games_hi
     static GE_HD void unpack(const uint32_t *w, WW<12> &s) {
         s.alive = w[0] & 0xFFF; s.can_vote = (w[0] >> 12) & 0xFFF; s.phase = w[0] >> 24;
@@ -84,6 +97,7 @@ template <> struct WWLayout<12> {
         s.games = (w[5] >> 24) | ((w[6] >> 24) << 8);
         s.sel = (uint64_t)w[7] | ((uint64_t)(w[9] & 0xFFFF) << 32);
         s.choice = (uint64_t)w[8] | ((uint64_t)(w[9] >> 16) << 32);
+        s.deal_cache = 0;                               // all 320 bits of the record are state: no room for a prepared deal
     }
     static GE_HD void pack(const WW<12> &s, uint32_t *w) {
         w[0] = s.alive | (s.can_vote << 12) | (s.phase << 24);
@@ -123,6 +137,25 @@ template <int NB> struct WWR {
     template <int F> GE_HD void clear(uint32_t bits) { W[F / FPW] &= ~(bits << (FB * (F % FPW))); }
     template <int F> GE_HD void put(uint32_t v) { W[F / FPW] = (W[F / FPW] & ~(FM << (FB * (F % FPW)))) | (v << (FB * (F % FPW))); }
 
+    // flat form (the restart template travels as SegDev::init_regs and is read with scalar loads)
+    static constexpr int NREGS = NW + 3 + 2 * (int)(sizeof(nib_t) / 4) + 5;
+    GE_HD void to_regs(uint32_t *r) const {
+        int k = 0;
+        for (int j = 0; j < NW; j++) r[k++] = W[j];
+        r[k++] = acted; r[k++] = det_v; r[k++] = det_w;
+        r[k++] = (uint32_t)sel; if (sizeof(nib_t) > 4) r[k++] = (uint32_t)((uint64_t)sel >> 32);
+        r[k++] = (uint32_t)choice; if (sizeof(nib_t) > 4) r[k++] = (uint32_t)((uint64_t)choice >> 32);
+        r[k++] = phase; r[k++] = prev; r[k++] = flags; r[k++] = end_turn; r[k++] = games;
+    }
+    GE_HD void from_regs(const uint32_t *r) {
+        int k = 0;
+        for (int j = 0; j < NW; j++) W[j] = r[k++];
+        acted = r[k++]; det_v = r[k++]; det_w = r[k++];
+        if (sizeof(nib_t) > 4) { sel = (nib_t)((uint64_t)r[k] | ((uint64_t)r[k + 1] << 32)); k += 2; choice = (nib_t)((uint64_t)r[k] | ((uint64_t)r[k + 1] << 32)); k += 2; }
+        else { sel = (nib_t)r[k++]; choice = (nib_t)r[k++]; }
+        phase = r[k++]; prev = r[k++]; flags = r[k++]; end_turn = r[k++]; games = r[k++];
+    }
+
     GE_HD void from(const WW<NB> &u) {
         for (int k = 0; k < NW; k++) W[k] = 0;
         set<F_ALIVE>(u.alive); set<F_CAN_VOTE>(u.can_vote); set<F_REVEALED>(u.revealed); set<F_SECRET>(u.secret);
@@ -143,6 +176,36 @@ template <int NB> struct WWR {
     }
 };
 
+// record words <-> registers.  N <= 8: the record is the register form; N <= 12: through the 12-bit field layout.
+template <int NB> GE_HD void ww_load_regs(const uint32_t *w, WWR<NB> &s, uint32_t &deal_cache) {
+    if (NB <= 8) {
+        s.W[0] = w[0]; s.W[1] = w[1]; s.W[2] = w[2];
+        s.det_v = w[3] & 0xFF; s.det_w = (w[3] >> 8) & 0xFF; s.phase = (w[3] >> 16) & 0xFF; s.prev = w[3] >> 24;
+        s.sel = (typename WWR<NB>::nib_t)w[4]; s.choice = (typename WWR<NB>::nib_t)w[5];
+        s.end_turn = w[6] & 0xFFFF; s.flags = (w[6] >> 16) & 0xFF; s.acted = w[6] >> 24;
+        s.games = w[7] & 0xFFFF; deal_cache = w[7] >> 16;
+    } else {
+        WW<NB> u;
+        WWLayout<NB>::unpack(w, u);
+        s.from(u);
+        deal_cache = 0;
+    }
+}
+template <int NB> GE_HD void ww_store_regs(const WWR<NB> &s, uint32_t deal_cache, uint32_t *w) {
+    if (NB <= 8) {
+        w[0] = s.W[0]; w[1] = s.W[1]; w[2] = s.W[2];
+        w[3] = s.det_v | (s.det_w << 8) | (s.phase << 16) | (s.prev << 24);
+        w[4] = (uint32_t)s.sel; w[5] = (uint32_t)s.choice;
+        w[6] = s.end_turn | (s.flags << 16) | (s.acted << 24);
+        w[7] = s.games | (deal_cache << 16);
+    } else {
+        WW<NB> u;
+        s.to(u);
+        u.deal_cache = 0;
+        WWLayout<NB>::pack(u, w);
+    }
+}
+
 // ---------------------------------------------------------------- two-truths pack
 // masks 0..4 are the base predicates 0..4 (is_speaker, statements_submitted, lie_revealed,
 // can_vote, has_voted).  lie / vote / choice: 2 bits per player.  score: a byte per player,
@@ -154,6 +217,26 @@ template <int NB> struct TT {
     uint64_t rounds;                                // 4 bits x N
     uint32_t phase, prev, flags, end_turn;
     uint32_t games;
+
+    // flat form of the restart template (SegDev::init_regs)
+    static constexpr int NS = (NB + 3) / 4;
+    static constexpr int NREGS = 9 + NS + 2 + 5;
+    GE_HD void to_regs(uint32_t *r) const {
+        int k = 0;
+        r[k++] = speaker; r[k++] = submitted; r[k++] = revealed; r[k++] = can_vote; r[k++] = has_voted; r[k++] = acted;
+        r[k++] = lie; r[k++] = vote; r[k++] = choice;
+        for (int j = 0; j < NS; j++) r[k++] = score[j];
+        r[k++] = (uint32_t)rounds; r[k++] = (uint32_t)(rounds >> 32);
+        r[k++] = phase; r[k++] = prev; r[k++] = flags; r[k++] = end_turn; r[k++] = games;
+    }
+    GE_HD void from_regs(const uint32_t *r) {
+        int k = 0;
+        speaker = r[k++]; submitted = r[k++]; revealed = r[k++]; can_vote = r[k++]; has_voted = r[k++]; acted = r[k++];
+        lie = r[k++]; vote = r[k++]; choice = r[k++];
+        for (int j = 0; j < NS; j++) score[j] = r[k++];
+        rounds = (uint64_t)r[k] | ((uint64_t)r[k + 1] << 32); k += 2;
+        phase = r[k++]; prev = r[k++]; flags = r[k++]; end_turn = r[k++]; games = r[k++];
+    }
 };
 
 template <int NB> struct TTLayout;

@@ -26,20 +26,6 @@ namespace {
 constexpr uint32_t LDS_ROWS = sizeof(DevRow) * GE_MAX_PHASES;
 constexpr uint32_t LDS_ORD8 = 1024;
 
-// A/B switch for the bot-action step: wave-level work queue in LDS (true) or per-lane loop (false).
-// Measured on MI355X (steady state, K=64): 1 048 576 Werewolf x8 rooms 1.19e11 vs 6.2e10 steps/s,
-// 2 097 152 x12 9.4e10 vs 3.7e10, 65 536 x8 4.4e10 vs 3.6e10 (profiles/r01_queue_ab.txt).
-#ifndef GE_WAVE_QUEUE
-#define GE_WAVE_QUEUE true
-#endif
-
-// the lone-wavefront build could compile the turn once for the turns that prepare role deals and once for those that do
-// not (no per-turn test of the wave-uniform flag): measured 1.281 -> 1.362 us/turn at C2 (profiles/r02_ab_open_tpldeal.txt;
-// the two copies disagree on registers and pay moves at the join, 90 -> 118 VGPRs): off
-#ifndef GE_TPL_DEAL
-#define GE_TPL_DEAL 0
-#endif
-
 enum Kind { K_WW8 = 0, K_WW12, K_TT4, K_TT8, K_TT12, K_COUNT };
 
 struct SegDev {
@@ -52,6 +38,9 @@ struct SegDev {
     uint32_t human_mask, pad0;
     uint64_t local_first;      // index of the segment's room 0 inside the batch
     uint32_t init_words[12];   // the initial record (player_states_template, phase 0)
+    uint32_t init_regs[20];    // the same in the kernels' register form (WWR::to_regs / TT::to_regs): the restart template, read with scalar loads
+    uint32_t term_mask;        // bit r = table row r is terminal (no next_phase branch)
+    uint32_t done0;            // two-truths: tt_done_mask of the initial record
     uint32_t *trace;           // GE_FLAG_TRACE: [turn in launch][rooms_padded] x 4 words, else null
 };
 
@@ -120,11 +109,12 @@ __device__ __forceinline__ void load_rows(DevRow *rows, const DevTable *tables, 
     __syncthreads();
 }
 
-template <int NB, bool LOWOCC, bool GENERIC>
+template <int NB, bool LOWOCC, bool GENERIC, bool SINGLE>
 __device__ __forceinline__ void run_ww(const SegDev *__restrict__ sgp, const StepArgs &a, DevRow *rows, void *lw,
                                        uint8_t *nth8, const DevTable *__restrict__ tables, uint64_t room_in) {
     const SegDev &sg = *sgp;
     using L = WWLayout<NB>;
+    using B = WwBuild<NB, LOWOCC, SINGLE>;
     // lanes past the end of the segment stay in the wavefront (the action queue is a wave-wide
     // collective); they shadow room 0 with no actions and store nothing
     const bool valid = room_in < sg.rooms;
@@ -133,78 +123,86 @@ __device__ __forceinline__ void run_ww(const SegDev *__restrict__ sgp, const Ste
     load_words<L::WORDS>(sg.base, sg.rooms_padded, room, w);      // in flight while the block fills its LDS tables
     // the slot -> player table of the action queue sits right behind the phase rows (step_lds_bytes)
     uint32_t *ord8 = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(rows) + LDS_ROWS);
-    load_rows(rows, tables, sg.table_idx, LOWOCC ? nullptr : nth8, (GE_ORD && NB <= 8) ? ord8 : nullptr);
+    load_rows(rows, tables, sg.table_idx, B::TABLE ? nth8 : nullptr, B::ORD ? ord8 : nullptr);
     WWR<NB> s;
-    {
-        WW<NB> u;
-        L::unpack(w, u);
-        s.from(u);                                            // packed predicates, one-hot roles (ge_layout.h)
-    }
+    uint32_t cache;
+    ww_load_regs<NB>(w, s, cache);                            // N <= 8: the record is the register form (ge_layout.h)
+    const uint32_t ALL = (1u << sg.n_players) - 1u;
     const uint32_t rk = room_key_from(a.seed_key, sg.first_global + room);
-    DevRow row = rows[s.phase];
-    // the fresh room a finished one is recycled into: wave-uniform, kept in scalar registers
-    uint32_t iw[L::WORDS];
+    // the fresh room a finished one is recycled into: wave-uniform, already in register form, kept in scalar registers
+    uint32_t ir[WWR<NB>::NREGS];
 #pragma unroll
-    for (int j = 0; j < L::WORDS; j++) iw[j] = __builtin_amdgcn_readfirstlane(sg.init_words[j]);
+    for (int j = 0; j < WWR<NB>::NREGS; j++) ir[j] = __builtin_amdgcn_readfirstlane(sg.init_regs[j]);
     WWR<NB> s0;
-    {
-        WW<NB> u;
-        L::unpack(iw, u);
-        s0.from(u);
-    }
-    const DevRow row0 = rows[sg.phase0_idx];
+    s0.from_regs(ir);
+    const uint32_t term_mask = __builtin_amdgcn_readfirstlane(sg.term_mask);
     const uint32_t turn0 = a.turn0 + (a.turn_dev ? *a.turn_dev : 0u);   // uniform (scalar load)
     CondShape cs = {0u, 0u, 0u, 0u};
     if (GENERIC) cs = CondShape{(uint32_t)__builtin_amdgcn_readfirstlane(tables[sg.table_idx].cond_shape), (uint32_t)__builtin_amdgcn_readfirstlane(tables[sg.table_idx].cond_slots),
                                (uint32_t)__builtin_amdgcn_readfirstlane(tables[sg.table_idx].cond_fields[0]), (uint32_t)__builtin_amdgcn_readfirstlane(tables[sg.table_idx].cond_fields[1])};
-    // Role deals are keyed by (room, game index), so they can be prepared before the turn that applies
-    // them.  Entering the role-assignment phase is rare per room (once a game) but in a wavefront of 64
-    // rooms some room does it on ~80 % of the turns; instead of running the deal for that one lane, every
-    // GE_DEAL_PERIOD-th turn all lanes without a prepared deal get their next one together (ww_turn, in an
-    // LDS wait shadow; a game is longer than the period).
-    Deal deal = {0u, 0u, 0u, 0u, 0u, 0u};
-    const bool ahead = a.n_turns >= 16u;                      // not worth it for short launches
+    // Role deals are keyed by (room, game index), so they can be prepared before the turn that applies them.  Entering
+    // the role-assignment phase is rare per room (once a game) but in a wavefront of 64 rooms some room does it on ~80 %
+    // of the turns; instead of running the deal for that one lane, every GE_DEAL_PERIOD-th turn all lanes without a
+    // prepared deal get their next one together (ww_turn, in an LDS wait shadow; a game is longer than the period).
+    // N <= 8: the record carries a prepared deal across launches, so this works for any number of turns per launch
+    // (the period then counts absolute turns); Werewolf x 12 records have no spare bits - only launches of >= 16 turns
+    // deal ahead there.
+    Deal deal;
+    deal_from_cache<NB, B::DEAL_FORM>(cache, s, ALL, deal);
+    const bool ahead = NB <= 8 || a.n_turns >= 16u;
+    const uint32_t deal_phase = NB <= 8 ? turn0 : 0u;
     uint32_t tk = turn_key(rk, turn0);                        // this turn's key; ww_turn leaves the next turn's (computed in an LDS wait shadow)
     Stamps stamps;
     if (GE_STAMPS) stamps.start();
-    // the turn loop, compiled once per trace setting: the event-trace branches (two per turn, both wave-uniform and
-    // almost always taken) cost a lone wavefront an instruction-fetch bubble each
-    auto turns = [&](auto trace_c) {
-        constexpr bool KNOWN = decltype(trace_c)::value != 2;
-        const bool trace = KNOWN ? decltype(trace_c)::value == 1 : a.trace != 0u;
-#if GE_UNROLL2
-#pragma unroll 2
-#endif
-        for (uint32_t t = 0; t < a.n_turns; t++) {
-            uint32_t restarted = 0;
-            if (a.restart && ((row.r0 >> 11) & 7u) == 0u) {      // recycle a finished room
-                const uint32_t g = s.games;
-                s = s0;
-                s.games = g < 0xFFFFu ? g + 1u : g;
-                row = row0;
-                restarted = 1;
-            }
-            const uint32_t p = s.phase;
-            uint32_t ev_newly = 0;
-            uint64_t ev_choice = 0;
-            const bool deal_now = ahead && (t & (GE_DEAL_PERIOD - 1u)) == 0u;        // wave-uniform
-            Stamps *const stp = (GE_STAMPS && a.stamps) ? &stamps : nullptr;
-            if (LOWOCC && GE_TPL_DEAL) {                                              // two copies of the turn, a scalar branch between them
-                if (deal_now) ww_turn<NB, GE_WAVE_QUEUE, LOWOCC, GENERIC, 1>(s, row, rows, tables[sg.table_idx].conds, cs, lw, nth8, ord8, valid, sg.n_players, sg.nw, sg.phase0_idx, rk, turn0 + t, tk,
-                                                                              trace, sg.human_mask, deal, true, ev_newly, ev_choice, stp);
-                else ww_turn<NB, GE_WAVE_QUEUE, LOWOCC, GENERIC, 0>(s, row, rows, tables[sg.table_idx].conds, cs, lw, nth8, ord8, valid, sg.n_players, sg.nw, sg.phase0_idx, rk, turn0 + t, tk,
-                                                                    trace, sg.human_mask, deal, false, ev_newly, ev_choice, stp);
-            } else {
-                ww_turn<NB, GE_WAVE_QUEUE, LOWOCC, GENERIC, 2>(s, row, rows, tables[sg.table_idx].conds, cs, lw, nth8, ord8, valid, sg.n_players, sg.nw, sg.phase0_idx, rk, turn0 + t, tk,
-                                                               trace, sg.human_mask, deal, deal_now, ev_newly, ev_choice, stp);
-            }
-            if (trace && valid) store_event(sg.trace, sg.rooms_padded, t, room, turn0 + t, p, s.phase, restarted, ev_newly, ev_choice);
+    const WwCtx ctx = {rows, tables[sg.table_idx].conds, cs, lw, nth8, ord8, valid, sg.n_players, sg.nw, sg.phase0_idx, rk, sg.human_mask, term_mask};
+    if constexpr (SINGLE) {
+        // one turn, no loop: the row is fetched after the restart decision (terminal rows are a bit mask), nothing is
+        // prepared for a next turn
+        uint32_t restarted = 0;
+        if (a.restart && ((term_mask >> s.phase) & 1u)) {        // recycle a finished room
+            const uint32_t g = s.games;
+            s = s0;
+            s.games = g < 0xFFFFu ? g + 1u : g;
+            restarted = 1;
         }
-    };
-    if (GE_TPL_TRACE && LOWOCC) {                             // (two copies of the loop cost the large-batch build registers)
-        if (a.trace) turns(std::integral_constant<int, 1>{}); else turns(std::integral_constant<int, 0>{});
+        DevRow row = rows[s.phase];
+        const uint32_t p = s.phase;
+        uint32_t ev_newly = 0;
+        uint64_t ev_choice = 0;
+        const bool trace = a.trace != 0u;
+        const bool deal_now = NB <= 8 && (turn0 & (GE_DEAL_PERIOD - 1u)) == 0u;       // wave-uniform
+        ww_turn<NB, LOWOCC, GENERIC, true>(s, row, ctx, turn0, tk, trace, deal, deal_now, ev_newly, ev_choice, nullptr);
+        if (trace && valid) store_event(sg.trace, sg.rooms_padded, 0u, room, turn0, p, s.phase, restarted, ev_newly, ev_choice);
     } else {
-        turns(std::integral_constant<int, 2>{});
+        DevRow row = rows[s.phase];
+        const DevRow row0 = rows[sg.phase0_idx];
+        // the turn loop; the lone-wavefront build compiles it once per trace setting: the event-trace branches (two per turn,
+        // both wave-uniform and almost always taken) cost a lone wavefront an instruction-fetch bubble each
+        auto turns = [&](auto trace_c) {
+            constexpr bool KNOWN = decltype(trace_c)::value != 2;
+            const bool trace = KNOWN ? decltype(trace_c)::value == 1 : a.trace != 0u;
+            for (uint32_t t = 0; t < a.n_turns; t++) {
+                uint32_t restarted = 0;
+                if (a.restart && ((row.r0 >> 11) & 7u) == 0u) {      // recycle a finished room
+                    const uint32_t g = s.games;
+                    s = s0;
+                    s.games = g < 0xFFFFu ? g + 1u : g;
+                    row = row0;
+                    restarted = 1;
+                }
+                const uint32_t p = s.phase;
+                uint32_t ev_newly = 0;
+                uint64_t ev_choice = 0;
+                const bool deal_now = ahead && ((deal_phase + t) & (GE_DEAL_PERIOD - 1u)) == 0u;        // wave-uniform
+                ww_turn<NB, LOWOCC, GENERIC, false>(s, row, ctx, turn0 + t, tk, trace, deal, deal_now, ev_newly, ev_choice, (GE_STAMPS && a.stamps) ? &stamps : nullptr);
+                if (trace && valid) store_event(sg.trace, sg.rooms_padded, t, room, turn0 + t, p, s.phase, restarted, ev_newly, ev_choice);
+            }
+        };
+        if (B::TPL_TRACE) {                                       // (two copies of the loop cost the large-batch build registers)
+            if (a.trace) turns(std::integral_constant<int, 1>{}); else turns(std::integral_constant<int, 0>{});
+        } else {
+            turns(std::integral_constant<int, 2>{});
+        }
     }
     if (GE_STAMPS && a.stamps && (threadIdx.x & 63u) == 0u) {
         stamps.mark(3);
@@ -212,9 +210,7 @@ __device__ __forceinline__ void run_ww(const SegDev *__restrict__ sgp, const Ste
         atomicAdd(a.stamps + 4, (unsigned long long)a.n_turns);
     }
     if (!valid) return;
-    WW<NB> u;
-    s.to(u);
-    L::pack(u, w);
+    ww_store_regs<NB>(s, deal_to_cache<NB, B::DEAL_FORM>(deal, s), w);
     store_words<L::WORDS>(sg.base, sg.rooms_padded, room, w);
 }
 
@@ -226,7 +222,7 @@ __device__ __forceinline__ void run_ww(const SegDev *__restrict__ sgp, const Ste
 #endif
 constexpr bool tt_uses_queue(int nb, bool lowocc) { return !lowocc || nb >= GE_TT_LOW_QUEUE_MIN; }
 
-template <int NB, bool LOWOCC, bool GENERIC>
+template <int NB, bool LOWOCC, bool GENERIC, bool SINGLE>
 __device__ __forceinline__ void run_tt(const SegDev *__restrict__ sgp, const StepArgs &a, DevRow *rows, void *lw, uint8_t *nth8,
                                        const DevTable *__restrict__ tables, uint64_t room_in) {
     constexpr bool QUEUE = tt_uses_queue(NB, LOWOCC);
@@ -240,34 +236,53 @@ __device__ __forceinline__ void run_tt(const SegDev *__restrict__ sgp, const Ste
     TT<NB> s;
     L::unpack(w, s);
     const uint32_t rk = room_key_from(a.seed_key, sg.first_global + room);
-    DevRow row = rows[s.phase];
-    uint32_t iw[L::WORDS];
+    // the restart template, already unpacked (scalar loads)
+    uint32_t ir[TT<NB>::NREGS];
 #pragma unroll
-    for (int j = 0; j < L::WORDS; j++) iw[j] = __builtin_amdgcn_readfirstlane(sg.init_words[j]);
+    for (int j = 0; j < TT<NB>::NREGS; j++) ir[j] = __builtin_amdgcn_readfirstlane(sg.init_regs[j]);
     TT<NB> s0;
-    L::unpack(iw, s0);
-    const DevRow row0 = rows[sg.phase0_idx];
+    s0.from_regs(ir);
+    const uint32_t done0 = __builtin_amdgcn_readfirstlane(sg.done0);
+    const uint32_t term_mask = __builtin_amdgcn_readfirstlane(sg.term_mask);
     const uint32_t turn0 = a.turn0 + (a.turn_dev ? *a.turn_dev : 0u);
     CondShape cs = {0u, 0u, 0u, 0u};
     if (GENERIC) cs = CondShape{(uint32_t)__builtin_amdgcn_readfirstlane(tables[sg.table_idx].cond_shape), (uint32_t)__builtin_amdgcn_readfirstlane(tables[sg.table_idx].cond_slots),
                                (uint32_t)__builtin_amdgcn_readfirstlane(tables[sg.table_idx].cond_fields[0]), (uint32_t)__builtin_amdgcn_readfirstlane(tables[sg.table_idx].cond_fields[1])};
     uint32_t done = tt_done_mask<NB>(s.rounds, sg.rounds);   // who has spoken all agreed rounds (ge_device.h)
-    const uint32_t done0 = tt_done_mask<NB>(s0.rounds, sg.rounds);
-    for (uint32_t t = 0; t < a.n_turns; t++) {
+    if constexpr (SINGLE) {
         uint32_t restarted = 0;
-        if (a.restart && ((row.r0 >> 11) & 7u) == 0u) {
+        if (a.restart && ((term_mask >> s.phase) & 1u)) {
             const uint32_t g = s.games;
             s = s0;
             s.games = g < 0xFFFFu ? g + 1u : g;
-            row = row0;
             done = done0;
             restarted = 1;
         }
+        DevRow row = rows[s.phase];
         const uint32_t p = s.phase;
         uint32_t ev_newly = 0;
         uint64_t ev_choice = 0;
-        tt_turn<NB, QUEUE, !LOWOCC, GENERIC>(s, done, row, rows, tables[sg.table_idx].conds, cs, lw, nth8, valid, sg.n_players, sg.rounds, sg.phase0_idx, rk, turn0 + t, a.trace != 0u, sg.human_mask, ev_newly, ev_choice);
-        if (a.trace && valid) store_event(sg.trace, sg.rooms_padded, t, room, turn0 + t, p, s.phase, restarted, ev_newly, ev_choice);
+        tt_turn<NB, QUEUE, !LOWOCC, GENERIC, true>(s, done, row, rows, tables[sg.table_idx].conds, cs, lw, nth8, valid, sg.n_players, sg.rounds, sg.phase0_idx, rk, turn0, a.trace != 0u, sg.human_mask, term_mask, ev_newly, ev_choice);
+        if (a.trace && valid) store_event(sg.trace, sg.rooms_padded, 0u, room, turn0, p, s.phase, restarted, ev_newly, ev_choice);
+    } else {
+        DevRow row = rows[s.phase];
+        const DevRow row0 = rows[sg.phase0_idx];
+        for (uint32_t t = 0; t < a.n_turns; t++) {
+            uint32_t restarted = 0;
+            if (a.restart && ((row.r0 >> 11) & 7u) == 0u) {
+                const uint32_t g = s.games;
+                s = s0;
+                s.games = g < 0xFFFFu ? g + 1u : g;
+                row = row0;
+                done = done0;
+                restarted = 1;
+            }
+            const uint32_t p = s.phase;
+            uint32_t ev_newly = 0;
+            uint64_t ev_choice = 0;
+            tt_turn<NB, QUEUE, !LOWOCC, GENERIC, false>(s, done, row, rows, tables[sg.table_idx].conds, cs, lw, nth8, valid, sg.n_players, sg.rounds, sg.phase0_idx, rk, turn0 + t, a.trace != 0u, sg.human_mask, term_mask, ev_newly, ev_choice);
+            if (a.trace && valid) store_event(sg.trace, sg.rooms_padded, t, room, turn0 + t, p, s.phase, restarted, ev_newly, ev_choice);
+        }
     }
     if (!valid) return;
     L::pack(s, w);
@@ -279,14 +294,14 @@ __device__ __forceinline__ void run_tt(const SegDev *__restrict__ sgp, const Ste
 // Two-Truths batch diverges per block, never inside a wavefront.  Segment descriptors live in
 // device memory and are read with a block-uniform index (scalar loads): indexing the kernel
 // arguments dynamically would push them through scratch.
-template <int KIND, bool LOWOCC, bool GENERIC>
+template <int KIND, bool LOWOCC, bool GENERIC, bool SINGLE = false>
 __device__ __forceinline__ void run_kind(const SegDev *__restrict__ sg, const StepArgs &a, DevRow *rows, void *lw,
                                          uint8_t *nth8, const DevTable *__restrict__ tables, uint64_t room) {
-    if (KIND == K_WW8) run_ww<8, LOWOCC, GENERIC>(sg, a, rows, lw, nth8, tables, room);
-    else if (KIND == K_WW12) run_ww<12, LOWOCC, GENERIC>(sg, a, rows, lw, nth8, tables, room);
-    else if (KIND == K_TT4) run_tt<4, LOWOCC, GENERIC>(sg, a, rows, lw, nth8, tables, room);
-    else if (KIND == K_TT8) run_tt<8, LOWOCC, GENERIC>(sg, a, rows, lw, nth8, tables, room);
-    else run_tt<12, LOWOCC, GENERIC>(sg, a, rows, lw, nth8, tables, room);
+    if (KIND == K_WW8) run_ww<8, LOWOCC, GENERIC, SINGLE>(sg, a, rows, lw, nth8, tables, room);
+    else if (KIND == K_WW12) run_ww<12, LOWOCC, GENERIC, SINGLE>(sg, a, rows, lw, nth8, tables, room);
+    else if (KIND == K_TT4) run_tt<4, LOWOCC, GENERIC, SINGLE>(sg, a, rows, lw, nth8, tables, room);
+    else if (KIND == K_TT8) run_tt<8, LOWOCC, GENERIC, SINGLE>(sg, a, rows, lw, nth8, tables, room);
+    else run_tt<12, LOWOCC, GENERIC, SINGLE>(sg, a, rows, lw, nth8, tables, room);
 }
 
 // LDS of a step block is sized at launch (a 64-room block must not pay for four wavefronts' queues, or
@@ -312,7 +327,8 @@ extern __shared__ __align__(16) unsigned char ge_lds[];
 #ifndef GE_WW8_WAVES
 #define GE_WW8_WAVES 1
 #endif
-template <int KIND, bool LOWOCC, bool GENERIC = false>
+// SINGLE: the launch is one turn (a.n_turns == 1) of a single-game batch with shipped-grammar conditions (run_ww / run_tt)
+template <int KIND, bool LOWOCC, bool GENERIC = false, bool SINGLE = false>
 __global__ void __launch_bounds__(256, (KIND == K_WW12 && !LOWOCC && !GENERIC) ? GE_WW12_WAVES : (KIND == K_WW8 && !LOWOCC && !GENERIC) ? GE_WW8_WAVES : 1) ge_step_kernel(const StepArgs a, const SegDev *__restrict__ segs,
                                                       const DevTable *__restrict__ tables) {
     constexpr bool WWK = KIND == K_WW8 || KIND == K_WW12 || tt_uses_queue(KIND == K_TT4 ? 4 : KIND == K_TT8 ? 8 : 12, LOWOCC);   // uses the action queue
@@ -320,7 +336,7 @@ __global__ void __launch_bounds__(256, (KIND == K_WW12 && !LOWOCC && !GENERIC) ?
     uint8_t *nth8 = ge_lds + LDS_ROWS + LDS_ORD8;
     auto *wl = reinterpret_cast<typename WaveLdsOf<LOWOCC>::type *>(ge_lds + LDS_ROWS + LDS_ORD8 + (LOWOCC ? 0u : LDS_NTH8));
     const uint64_t room = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    run_kind<KIND, LOWOCC, GENERIC>(segs, a, rows, WWK ? &wl[threadIdx.x >> 6] : nullptr, nth8, tables, room);
+    run_kind<KIND, LOWOCC, GENERIC, SINGLE>(segs, a, rows, WWK ? &wl[threadIdx.x >> 6] : nullptr, nth8, tables, room);
 }
 
 // mixed batch: several segments (games / player counts) in one launch
@@ -413,7 +429,7 @@ __global__ void __launch_bounds__(256) ge_summary_kernel(const StepArgs a, const
         uint32_t h = h0;
         RoomStats q;
         switch (sg.kind) {
-        case K_WW8: { uint32_t w[8]; load_words<8>(sg.base, sg.rooms_padded, room, w); q = stats_ww<8>(w, rows, h_score); h = fold_words<8>(h0, w); break; }
+        case K_WW8: { uint32_t w[8]; load_words<8>(sg.base, sg.rooms_padded, room, w); q = stats_ww<8>(w, rows, h_score); w[7] &= WWLayout<8>::CHECKSUM_MASK7; h = fold_words<8>(h0, w); break; }   // (the prepared-deal cache is not state)
         case K_WW12: { uint32_t w[10]; load_words<10>(sg.base, sg.rooms_padded, room, w); q = stats_ww<12>(w, rows, h_score); h = fold_words<10>(h0, w); break; }
         case K_TT4: { uint32_t w[6]; load_words<6>(sg.base, sg.rooms_padded, room, w); q = stats_tt<4>(w, rows, sg.n_players, h_score); h = fold_words<6>(h0, w); break; }
         case K_TT8: { uint32_t w[8]; load_words<8>(sg.base, sg.rooms_padded, room, w); q = stats_tt<8>(w, rows, sg.n_players, h_score); h = fold_words<8>(h0, w); break; }
@@ -724,6 +740,17 @@ DevCond to_dev_cond(const ge_phase_row &r, bool ww8 = false) {
     return c;
 }
 
+// the initial record in the kernels' register form (SegDev::init_regs)
+void init_regs_of(uint32_t kind, const uint32_t *w, uint32_t *regs) {
+    switch (kind) {
+    case K_WW8: { WWR<8> s; uint32_t c; ww_load_regs<8>(w, s, c); s.to_regs(regs); break; }
+    case K_WW12: { WWR<12> s; uint32_t c; ww_load_regs<12>(w, s, c); s.to_regs(regs); break; }
+    case K_TT4: { TT<4> s; TTLayout<4>::unpack(w, s); s.to_regs(regs); break; }
+    case K_TT8: { TT<8> s; TTLayout<8>::unpack(w, s); s.to_regs(regs); break; }
+    default: { TT<12> s; TTLayout<12>::unpack(w, s); s.to_regs(regs); break; }
+    }
+}
+
 int words_of(uint32_t kind) {
     switch (kind) {
     case K_WW8: return 8; case K_WW12: return 10; case K_TT4: return 6; case K_TT8: return 8; default: return 12;
@@ -950,13 +977,16 @@ const char *ge_strerror(int status) {
     case GE_ERR_NOMEM: return "out of memory";
     case GE_ERR_RANGE: return "out of range";
     case GE_ERR_UNSUPPORTED: return "unsupported";
+    case GE_ERR_COMM: return "collective library (RCCL) error";
     default: return "unknown status";
     }
 }
 
 }  // extern "C"
 
-static int create_impl(const ge_batch_desc *desc, ge_batch **out) {
+// seg_first (may be null): global index of each segment's room 0.  Null = the segments follow each other from
+// desc->first_room on; a device group (ge_group.inl) passes the indices its shard has in the whole job.
+static int create_impl(const ge_batch_desc *desc, ge_batch **out, const uint64_t *seg_first = nullptr) {
     if (!desc || !out || desc->n_segments == 0 || desc->n_segments > GE_MAX_SEGMENTS) return GE_ERR_ARG;
     *out = nullptr;
     if (ge_device_count() <= 0) return GE_ERR_NO_DEVICE;
@@ -997,7 +1027,7 @@ static int create_impl(const ge_batch_desc *desc, ge_batch **out) {
         d.words = (uint32_t)words_of(d.kind);
         d.rooms = sd.n_rooms;
         d.rooms_padded = (sd.n_rooms + 255u) & ~uint64_t(255);
-        d.first_global = global;
+        d.first_global = seg_first ? seg_first[k] : global;
         d.local_first = local;
         d.n_players = n; d.nw = n / 4 > 1 ? n / 4 : 1; d.rounds = (uint32_t)s.table.rounds;
         d.human_mask = sd.human_mask & ((1u << n) - 1u);
@@ -1074,6 +1104,13 @@ static int create_impl(const ge_batch_desc *desc, ge_batch **out) {
                 uint32_t w[12] = {0};
                 view_to_words(s.dev.kind, v, s.table, w);
                 memcpy(s.dev.init_words, w, sizeof w);
+                init_regs_of(s.dev.kind, w, s.dev.init_regs);
+                s.dev.done0 = 0;                                          // tt_done_mask of the initial record: rounds_as_speaker >= agreed rounds
+                if (s.table.pack == GE_PACK_TWO_TRUTHS)
+                    for (uint32_t i = 0; i < s.dev.n_players; i++)
+                        if ((int)(v.players[i][8] & 15) >= s.table.rounds) s.dev.done0 |= 1u << i;
+                for (int r = 0; r < s.table.n_phases; r++)
+                    if (s.table.rows[r].n_branches == 0) s.dev.term_mask |= 1u << r;
             }
             if (hipMemcpy(b->tables, host_tables.data(), sizeof(DevTable) * host_tables.size(), hipMemcpyHostToDevice) != hipSuccess) { st = GE_ERR_HIP; break; }
             SegDev host[GE_MAX_SEGMENTS];
@@ -1131,6 +1168,15 @@ static hipError_t launch_step(const ge_batch *b, const StepArgs &a, hipStream_t 
         }
     } else if (b->segs.size() > 1) {
         if (low) GE_LAUNCH(ge_step_kernel_mixed<true>, true, true); else GE_LAUNCH(ge_step_kernel_mixed<false>, true, false);
+    } else if (a.n_turns == 1u) {
+        // one turn per launch (max_fuse = 1, or the tail of a step): the single-turn builds
+        switch (b->segs[0].dev.kind) {
+        case K_WW8: if (low) GE_LAUNCH((ge_step_kernel<K_WW8, true, false, true>), true, true); else GE_LAUNCH((ge_step_kernel<K_WW8, false, false, true>), true, false); break;
+        case K_WW12: if (low) GE_LAUNCH((ge_step_kernel<K_WW12, true, false, true>), true, true); else GE_LAUNCH((ge_step_kernel<K_WW12, false, false, true>), true, false); break;
+        case K_TT4: if (low) GE_LAUNCH((ge_step_kernel<K_TT4, true, false, true>), tt_uses_queue(4, true), true); else GE_LAUNCH((ge_step_kernel<K_TT4, false, false, true>), true, false); break;
+        case K_TT8: if (low) GE_LAUNCH((ge_step_kernel<K_TT8, true, false, true>), tt_uses_queue(8, true), true); else GE_LAUNCH((ge_step_kernel<K_TT8, false, false, true>), true, false); break;
+        default: if (low) GE_LAUNCH((ge_step_kernel<K_TT12, true, false, true>), tt_uses_queue(12, true), true); else GE_LAUNCH((ge_step_kernel<K_TT12, false, false, true>), true, false); break;
+        }
     } else {
         switch (b->segs[0].dev.kind) {
         case K_WW8: if (low) GE_LAUNCH((ge_step_kernel<K_WW8, true>), true, true); else GE_LAUNCH((ge_step_kernel<K_WW8, false>), true, false); break;
@@ -1541,3 +1587,5 @@ void ge_batch_destroy(ge_batch *b) {
 }
 
 }  // extern "C"
+
+#include "ge_group.inl"

@@ -345,8 +345,16 @@ napi_value InjectActions(napi_env env, napi_callback_info info) {
     void *st_data = nullptr;
     napi_value st_buf, st_arr;
     NAPI_OK(napi_create_arraybuffer(env, len[0] * sizeof(int32_t), &st_data, &st_buf));
-    ge_batch_inject_actions(b, len[0], static_cast<const uint64_t *>(data[0]), static_cast<const uint32_t *>(data[1]),
-                            static_cast<const uint32_t *>(data[2]), static_cast<int32_t *>(st_data));
+    memset(st_data, 0, len[0] * sizeof(int32_t));
+    const int st = ge_batch_inject_actions(b, len[0], static_cast<const uint64_t *>(data[0]), static_cast<const uint32_t *>(data[1]),
+                                           static_cast<const uint32_t *>(data[2]), static_cast<int32_t *>(st_data));
+    if (st != GE_OK) {
+        // the return value is the first refused action's status - or a failure of the call itself (allocation, HIP error,
+        // too many actions), which leaves the status array untouched: that one must not read as "all applied"
+        bool any = false;
+        for (size_t k = 0; k < len[0] && !any; k++) any = static_cast<const int32_t *>(st_data)[k] != 0;
+        if (!any) return throw_status(env, st, "injectActions");
+    }
     NAPI_OK(napi_create_typedarray(env, napi_int32_array, len[0], st_buf, 0, &st_arr));
     return st_arr;
 }

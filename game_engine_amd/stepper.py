@@ -241,8 +241,12 @@ class RoomBatch:
         if not (len(rooms) == len(player_ids) == len(choices)):
             raise GeError(-1, "inject_actions: arrays differ in length")
         status = np.zeros(len(rooms), dtype=np.int32)
-        self._lib.ge_batch_inject_actions(self._h, len(rooms), rooms.ctypes.data, player_ids.ctypes.data,
-                                          choices.ctypes.data, status.ctypes.data)
+        st = self._lib.ge_batch_inject_actions(self._h, len(rooms), rooms.ctypes.data, player_ids.ctypes.data,
+                                               choices.ctypes.data, status.ctypes.data)
+        # the return value is the first refused action's status - or a failure of the call itself (closed handle,
+        # allocation, HIP error), which leaves the status array untouched: that one must not read as "all applied"
+        if st != 0 and not status.any():
+            _check(st, "ge_batch_inject_actions")
         return status
 
     def read_events(self, first: int = 0, count: Optional[int] = None) -> np.ndarray:
@@ -314,6 +318,84 @@ class RoomBatch:
         frontend's useCoAgent sync receives (src/lib/canvas/types.ts:338-360)."""
         tb, _ = self._segment_of(room)
         return view_to_agent_state(tb, self.read_rooms(room, 1)[0])
+
+
+class RoomGroup:
+    """One host process, several GPUs: the rooms of `segments` (the WHOLE job) sharded over `devices`, stepped
+    concurrently, with one RCCL all-gather of the per-device summaries inside the native library (ge_group_*,
+    include/ge_step.h).  Results equal those of one RoomBatch with the same arguments, for any number of devices.
+    (The multi-process form, one rank per GPU over torch.distributed, is game_engine_amd.dist.)"""
+
+    def __init__(self, segments: Sequence[Segment], devices: Sequence[int], seed: int = 0, first_room: int = 0,
+                 max_fuse: int = 0, restart: bool = False, trace: bool = False):
+        lib = _lib.load()
+        if not 1 <= len(segments) <= _lib.GE_MAX_SEGMENTS:
+            raise GeError(-1, "segments")
+        self.segments = list(segments)
+        d = _lib.BatchDesc()
+        d.seed, d.first_room, d.n_segments, d.device, d.max_fuse = seed, first_room, len(segments), 0, max_fuse
+        d.flags = (1 if restart else 0) | (2 if trace else 0)
+        for k, seg in enumerate(segments):
+            tb, n_players, n_rooms = seg[:3]
+            d.seg[k].table = C.pointer(tb.c)
+            d.seg[k].n_players, d.seg[k].n_rooms = n_players, n_rooms
+            d.seg[k].human_mask = seg[3] if len(seg) > 3 else 0
+        devs = (C.c_int * len(devices))(*devices)
+        h = C.c_void_p()
+        _check(lib.ge_group_create(C.byref(d), devs, len(devices), C.byref(h)), "ge_group_create")
+        self._h, self._lib = h, lib
+        self.n_devices = len(devices)
+        self.n_rooms = sum(s[2] for s in segments)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.ge_group_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def step(self, n_turns: int = 1):
+        _check(self._lib.ge_group_step(self._h, n_turns), "ge_group_step")
+
+    def sync(self):
+        _check(self._lib.ge_group_sync(self._h), "ge_group_sync")
+
+    def summary(self) -> Dict[str, Any]:
+        s = _lib.Summary()
+        _check(self._lib.ge_group_summary(self._h, C.byref(s)), "ge_group_summary")
+        return summary_to_dict(np.frombuffer(bytes(s), dtype="<u8"))
+
+    def shard_summaries(self) -> List[Dict[str, Any]]:
+        """Each device's own ge_batch_summary (host-side cross-check of the collective: they add up to summary())."""
+        out = []
+        for i in range(self.n_devices):
+            b, s = C.c_void_p(), _lib.Summary()
+            _check(self._lib.ge_group_shard(self._h, i, C.byref(b)), "ge_group_shard")
+            _check(self._lib.ge_batch_summary(b, C.byref(s)), "ge_batch_summary")
+            out.append(summary_to_dict(np.frombuffer(bytes(s), dtype="<u8")))
+        return out
+
+    def read_rooms(self) -> np.ndarray:
+        """All rooms in the order of one RoomBatch with the same segments (segment-major)."""
+        per_seg: List[List[np.ndarray]] = [[] for _ in self.segments]
+        for i in range(self.n_devices):
+            b = C.c_void_p()
+            _check(self._lib.ge_group_shard(self._h, i, C.byref(b)), "ge_group_shard")
+            first = 0
+            for k, seg in enumerate(self.segments):
+                R = seg[2]
+                cnt = R * (i + 1) // self.n_devices - R * i // self.n_devices
+                out = np.zeros(cnt, dtype=ROOM_VIEW_DTYPE)
+                _check(self._lib.ge_batch_read_rooms(b, first, cnt, out.ctypes.data, out.nbytes), "ge_batch_read_rooms")
+                per_seg[k].append(out)
+                first += cnt
+        return np.concatenate([x for seg in per_seg for x in seg])
 
 
 def summary_to_dict(w: np.ndarray) -> Dict[str, Any]:

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GE_ABI_VERSION 3
+#define GE_ABI_VERSION 4
 #define GE_MAX_PHASES 32
 #define GE_MAX_PLAYERS 12
 #define GE_MAX_SEGMENTS 4
@@ -49,7 +49,8 @@ typedef enum ge_status {
     GE_ERR_HIP = -4,        /* a HIP runtime call failed (ge_last_hip_error) */
     GE_ERR_NOMEM = -5,
     GE_ERR_RANGE = -6,      /* room range outside the batch / turn counter would overflow */
-    GE_ERR_UNSUPPORTED = -7 /* valid DSL feature the kernels do not implement yet */
+    GE_ERR_UNSUPPORTED = -7,/* valid DSL feature the kernels do not implement yet; no RCCL to load for a device group */
+    GE_ERR_COMM = -9        /* an RCCL call failed (ge_last_comm_error); -8 is the N-API host's GE_BUSY */
 } ge_status;
 
 /* rule packs: which declared player_states schema the game uses
@@ -298,6 +299,29 @@ int ge_batch_set_timing(ge_batch *b, int on);     /* off by default: no events a
 int ge_batch_kernel_time(ge_batch *b, int reset, double *total_ms, uint64_t *launches);
 
 void ge_batch_destroy(ge_batch *b);
+
+/* ---- device group: ONE host process, N GPUs of a node (SURVEY.md 8(e) process model; what a Node addon needs).
+ * Rooms never interact - the reference runs one LangGraph thread per room (src/app/api/copilotkit/route.ts:24-37) and has
+ * no collective at all (agent/requirements.txt:1-11) - so the group shards rooms and steps the devices concurrently with no
+ * exchange; the single collective of the whole job is ONE ncclAllGather (RCCL over xGMI) of the per-device ge_summary.
+ *
+ * `desc` describes the WHOLE job (desc->device is ignored): device i of n gets the i-th of n contiguous parts of every
+ * segment, and every room keeps the global index it has in a single batch of the same desc - results are identical to
+ * that batch's, whatever n is.  `devices` are distinct HIP ordinals (duplicates: GE_ERR_ARG); every segment needs at
+ * least n rooms.  The group owns one stream per device.  RCCL is loaded at run time (librccl.so.1) when the first group
+ * is created - GE_ERR_UNSUPPORTED if there is none; hosts that never create a group never load it.
+ * Not thread-safe, like a ge_batch.  The multi-PROCESS form (one rank per GPU, torch.distributed) is game_engine_amd/dist.py. */
+typedef struct ge_group ge_group;
+int ge_group_create(const ge_batch_desc *desc, const int *devices, int n_devices, ge_group **out);
+int ge_group_size(const ge_group *g);                           /* number of devices, or GE_ERR_ARG */
+int ge_group_shard(ge_group *g, int i, ge_batch **out);         /* borrow device i's batch (read_rooms, inject, events ...); owned by the group */
+int ge_group_step(ge_group *g, uint32_t n_turns);               /* every shard, asynchronous, each on its device's stream */
+int ge_group_sync(ge_group *g);
+/* Per-device reductions, one ncclAllGather of the n ge_summary records on the devices' streams, then the sum (every
+ * field is a sum over rooms; `turn` is common).  Synchronises. */
+int ge_group_summary(ge_group *g, ge_summary *out);
+void ge_group_destroy(ge_group *g);
+int ge_last_comm_error(void);             /* ncclResult_t of the last GE_ERR_COMM on this thread */
 
 const char *ge_strerror(int status);
 int ge_last_hip_error(void);              /* hipError_t of the last GE_ERR_HIP on this thread */

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     assert set(names) == set(_lib.SYMBOLS)
     for n in names:
         assert getattr(lib, n) is not None
-    assert lib.ge_abi_version() == _lib.GE_ABI_VERSION == 3
+    assert lib.ge_abi_version() == _lib.GE_ABI_VERSION == 4
 
 
 def test_struct_sizes_match_header():
@@ -51,6 +51,34 @@ def test_no_cpu_fallback(dsl_ww):
     with pytest.raises(GeError) as e:
         RoomBatch([(GameTable(dsl_ww), 8, 16)])
     assert e.value.status == -3
+
+
+def test_device_group_refuses_without_gpu_and_bad_arguments(dsl_ww):
+    """ge_group_* (single process, N devices, RCCL all-gather inside the library): argument errors, and no CPU path."""
+    from game_engine_amd import RoomGroup
+    lib = _lib.load()
+    assert lib.ge_group_create(None, None, 0, None) == -1
+    assert lib.ge_group_size(None) == -1 and lib.ge_group_step(None, 1) == -1 and lib.ge_group_summary(None, None) == -1
+    assert b"RCCL" in lib.ge_strerror(-9)
+    tb = GameTable(dsl_ww)
+    if lib.ge_device_count() > 0:
+        pytest.skip("a GPU is present: covered by tests/test_gpu_group.py")
+    with pytest.raises(GeError) as e:
+        RoomGroup([(tb, 8, 64)], devices=[0])
+    assert e.value.status == -3                          # GE_ERR_NO_DEVICE: no CPU fallback here either
+
+
+def test_inject_actions_on_a_dead_handle_raises():
+    """A failure of ge_batch_inject_actions itself (here: no batch behind the handle) leaves the per-action status array
+    untouched; the host must raise, not report every action as applied (0 = applied)."""
+    import numpy as np
+    b = RoomBatch.__new__(RoomBatch)                 # a host object whose batch is gone (as after close())
+    b._lib, b._h = _lib.load(), None
+    with pytest.raises(GeError) as e:
+        b.inject_actions([0, 1], [1, 1], [2, 2])
+    assert e.value.status == -1
+    with pytest.raises(GeError):
+        b.inject_actions(np.zeros(0, np.uint64), [], [])       # even an empty call fails on a dead handle
 
 
 def test_product_does_not_import_the_oracle():
