@@ -19,11 +19,20 @@ reference) in registers, and stored once.  `value` counts room-phase steps (room
     value = rooms x ranks x turns_fused_per_launch x K / time of the K launches.
 Inputs are resident in HBM before the timed region.
 
-Prints ONE JSON line on rank 0 (contract in the task brief) with `roofline` (dominant kernel, HIP
-events on the launch stream), `issue` (the bound that really holds for the fused kernel: wave
-instructions per second against the SIMD issue ceiling), `hbm_streaming` (the max_fuse=1 point, where
-every turn really streams the state) and `cpu_baseline` (the oracle's C restatement on the host
-cores; the ONLY place bench.py touches oracle/).
+Prints ONE JSON line on rank 0 (contract in the task brief):
+  roofline        the contract's block for the dominant kernel: SURVEY 8(d)'s ALGORITHMIC bytes per launch / launch
+                  duration (HIP events on the launch stream) against the HBM peak.  With fused turns that is a yardstick,
+                  not traffic - `bound_actual` names the bound that really holds (instruction issue) and
+                  `hbm_frac_of_measured_traffic` what the measured bytes amount to;
+  issue           wave-instructions per second against the SIMD issue ceiling (counters of the committed PMC pass of
+                  this same shape and fuse; dropped when the kernel sources have changed since);
+  hbm_streaming   the max_fuse = 1 launch, where every turn really streams every record through HBM: the physical
+                  HBM fraction of the path;
+  other_shapes    (N = 1) the other BASELINE shapes on this GPU, each with its own fused figure, hbm_streaming block
+                  and a bounded CPU row;
+  other_workloads (N > 1) BASELINE configs[3] and [4]: every rank steps its share of C4 (16 777 216 Werewolf x 12 over 8
+                  GPUs = 2 097 152 per rank) and C5 (50/50 mix), with the timed summary all-gather;
+  cpu_baseline    the oracle's C restatement on the host cores (the ONLY place bench.py touches oracle/).
 """
 import argparse
 import json
@@ -44,15 +53,22 @@ ROOMS_PER_GPU = 65536
 N_PLAYERS = 8
 GAME = "werewolf-(mafia)"
 SEED = 0xC0FFEE
+WW, TT = "werewolf-(mafia)", "two-truths-and-a-lie"
 
 # BASELINE.json configs as per-GPU workloads: [(game, players, rooms per GPU)], rooms grouped by game.
 # c2 is the contract workload (default); the others are optional extra lines, same JSON format.
 WORKLOADS = {
-    "c2": [("werewolf-(mafia)", 8, 65536)],
-    "c3": [("two-truths-and-a-lie", 4, 1048576)],
-    "c4": [("werewolf-(mafia)", 12, 2097152)],                                   # 16 777 216 rooms over 8 GPUs
-    "c5": [("werewolf-(mafia)", 8, 524288), ("two-truths-and-a-lie", 4, 524288)],  # 50/50 mix, one launch
+    "c2": [(WW, 8, 65536)],
+    "c3": [(TT, 4, 1048576)],
+    "c4": [(WW, 12, 2097152)],                                   # 16 777 216 rooms over 8 GPUs
+    "c5": [(WW, 8, 524288), (TT, 4, 524288)],                    # 50/50 mix, one launch
 }
+# the informational shapes of an N = 1 run: (label, profile key, per-GPU segments)
+OTHER_SHAPES = (
+    ("1048576 Werewolf x8", "ww8_1048576", [(WW, 8, 1 << 20)]),
+    ("2097152 Werewolf x12 (one GPU's share of C4)", "c4", WORKLOADS["c4"]),
+    ("1048576 Two-Truths x4 (C3)", "c3", WORKLOADS["c3"]),
+)
 
 
 def load_dsl(game=GAME):
@@ -82,44 +98,52 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(dsl, budget_s=12.0):
-    """The oracle (a scalar C port of the reference loop + policy) on this host's cores, on a
-    bounded sample of the same steady-state workload."""
+def cpu_baseline(spec, budget_s=12.0, sample_rooms=None, single_thread=True):
+    """The oracle (a scalar C port of the reference loop + policy) on this host's cores, on a bounded sample of the
+    same steady-state workload: the first segment's game, `sample_rooms` rooms (default: the segment's own count,
+    capped at 1 048 576), as many turns as fit the time budget."""
     from oracle.oracle import Oracle
+    game, n_players, rooms = spec[0]
+    rooms = min(sample_rooms or rooms, 1 << 20)
     cores = usable_cores()
-    orc = Oracle(dsl, N_PLAYERS)
-    rooms = orc.init_rooms(ROOMS_PER_GPU)
+    orc = Oracle(load_dsl(game), n_players)
+    state = orc.init_rooms(rooms)
     t0 = time.perf_counter()
-    orc.run(rooms, SEED, 0, 0, 16, threads=cores, restart=True)        # calibrate
+    orc.run(state, SEED, 0, 0, 8, threads=cores, restart=True)        # calibrate
     dt = max(time.perf_counter() - t0, 1e-4)
-    turns = int(min(max(16 * budget_s / dt, 64), 4096))
-    rooms = orc.init_rooms(ROOMS_PER_GPU)
+    turns = int(min(max(8 * budget_s / dt, 16), 4096))
+    state = orc.init_rooms(rooms)
     t0 = time.perf_counter()
-    orc.run(rooms, SEED, 0, 0, turns, threads=cores, restart=True)
+    orc.run(state, SEED, 0, 0, turns, threads=cores, restart=True)
     dt_all = time.perf_counter() - t0
-    one = orc.init_rooms(4096)
-    t1 = max(turns // 8, 16)
-    t0 = time.perf_counter()
-    orc.run(one, SEED, 0, 0, t1, threads=1, restart=True)
-    dt_one = time.perf_counter() - t0
-    return {"value": ROOMS_PER_GPU * turns / dt_all, "unit": "room-phase steps/s", "cores": cores,
-            "kind": "port",
-            "sample": f"{ROOMS_PER_GPU} werewolf x{N_PLAYERS} rooms x {turns} turns, steady state, OpenMP over rooms",
-            "single_thread_value": 4096 * t1 / dt_one}
+    out = {"value": rooms * turns / dt_all, "unit": "room-phase steps/s", "cores": cores, "kind": "port",
+           "sample": f"{rooms} {game} x{n_players} rooms x {turns} turns, steady state, OpenMP over rooms"}
+    if single_thread:
+        one = orc.init_rooms(4096)
+        t1 = max(turns // 8, 16)
+        t0 = time.perf_counter()
+        orc.run(one, SEED, 0, 0, t1, threads=1, restart=True)
+        out["single_thread_value"] = 4096 * t1 / (time.perf_counter() - t0)
+    return out
 
 
-def committed_profile(workload):
-    """Counters of a committed rocprofv3 --pmc run of this same command (profiles/pmc_<workload>.json,
-    written by tools/pmc_summary.py), or {}.  PMC counters cannot be collected from inside the timed
-    run, so the bench line quotes the committed passes and says so (`source`)."""
-    p = os.path.join(ROOT, "profiles", f"pmc_{workload}.json")
+def committed_profile(key, fuse):
+    """Counters of a committed rocprofv3 --pmc run of this same shape AND fuse setting (profiles/pmc_<key>.json for fused
+    launches, pmc_<key>_k1.json for --fuse 1; written by tools/pmc_summary.py), or {}.  PMC counters cannot be collected
+    from inside the timed run, so the bench line quotes the committed passes and says so (`source`).  A profile taken
+    on other kernel sources than the ones this library was built from is stale: its instruction counts are not quoted."""
+    from game_engine_amd._lib import kernel_source_hash
+    p = os.path.join(ROOT, "profiles", f"pmc_{key}_k1.json" if fuse == 1 else f"pmc_{key}.json")
     try:
         with open(p) as f:
             d = json.load(f)
-        d["_path"] = os.path.relpath(p, ROOT)
-        return d
     except (OSError, ValueError):
         return {}
+    if fuse != 1 and int(d.get("turns_per_launch", fuse)) == 1:
+        return {}
+    d["_path"] = os.path.relpath(p, ROOT)
+    d["_stale"] = d.get("kernel_src_sha256") != kernel_source_hash()
+    return d
 
 
 def spawn_ranks(args, argv):
@@ -146,6 +170,36 @@ def spawn_ranks(args, argv):
     sys.stdout.flush()
 
 
+def issue_block(prof, rooms, turns, kernel_s):
+    """The bound of the fused kernel: wave-instructions issued per second against the SIMD issue
+    ceiling.  A wave64 VALU instruction occupies its SIMD-32 for 2 cycles (MI355X_MICROARCH.md:54, :473)
+    -> 1 024 SIMDs x 2.4 GHz / 2 = 1.23e12 wave-instr/s with >= 2 wavefronts per SIMD; a wavefront ALONE
+    on its SIMD issues one instruction per 4 cycles (same table, row 'vector-instruction ISSUE cost')
+    -> 6.1e11.  Instructions per wave-turn come from the committed SQ counter pass (PMC cannot be
+    collected inside the timed run)."""
+    waves = (rooms + 63) // 64
+    waves_per_simd = waves / N_SIMD
+    cyc = 4.0 if waves_per_simd < 2.0 else 2.0
+    ceiling = N_SIMD * CLOCK_HZ / cyc
+    wave_turns_per_s = waves * turns / kernel_s
+    out = {"bound": "valu-issue", "waves_per_simd": waves_per_simd, "cycles_per_wave_instruction": cyc,
+           "ceiling_wave_instr_per_s": ceiling, "wave_turns_per_s": wave_turns_per_s,
+           # SIMD cycles (at 2.4 GHz) one wave-turn has to itself: busy SIMDs x clock / wave-turns per second
+           "simd_cycles_per_wave_turn": min(waves, N_SIMD) * CLOCK_HZ / wave_turns_per_s}
+    ipt = prof.get("instructions_per_wave_turn")
+    if ipt and not prof.get("_stale"):
+        total = float(ipt.get("valu", 0)) + float(ipt.get("salu", 0)) + float(ipt.get("lds", 0))
+        out.update({"instructions_per_wave_turn": ipt, "wave_instr_per_s": total * wave_turns_per_s,
+                    "frac": total * wave_turns_per_s / ceiling,
+                    "valu_frac": float(ipt.get("valu", 0)) * wave_turns_per_s / ceiling,
+                    "wait_any_frac_of_wave_cycles": prof.get("wait_any_frac"),
+                    "source": f"{prof.get('_path')} (committed rocprofv3 --pmc SQ pass of this shape and fuse setting, same kernel sources)"})
+    else:
+        out.update({"instructions_per_wave_turn": None, "frac": None,
+                    "source": (f"{prof.get('_path')} is stale: taken on other kernel sources (kernel_src_sha256 differs)" if ipt else None)})
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -155,8 +209,8 @@ def main():
     ap.add_argument("--rooms", type=int, default=None, help="rooms per GPU (overrides the workload's count; c2 only)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2", help="BASELINE.json config (default c2 = configs[1])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-unfused", action="store_true", help="skip the one-launch-per-turn reference point")
-    ap.add_argument("--no-other-shapes", action="store_true", help="skip the informational larger shapes")
+    ap.add_argument("--no-unfused", action="store_true", help="skip the one-launch-per-turn points")
+    ap.add_argument("--no-other-shapes", action="store_true", help="skip the other BASELINE shapes (N = 1) / workloads (N > 1)")
     ap.add_argument("--no-from-init", action="store_true", help="skip the S=64-from-initial-state variant")
     args = ap.parse_args()
     if args.gpus < 1 or args.steps < 1 or args.warmup < 0 or args.fuse < 1:
@@ -209,19 +263,68 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    dsl = load_dsl()
-    table = GameTable(dsl)
+    def max_over_ranks(x):
+        t = torch.tensor([x], dtype=torch.float64, device=coll_device)
+        if use_dist:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    tables = {}
+
+    def segments_of(spec):
+        for g, _, _ in spec:
+            if g not in tables:
+                tables[g] = GameTable(load_dsl(g))
+        return [(tables[g], n, r) for g, n, r in spec]
+
+    def record_bytes(batch, spec):
+        """algorithmic bytes per room-phase step / 2: the record, room-weighted mean over the segments"""
+        rooms = sum(r for _, _, r in spec)
+        return sum(batch.bytes_per_room(k) * r for k, (_, _, r) in enumerate(spec)) / rooms
+
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def streaming_point(spec, launches=256):
+        """The HBM-streaming point of a shape: max_fuse = 1, one launch per turn - every turn reads and writes every record
+        through HBM.  Device time per launch by HIP events on the launch stream, and the wall clock of hipGraph replays."""
+        segs = segments_of(spec)
+        rooms = sum(r for _, _, r in spec)
+        b1 = RoomBatch(segs, seed=SEED, device=device_index, max_fuse=1, restart=True)
+        bpr = record_bytes(b1, spec)
+        b1.step(PREROLL_TURNS, stream); b1.step(launches, stream); b1.sync()   # pre-roll; the second call builds the graph of `launches` launches
+        # wall clock first, without per-launch events (they serialise the launches; here the launches of a step() call are
+        # replayed from a hipGraph), then the kernel time per launch
+        t1 = time.perf_counter()
+        for _ in range(4):
+            b1.step(launches, stream)
+        b1.sync()
+        w1 = (time.perf_counter() - t1) / 4
+        b1.set_timing(True); b1.kernel_time(reset=True)
+        b1.step(launches, stream); b1.sync()
+        k1, l1 = b1.kernel_time(reset=True)
+        b1.close()
+        us = k1 * 1e3 / max(l1, 1)
+        gbs_wall = 2 * bpr * rooms * launches / w1 / 1e9
+        gbs_kernel = 2 * bpr * rooms / (us * 1e-6) / 1e9
+        return {"value": rooms * launches / w1, "unit": "room-phase steps/s (wall)", "ms_per_turn": w1 * 1e3 / launches,
+                "kernel_us_per_launch": us, "bytes_per_launch": 2 * bpr * rooms,
+                "achieved_GBs_kernel": gbs_kernel, "frac_kernel": gbs_kernel / HBM_PEAK_GBS, "frac_kernel_of_measured_copy_peak": gbs_kernel / HBM_COPY_GBS,
+                "achieved_GBs_wall": gbs_wall, "frac_wall": gbs_wall / HBM_PEAK_GBS, "frac_wall_of_measured_copy_peak": gbs_wall / HBM_COPY_GBS,
+                "bound": "hbm",
+                "note": "max_fuse=1: one launch per turn, every turn reads and writes every record through HBM (bytes_per_launch = the "
+                        "state, read + written; the committed FETCH/WRITE passes profiles/pmc_<shape>_k1.json measure the same bytes); "
+                        "kernel = HIP events around single launches on the launch stream, wall = hipGraph replays of "
+                        f"{launches} launches"}
+
     spec = [list(x) for x in WORKLOADS[args.workload]]
     if args.rooms:
         spec[0][2] = args.rooms
-    tables = {g: GameTable(load_dsl(g)) for g, _, _ in spec}
-    segments = [(tables[g], n, r) for g, n, r in spec]
+    spec = [tuple(x) for x in spec]
+    segments = segments_of(spec)
     rooms = sum(r for _, _, r in spec)
     batch = RoomBatch(segments, seed=SEED, first_room=shard_first_room(rooms, rank),
                       device=device_index, max_fuse=args.fuse, restart=True)
-    # algorithmic bytes per room-phase step: record read + written once (room-weighted mean over segments)
-    bytes_per_room = sum(batch.bytes_per_room(k) * r for k, (_, _, r) in enumerate(spec)) / rooms
-    stream = torch.cuda.current_stream().cuda_stream
+    bytes_per_room = record_bytes(batch, spec)
 
     # untimed: fixed pre-roll to steady state, then W warm-up steps of the timed shape
     preroll = 0
@@ -241,11 +344,7 @@ def main():
     elapsed = time.perf_counter() - t0
     kernel_ms, launches = batch.kernel_time(reset=True)
     batch.set_timing(False)
-
-    t_el = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
-    if use_dist:
-        dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
-    elapsed = float(t_el.item())
+    elapsed = max_over_ranks(elapsed)
 
     # the one collective of the path: all-gather of the per-GPU summary (RCCL over xGMI)
     ts = time.perf_counter()
@@ -253,30 +352,10 @@ def main():
     barrier()
     summary_ms = (time.perf_counter() - ts) * 1e3
 
-    # the HBM-streaming point: one launch per turn, same workload, short (N=1 only: keeps multi-GPU runs symmetric)
+    # the HBM-streaming point of the contract shape (N=1 only: keeps multi-GPU runs symmetric)
     unfused = None
     if rank == 0 and world == 1 and not args.no_unfused:
-        b1 = RoomBatch(segments, seed=SEED, device=device_index, max_fuse=1, restart=True)
-        b1.step(PREROLL_TURNS, stream); b1.step(256, stream); b1.sync()     # pre-roll; the second call builds the 256-launch graph
-        # wall clock first, without per-launch events (they serialise the launches; here the 256
-        # launches of a step() call are replayed from a hipGraph), then the kernel time per launch
-        t1 = time.perf_counter()
-        for _ in range(4):
-            b1.step(256, stream)
-        b1.sync()
-        w1 = (time.perf_counter() - t1) / 4
-        b1.set_timing(True); b1.kernel_time(reset=True)
-        b1.step(256, stream); b1.sync()
-        k1, l1 = b1.kernel_time(reset=True)
-        gbs_wall = 2 * bytes_per_room * rooms * 256 / w1 / 1e9
-        gbs_kernel = 2 * bytes_per_room * rooms / (k1 * 1e-3 / max(l1, 1)) / 1e9
-        unfused = {"value": rooms * 256 / w1, "unit": "room-phase steps/s (wall)", "ms_per_turn": w1 * 1e3 / 256,
-                   "kernel_us_per_launch": k1 * 1e3 / max(l1, 1),
-                   "achieved_GBs_wall": gbs_wall, "frac_wall": gbs_wall / HBM_PEAK_GBS,
-                   "achieved_GBs_kernel": gbs_kernel, "frac_kernel": gbs_kernel / HBM_PEAK_GBS,
-                   "note": "max_fuse=1: one launch per turn, every turn reads and writes every record through HBM; "
-                           "wall = 256-launch hipGraph replays, kernel = HIP events around single launches"}
-        b1.close()
+        unfused = streaming_point(spec)
 
     # BASELINE.md §3 variant: S = 64 turns from the initial state (no recycling), 3 warm-ups, median of 10
     from_init = None
@@ -300,26 +379,68 @@ def main():
                      "ms_per_64_turns": med * 1e3, "finished_after_64": sm["finished"], "rooms": rooms}
         bi.close()
 
-    # other BASELINE shapes on one GPU (device time, informational; `value` above is the contract number)
+    # N = 1: the other BASELINE shapes on this GPU (device time; `value` above is the contract number), each with the
+    # launch that really streams it through HBM and a bounded CPU row
     other = None
     if rank == 0 and world == 1 and not args.no_other_shapes and args.workload == "c2":
         other = {}
-        tt_dsl = load_dsl("two-truths-and-a-lie")
-        for label, key, tb, n, r in (("1048576 Werewolf x8", "ww8_1048576", table, 8, 1 << 20),
-                                     ("2097152 Werewolf x12 (one GPU's share of C4)", "c4", table, 12, 1 << 21),
-                                     ("1048576 Two-Truths x4 (C3)", "c3", GameTable(tt_dsl), 4, 1 << 20)):
-            bb = RoomBatch([(tb, n, r)], seed=SEED, device=device_index, max_fuse=args.fuse, restart=True)
+        for label, key, sp in OTHER_SHAPES:
+            r = sum(x[2] for x in sp)
+            bb = RoomBatch(segments_of(sp), seed=SEED, device=device_index, max_fuse=args.fuse, restart=True)
             bb.step(256, stream); bb.sync()
             bb.set_timing(True); bb.kernel_time(reset=True)
             bb.step(512, stream); bb.sync()
             ms, nl = bb.kernel_time(reset=True)
-            bpr = bb.bytes_per_room(0)
-            other[label] = {"value": r * 512 / (ms * 1e-3), "unit": "room-phase steps/s (device time)",
-                            "us_per_turn": ms * 1e3 / 512,
-                            "algorithmic_GBs": 2 * bpr * r * 512 / (ms * 1e-3) / 1e9,
-                            "algorithmic_frac": 2 * bpr * r * 512 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "bytes_per_room_record": bpr,
-                            "issue": issue_block(committed_profile(key), r, 512, ms * 1e-3)}
+            bpr = record_bytes(bb, sp)
             bb.close()
+            alg = 2 * bpr * r * 512 / (ms * 1e-3) / 1e9
+            other[label] = {"value": r * 512 / (ms * 1e-3), "unit": "room-phase steps/s (device time)",
+                            "us_per_turn": ms * 1e3 / 512, "bytes_per_room_record": bpr,
+                            "algorithmic_GBs": alg, "algorithmic_frac": alg / HBM_PEAK_GBS,
+                            "algorithmic_note": "SURVEY 8(d) yardstick (2 x record x rooms x turns / time): fused turns keep the state in "
+                                                "registers, so this is not traffic and may exceed 1; the physical HBM fraction is hbm_streaming",
+                            "bound_actual": "valu-issue",
+                            "issue": issue_block(committed_profile(key, args.fuse), r, 512, ms * 1e-3),
+                            "hbm_streaming": None if args.no_unfused else streaming_point(sp, launches=128)}
+            if not args.no_cpu_baseline:
+                other[label]["cpu_baseline"] = cpu_baseline(sp, budget_s=4.0, sample_rooms=1 << 18, single_thread=False)
+
+    # N > 1: BASELINE configs[3] (C4) and configs[4] (C5) - every rank steps its share, no data-path collective; the
+    # summary all-gather is timed on its own
+    other_workloads = None
+    if world > 1 and not args.no_other_shapes and args.workload == "c2":
+        other_workloads = {}
+        k_timed = max(2, min(args.steps, 8))
+        for key in ("c4", "c5"):
+            sp = WORKLOADS[key]
+            r = sum(x[2] for x in sp)
+            bb = RoomBatch(segments_of(sp), seed=SEED, first_room=shard_first_room(r, rank), device=device_index,
+                           max_fuse=args.fuse, restart=True)
+            bpr = record_bytes(bb, sp)
+            bb.step(args.fuse, stream)                                       # pre-roll + warm-up in one launch
+            bb.sync()
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(k_timed):
+                bb.step(args.fuse, stream)
+            barrier()
+            dt = max_over_ranks(time.perf_counter() - t1)
+            t2 = time.perf_counter()
+            sm = allgather_summary(bb, world, force=use_dist)
+            barrier()
+            ag_ms = (time.perf_counter() - t2) * 1e3
+            turns_total = int(bb.turn)
+            bb.close()
+            steps_s = r * world * args.fuse * k_timed / dt
+            alg = 2 * bpr * steps_s / 1e9                                    # whole job
+            other_workloads[key] = {
+                "workload": " + ".join(f"{x[2]} {x[0]} rooms x {x[1]} players" for x in sp) + f" per GPU, x{world} GPUs, steady state",
+                "rooms_total": r * world, "rooms_per_gpu": r, "turns_fused_per_launch": args.fuse, "launches_timed": k_timed,
+                "turns_stepped": turns_total, "seed": SEED,
+                "value": steps_s, "unit": "room-phase steps/s (whole job, wall, max over ranks)", "ms_per_launch": dt * 1e3 / k_timed,
+                "bytes_per_room_record": bpr, "algorithmic_GBs": alg, "algorithmic_frac": alg / (HBM_PEAK_GBS * world),
+                "summary_allgather_ms": ag_ms,
+                "checksum": sm["checksum"], "summary": {k: sm[k] for k in ("rooms", "finished", "village_wins", "wolf_wins", "games_recycled")}}
 
     if rank == 0:
         turns_timed = args.fuse * args.steps
@@ -328,9 +449,11 @@ def main():
         alg_bytes = 2 * bytes_per_room * per_launch_units
         avg_launch_s = kernel_ms * 1e-3 / max(launches, 1)
         achieved = alg_bytes / avg_launch_s / 1e9
-        prof = committed_profile(args.workload if not args.rooms else f"ww8_{args.rooms}")
+        prof = committed_profile(args.workload if not args.rooms else f"ww8_{args.rooms}", args.fuse)
         state_rw = 2.0 * bytes_per_room * rooms
         traffic = prof.get("hbm_bytes_per_launch") if abs(prof.get("state_bytes_read_plus_written", -1) - state_rw) < 1 else None
+        issue = issue_block(prof, rooms, turns_timed, kernel_ms * 1e-3)
+        fused = args.fuse > 1
         out = {
             "metric": "room-phase steps/sec", "value": total_steps / elapsed, "unit": "room-phase steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -347,53 +470,30 @@ def main():
                          "traffic": traffic,
                          "traffic_source": (prof.get("_path", None) and f"{prof['_path']} (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; not measured in this run)"),
                          "kernel": "ge_step_kernel", "avg_launch_us": avg_launch_s * 1e6, "launches": launches,
-                         "algorithmic_bytes_per_launch": alg_bytes,
-                         "note": "SURVEY 8(d) yardstick: algorithmic bytes = 2 x record x rooms x turns in the launch. With fused "
-                                 "turns the state stays in registers: real HBM traffic is `traffic` (~1/fuse of the algorithmic "
-                                 "figure) and the kernel is bound by instruction issue, see `issue`; the launch that really streams "
-                                 "the state every turn is `hbm_streaming`"},
-            "issue": issue_block(prof, rooms, turns_timed, kernel_ms * 1e-3),
+                         "algorithmic": True, "algorithmic_bytes_per_launch": alg_bytes,
+                         # what really bounds this launch, and the physical HBM figure of the same launch
+                         "bound_actual": "valu-issue" if fused else "hbm",
+                         "frac_of_actual_bound": issue.get("frac") if fused else achieved / HBM_PEAK_GBS,
+                         "hbm_frac_of_measured_traffic": (traffic / avg_launch_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                         "note": "`achieved` / `frac` are SURVEY 8(d)'s yardstick: ALGORITHMIC bytes = 2 x record x rooms x turns in the launch. "
+                                 "With fused turns the state stays in registers, those bytes never reach HBM (real traffic: `traffic`, ~1/fuse of "
+                                 "it) and the figure is not a physical fraction - the launch is bound by instruction issue (`bound_actual`, "
+                                 "block `issue`).  The physical HBM fraction of the path is `hbm_streaming` (max_fuse = 1), per shape in "
+                                 "`other_shapes[*].hbm_streaming`"},
+            "issue": issue,
             "hbm_streaming": unfused,
             "from_init_64": from_init,
             "other_shapes": other,
+            "other_workloads": other_workloads,
             "summary": {k: summary[k] for k in ("rooms", "finished", "village_wins", "wolf_wins", "games_recycled", "checksum")},
             "summary_allgather_ms": summary_ms,
         }
         if not args.no_cpu_baseline and args.workload == "c2" and world == 1:   # rank 0 at N=1 only (contract)
-            out["cpu_baseline"] = cpu_baseline(dsl)
+            out["cpu_baseline"] = cpu_baseline(spec)
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     batch.close()
     if use_dist:
         dist.destroy_process_group()
-
-
-def issue_block(prof, rooms, turns, kernel_s):
-    """The bound of the fused kernel: wave-instructions issued per second against the SIMD issue
-    ceiling.  A wave64 VALU instruction occupies its SIMD-32 for 2 cycles (MI355X_MICROARCH.md:54, :473)
-    -> 1 024 SIMDs x 2.4 GHz / 2 = 1.23e12 wave-instr/s with >= 2 wavefronts per SIMD; a wavefront ALONE
-    on its SIMD issues one instruction per 4 cycles (same table, row 'vector-instruction ISSUE cost')
-    -> 6.1e11.  Instructions per wave-turn come from the committed SQ counter pass (PMC cannot be
-    collected inside the timed run)."""
-    waves = (rooms + 63) // 64
-    waves_per_simd = waves / N_SIMD
-    cyc = 4.0 if waves_per_simd < 2.0 else 2.0
-    ceiling = N_SIMD * CLOCK_HZ / cyc
-    wave_turns_per_s = waves * turns / kernel_s
-    out = {"bound": "valu-issue", "waves_per_simd": waves_per_simd, "cycles_per_wave_instruction": cyc,
-           "ceiling_wave_instr_per_s": ceiling, "wave_turns_per_s": wave_turns_per_s,
-           # SIMD cycles (at 2.4 GHz) one wave-turn has to itself: busy SIMDs x clock / wave-turns per second
-           "simd_cycles_per_wave_turn": min(waves, N_SIMD) * CLOCK_HZ / wave_turns_per_s}
-    ipt = prof.get("instructions_per_wave_turn")
-    if ipt:
-        total = float(ipt.get("valu", 0)) + float(ipt.get("salu", 0)) + float(ipt.get("lds", 0))
-        out.update({"instructions_per_wave_turn": ipt, "wave_instr_per_s": total * wave_turns_per_s,
-                    "frac": total * wave_turns_per_s / ceiling,
-                    "valu_frac": float(ipt.get("valu", 0)) * wave_turns_per_s / ceiling,
-                    "wait_any_frac_of_wave_cycles": prof.get("wait_any_frac"),
-                    "source": f"{prof.get('_path')} (committed rocprofv3 --pmc SQ pass of this shape)"})
-    else:
-        out.update({"instructions_per_wave_turn": None, "frac": None, "source": None})
-    return out
 
 
 if __name__ == "__main__":

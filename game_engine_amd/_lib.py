@@ -64,6 +64,19 @@ SYMBOLS = ["ge_table_compile_json", "ge_batch_create", "ge_batch_step", "ge_batc
 _lib = None
 
 
+def kernel_source_hash() -> str:
+    """sha256 over the sources libge_step.so is built from: what ties a committed counter profile (profiles/pmc_*.json,
+    tools/pmc_summary.py) to the kernels it was measured on (bench.py does not quote a profile of other sources)."""
+    import hashlib
+    h = hashlib.sha256()
+    src = os.path.join(_HERE, "csrc")
+    for name in sorted(os.listdir(src)):
+        if name.endswith((".hip", ".h", ".inl", ".cpp")):
+            with open(os.path.join(src, name), "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()
+
+
 def load() -> C.CDLL:
     global _lib
     if _lib is not None:
@@ -99,17 +112,20 @@ def load() -> C.CDLL:
     lib.ge_batch_kernel_time.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(u64)]
     lib.ge_batch_destroy.argtypes = [vp]
     lib.ge_batch_destroy.restype = None
-    lib.ge_group_create.argtypes = [C.POINTER(BatchDesc), C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]
-    lib.ge_group_size.argtypes = [vp]
-    lib.ge_group_shard.argtypes = [vp, C.c_int, C.POINTER(vp)]
-    lib.ge_group_step.argtypes = [vp, u32]
-    lib.ge_group_sync.argtypes = [vp]
-    lib.ge_group_summary.argtypes = [vp, C.POINTER(Summary)]
-    lib.ge_group_destroy.argtypes = [vp]
-    lib.ge_group_destroy.restype = None
     lib.ge_strerror.argtypes = [C.c_int]
     lib.ge_strerror.restype = C.c_char_p
-    if lib.ge_abi_version() != GE_ABI_VERSION:
+    # (GE_LIB_ANY_ABI: timing an older build through tools/abn.sh - only the entry points both versions share are used there)
+    any_abi = bool(os.environ.get("GE_LIB_PATH") and os.environ.get("GE_LIB_ANY_ABI"))
+    if lib.ge_abi_version() != GE_ABI_VERSION and not any_abi:
         raise ImportError("libge_step.so ABI version mismatch; rebuild it")
+    if hasattr(lib, "ge_group_create") or not any_abi:
+        lib.ge_group_create.argtypes = [C.POINTER(BatchDesc), C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]
+        lib.ge_group_size.argtypes = [vp]
+        lib.ge_group_shard.argtypes = [vp, C.c_int, C.POINTER(vp)]
+        lib.ge_group_step.argtypes = [vp, u32]
+        lib.ge_group_sync.argtypes = [vp]
+        lib.ge_group_summary.argtypes = [vp, C.POINTER(Summary)]
+        lib.ge_group_destroy.argtypes = [vp]
+        lib.ge_group_destroy.restype = None
     _lib = lib
     return lib

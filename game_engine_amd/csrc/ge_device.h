@@ -189,12 +189,19 @@ __device__ __forceinline__ uint32_t plurality(nib_t votes, uint32_t voters) {
         uint64_t tally = 0;
 #pragma unroll
         for (int i = 0; i < NB; i++) tally += uint64_t(1) << (4u * ((uint32_t)(v >> (4 * i)) & 15u));
-#pragma unroll
-        for (int k = 1; k <= NB; k++) {
-            const uint32_t cnt = (uint32_t)(tally >> (4 * k)) & 15u;
-            const uint32_t kk = (cnt << 4) | (uint32_t)(15 - k);
-            key = kk > key ? kk : key;
-        }
+        // keys count << 4 | 15 - id, two per register as above: ids 1..7 from the low word's nibbles, 8..12 from the high word's
+        typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+        auto pk = [](uint32_t x) { return __builtin_bit_cast(u16x2, x); };
+        const uint32_t lo = (uint32_t)tally, hi = (uint32_t)(tally >> 32);
+        const uint32_t a = (lo & 0x00F000F0u) | 0x000A000Eu;                                    // ids 1, 5
+        const uint32_t b = ((lo >> 4) & 0x00F000F0u) | 0x0009000Du;                             // ids 2, 6
+        const uint32_t c = ((lo >> 8) & 0x00F000F0u) | 0x0008000Cu;                             // ids 3, 7
+        const uint32_t d = ((lo >> 12) & 0x000000F0u) | ((hi & 15u) << 20) | 0x0007000Bu;       // ids 4, 8
+        const uint32_t e = (hi & 0x000000F0u) | ((hi << 12) & 0x00F00000u) | 0x00050006u;       // ids 9, 10
+        const uint32_t f = ((hi >> 8) & 0x000000F0u) | ((hi << 4) & 0x00F00000u) | 0x00030004u; // ids 11, 12
+        const u16x2 m = __builtin_elementwise_max(__builtin_elementwise_max(__builtin_elementwise_max(pk(a), pk(b)), __builtin_elementwise_max(pk(c), pk(d))),
+                                                  __builtin_elementwise_max(pk(e), pk(f)));
+        key = m.x > m.y ? m.x : m.y;
     }
     return (key >> 4) ? 15u - (key & 15u) : 0u;
 }
@@ -375,9 +382,11 @@ __device__ __forceinline__ void deal_roles(Deal &d, uint32_t dk, uint32_t game, 
     uint32_t rem = (1u << n) - 1u, wolves = 0, doc = 0, det = 0;
 #pragma unroll
     for (uint32_t j = 0; j < (NB > 8 ? 5u : 4u); j++) {           // nw + 2 picks, nw <= NB / 4
-        const uint32_t k = popc(rem);
-        const bool on = j < nw + 2u && k != 0u;            // selects, not branches (see WwBuild)
-        const uint32_t idx = pick(draw(dk, 16u + j), k | (k == 0u));
+        // every pick takes exactly one player (n >= 4 >= nw + 2 for every admitted n), so j picks leave n - j: a wave-uniform
+        // count instead of a popcount of `rem` per pick
+        const uint32_t k = n - j;
+        const bool on = j < nw + 2u;                       // selects, not branches (see WwBuild)
+        const uint32_t idx = pick(draw(dk, 16u + j), k);
         const uint32_t pos = TABLE ? nth_set_bit_lds<NB>(nth8, rem, idx)
                                    : (NB <= 8 ? nth_set_bit_swar8(rem, idx) : nth_set_bit<NB>(rem | (1u << 31), idx));
         const uint32_t bit = on ? (1u << (pos & 15u)) : 0u;
@@ -829,14 +838,12 @@ __device__ __forceinline__ uint32_t ww_decide(const WWR<NB> &s, uint32_t comp, u
 
 // ---- RefereeNode (B): the effect of entering row q = qe & 31 (qe >> 5 = its entry effect), then the move itself
 template <int NB, bool LOWOCC, bool SINGLE>
-__device__ __forceinline__ void ww_apply_effect(WWR<NB> &s, DevRow &row, const WwCtx &c, uint32_t qe, uint32_t alive, uint32_t ALL, uint32_t turn,
+__device__ __forceinline__ void ww_apply_effect(WWR<NB> &s, const DevRow &row, const DevRow &qrow, const WwCtx &c, uint32_t qe, uint32_t alive, uint32_t ALL, uint32_t turn,
                                                 Deal &deal, WWR<NB> &dealt) {
     using R = WWR<NB>;
     using nib_t = typename R::nib_t;
     using B = WwBuild<NB, LOWOCC, SINGLE>;
     const uint32_t q = qe & 31u, eff = qe >> 5, p_eff = (row.r0 >> 5) & 7u;
-    DevRow qrow = row;
-    if (!SINGLE) qrow = c.rows[q];                             // LDS read in flight during the effect: first used at the end
     // night / day resolution: the plurality victim dies unless the (highest-id living) Doctor guards it
     auto resolve = [&](bool on, bool day) {
         const uint32_t voters = day ? (alive & s.acted) : (alive & s.template get<F_WOLF>());
@@ -886,7 +893,6 @@ __device__ __forceinline__ void ww_apply_effect(WWR<NB> &s, DevRow &row, const W
     s.prev = s.phase;
     s.phase = q;
     const bool terminal = SINGLE ? ((c.term_mask >> q) & 1u) != 0u : ((qrow.r0 >> 11) & 7u) == 0u;
-    if (!SINGLE) row = qrow;
     s.end_turn = (terminal && s.end_turn == END_NONE) ? (turn < 0xFFFEu ? turn : 0xFFFEu) : s.end_turn;
 }
 
@@ -946,7 +952,13 @@ __device__ __forceinline__ void ww_turn(WWR<NB> &s, DevRow &row, const WwCtx &c,
         s.det_v = (s.det_v & ~seen) | acts.det_v;
         s.det_w = (s.det_w & ~seen) | acts.det_w;
     }
-    if ((qe & 31u) != s.phase) ww_apply_effect<NB, LOWOCC, SINGLE>(s, row, c, qe, alive, ALL, turn, deal, dealt);
+    if (SINGLE) {
+        if ((qe & 31u) != s.phase) ww_apply_effect<NB, LOWOCC, true>(s, row, row, c, qe, alive, ALL, turn, deal, dealt);
+    } else if ((qe & 31u) != s.phase) {
+        const DevRow qrow = c.rows[qe & 31u];                  // LDS read in flight during the effect: first used at its end
+        ww_apply_effect<NB, LOWOCC, false>(s, row, qrow, c, qe, alive, ALL, turn, deal, dealt);
+        row = qrow;
+    }
 }
 
 // ------------------------------------------------------------------ two truths and a lie

@@ -340,14 +340,15 @@ struct DevCond { uint32_t lit[4][4]; uint32_t meta, pad[3]; DevLit prep[4][4]; }
 // the generic rows' common shape, read once per launch into scalar registers (wave-uniform loop bounds and skips)
 struct CondShape { uint32_t shape, slots, f0, f1; };
 
+// rows | ord8 | nth8 lead the structure, contiguous and in the order of a step block's LDS: one linear copy fills it
 struct DevTable {
     DevRow rows[32];
+    uint32_t ord8[256];      // ord8[mask] = the positions of the set bits of an 8-bit mask, ascending, one nibble each
+    uint8_t nth8[2048];      // n-th-set-bit table (ge_device.h), copied to LDS by the large-batch build
     int32_t n_phases, rounds, n_players;
     uint32_t cond_shape;     // generic rows: largest clause count [2:0] and clause length [6:4], any base-set literal [8], any numeric literal [9]
     uint32_t cond_slots;     // generic rows: bit 4k + l = some row has a base-set literal in slot l of clause k; bit 16 + 4k + l = a numeric one
     uint32_t cond_fields[2]; // generic rows: nibble 4k + l (slots 0..7 in [0], 8..15 in [1]) = which numeric fields slot (k, l) compares, bit = GE_NUM_* - 1
-    uint8_t nth8[2048];      // n-th-set-bit table (ge_device.h), copied to LDS by the large-batch build
-    uint32_t ord8[256];      // ord8[mask] = the positions of the set bits of an 8-bit mask, ascending, one nibble each
     DevCond conds[32];       // clause form of the generic rows (read from global memory by the generic kernel builds only)
 };
 

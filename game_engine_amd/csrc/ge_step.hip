@@ -38,7 +38,7 @@ struct SegDev {
     uint32_t human_mask, pad0;
     uint64_t local_first;      // index of the segment's room 0 inside the batch
     uint32_t init_words[12];   // the initial record (player_states_template, phase 0)
-    uint32_t init_regs[20];    // the same in the kernels' register form (WWR::to_regs / TT::to_regs): the restart template, read with scalar loads
+    alignas(16) uint32_t init_regs[20];    // the same in the kernels' register form (WWR::to_regs / TT::to_regs): the restart template, read with scalar loads
     uint32_t term_mask;        // bit r = table row r is terminal (no next_phase branch)
     uint32_t done0;            // two-truths: tt_done_mask of the initial record
     uint32_t *trace;           // GE_FLAG_TRACE: [turn in launch][rooms_padded] x 4 words, else null
@@ -96,17 +96,46 @@ __device__ __forceinline__ void store_event(uint32_t *trace, uint64_t rooms_padd
     ((__attribute__((address_space(1))) u32x4 *)(uintptr_t)trace)[(uint64_t)t * rooms_padded + room] = v;
 }
 
-__device__ __forceinline__ void load_rows(DevRow *rows, const DevTable *tables, uint32_t table_idx, uint8_t *nth8, uint32_t *ord8 = nullptr) {
-    if (threadIdx.x < GE_MAX_PHASES) rows[threadIdx.x] = tables[table_idx].rows[threadIdx.x];
-    if (ord8) {                                                // 1 KB: one 16-B element per thread of a 64-room block
-        const u32x4 *src = reinterpret_cast<const u32x4 *>(tables[table_idx].ord8);
-        for (uint32_t i = threadIdx.x; i < 64u; i += blockDim.x) reinterpret_cast<u32x4 *>(ord8)[i] = src[i];
-    }
-    if (nth8) {                                                // 2 KB, 16 B per thread and pass
-        const u32x4 *src = reinterpret_cast<const u32x4 *>(tables[table_idx].nth8);
-        for (uint32_t i = threadIdx.x; i < 128u; i += blockDim.x) reinterpret_cast<u32x4 *>(nth8)[i] = src[i];
+// The large-batch turn loops take the restart template (SegDev::init_regs) from a copy in the block's LDS when a room
+// restarts (uniform-address reads inside the restart branch).  A/B on MI355X, us/turn at 64 fused turns
+// (profiles/r03_ab_restart_template.txt): template in scalar registers across the loop - spills to VGPR lanes; scalar-cache
+// load inside the branch 8.12 / 21.28 / 4.88 (1 M x 8 / 2 M x 12 / 1 M Two-Truths x 4); LDS copy 7.90 / 21.09 / 4.68.
+constexpr uint32_t LDS_S0 = 128;       // 20 words of init_regs, padded
+
+// Fills the block's LDS tables: DevTable starts with rows | ord8 | nth8 in the LDS order, so the first `n16` 16-byte
+// elements are one linear copy (64 = the phase rows, 128 = + ord8, 256 = + nth8); one element per thread and pass
+__device__ __forceinline__ void load_rows(DevRow *rows, const DevTable *tables, uint32_t table_idx, uint32_t n16, const SegDev *sg = nullptr) {
+    const u32x4 *src = reinterpret_cast<const u32x4 *>(tables + table_idx);
+    u32x4 *dst = reinterpret_cast<u32x4 *>(rows);
+    if (sg && n16 == 256u && threadIdx.x < 5u)
+        dst[256u + threadIdx.x] = reinterpret_cast<const u32x4 *>(sg->init_regs)[threadIdx.x];
+    for (uint32_t base = 0; base < n16; base += blockDim.x) {   // uniform trip count: 1 for 256-room blocks
+        const uint32_t i = base + threadIdx.x;
+        if (i < n16) dst[i] = src[i];
     }
     __syncthreads();
+}
+
+// The restart template (SegDev::init_regs) through the scalar cache.  The address is an opaque scalar: the loads are
+// s_load_dwordx8/x16, and they stay where they are written - inside the restart branch of a large-batch turn loop they are
+// not hoisted out of it: up to 19 scalar registers live across the whole loop spill to VGPR lanes there (v_writelane /
+// v_readlane per restart), while a scalar-cache hit per restart costs a wavefront with 5-7 neighbours on its SIMD nothing.
+template <int N>
+__device__ __forceinline__ void load_init_regs(const SegDev &sg, uint32_t *ir) {
+    // whole 16-byte groups (init_regs has 20 words): a ragged tail would be fetched with vector loads.  The opaque zero
+    // offset is what keeps the loads in place (an address the optimiser cannot prove loop-invariant)
+    typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+    uint32_t zero = 0;
+    asm volatile("" : "+s"(zero));
+    const u32x4_t *ip = reinterpret_cast<const u32x4_t *>(sg.init_regs) + zero;
+#pragma unroll
+    for (int j = 0; j < (N + 3) / 4; j++) {
+        const u32x4_t v = ip[j];
+        if (4 * j < N) ir[4 * j] = __builtin_amdgcn_readfirstlane(v.x);
+        if (4 * j + 1 < N) ir[4 * j + 1] = __builtin_amdgcn_readfirstlane(v.y);
+        if (4 * j + 2 < N) ir[4 * j + 2] = __builtin_amdgcn_readfirstlane(v.z);
+        if (4 * j + 3 < N) ir[4 * j + 3] = __builtin_amdgcn_readfirstlane(v.w);
+    }
 }
 
 template <int NB, bool LOWOCC, bool GENERIC, bool SINGLE>
@@ -123,18 +152,34 @@ __device__ __forceinline__ void run_ww(const SegDev *__restrict__ sgp, const Ste
     load_words<L::WORDS>(sg.base, sg.rooms_padded, room, w);      // in flight while the block fills its LDS tables
     // the slot -> player table of the action queue sits right behind the phase rows (step_lds_bytes)
     uint32_t *ord8 = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(rows) + LDS_ROWS);
-    load_rows(rows, tables, sg.table_idx, B::TABLE ? nth8 : nullptr, B::ORD ? ord8 : nullptr);
+    load_rows(rows, tables, sg.table_idx, B::TABLE ? 256u : B::ORD ? 128u : 64u, sgp);
     WWR<NB> s;
     uint32_t cache;
+    if (NB <= 8 && !SINGLE) {
+        // one opaque value per word: as elements of the loaded 16-byte vectors the packed predicate words would stay
+        // <2 x i32> values through the turn loop's phis, and the 64-bit register tuples that makes cost a v_mov_b64
+        // per pair and turn at the loop's back edge (the lone-wavefront build pays a full issue slot for each)
+#pragma unroll
+        for (int j = 0; j < L::WORDS; j++) asm volatile("" : "+v"(w[j]));
+    }
     ww_load_regs<NB>(w, s, cache);                            // N <= 8: the record is the register form (ge_layout.h)
     const uint32_t ALL = (1u << sg.n_players) - 1u;
     const uint32_t rk = room_key_from(a.seed_key, sg.first_global + room);
-    // the fresh room a finished one is recycled into: wave-uniform, already in register form, kept in scalar registers
-    uint32_t ir[WWR<NB>::NREGS];
+    // the fresh room a finished one is recycled into: wave-uniform, already in register form (SegDev::init_regs).  The
+    // lone-wavefront build keeps it in scalar registers across the turn loop; the large-batch builds fetch it when a room restarts
+    auto fresh_room = [&]() {
+        uint32_t ir[20];
+        if (!LOWOCC && !SINGLE) {
+            const u32x4 *p = reinterpret_cast<const u32x4 *>(rows) + 256;
 #pragma unroll
-    for (int j = 0; j < WWR<NB>::NREGS; j++) ir[j] = __builtin_amdgcn_readfirstlane(sg.init_regs[j]);
-    WWR<NB> s0;
-    s0.from_regs(ir);
+            for (int j = 0; j < (WWR<NB>::NREGS + 3) / 4; j++) { const u32x4 v = p[j]; ir[4 * j] = v.x; ir[4 * j + 1] = v.y; ir[4 * j + 2] = v.z; ir[4 * j + 3] = v.w; }
+        } else {
+            load_init_regs<WWR<NB>::NREGS>(sg, ir);
+        }
+        WWR<NB> s0;
+        s0.from_regs(ir);
+        return s0;
+    };
     const uint32_t term_mask = __builtin_amdgcn_readfirstlane(sg.term_mask);
     const uint32_t turn0 = a.turn0 + (a.turn_dev ? *a.turn_dev : 0u);   // uniform (scalar load)
     CondShape cs = {0u, 0u, 0u, 0u};
@@ -161,7 +206,7 @@ __device__ __forceinline__ void run_ww(const SegDev *__restrict__ sgp, const Ste
         uint32_t restarted = 0;
         if (a.restart && ((term_mask >> s.phase) & 1u)) {        // recycle a finished room
             const uint32_t g = s.games;
-            s = s0;
+            s = fresh_room();
             s.games = g < 0xFFFFu ? g + 1u : g;
             restarted = 1;
         }
@@ -175,7 +220,9 @@ __device__ __forceinline__ void run_ww(const SegDev *__restrict__ sgp, const Ste
         if (trace && valid) store_event(sg.trace, sg.rooms_padded, 0u, room, turn0, p, s.phase, restarted, ev_newly, ev_choice);
     } else {
         DevRow row = rows[s.phase];
-        const DevRow row0 = rows[sg.phase0_idx];
+        WWR<NB> s0;
+        DevRow row0 = row;
+        if (LOWOCC) { s0 = fresh_room(); row0 = rows[sg.phase0_idx]; }
         // the turn loop; the lone-wavefront build compiles it once per trace setting: the event-trace branches (two per turn,
         // both wave-uniform and almost always taken) cost a lone wavefront an instruction-fetch bubble each
         auto turns = [&](auto trace_c) {
@@ -185,9 +232,9 @@ __device__ __forceinline__ void run_ww(const SegDev *__restrict__ sgp, const Ste
                 uint32_t restarted = 0;
                 if (a.restart && ((row.r0 >> 11) & 7u) == 0u) {      // recycle a finished room
                     const uint32_t g = s.games;
-                    s = s0;
+                    s = LOWOCC ? s0 : fresh_room();
                     s.games = g < 0xFFFFu ? g + 1u : g;
-                    row = row0;
+                    row = LOWOCC ? row0 : rows[ctx.phase0_idx];
                     restarted = 1;
                 }
                 const uint32_t p = s.phase;
@@ -232,16 +279,24 @@ __device__ __forceinline__ void run_tt(const SegDev *__restrict__ sgp, const Ste
     const uint64_t room = valid ? room_in : 0;
     uint32_t w[L::WORDS];
     load_words<L::WORDS>(sg.base, sg.rooms_padded, room, w);
-    load_rows(rows, tables, sg.table_idx, (QUEUE && !LOWOCC) ? nth8 : nullptr);
+    load_rows(rows, tables, sg.table_idx, (QUEUE && !LOWOCC) ? 256u : 64u, sgp);
     TT<NB> s;
     L::unpack(w, s);
     const uint32_t rk = room_key_from(a.seed_key, sg.first_global + room);
-    // the restart template, already unpacked (scalar loads)
-    uint32_t ir[TT<NB>::NREGS];
+    // the restart template, already unpacked (see run_ww)
+    auto fresh_room = [&]() {
+        uint32_t ir[20];
+        if (QUEUE && !LOWOCC && !SINGLE) {
+            const u32x4 *p = reinterpret_cast<const u32x4 *>(rows) + 256;
 #pragma unroll
-    for (int j = 0; j < TT<NB>::NREGS; j++) ir[j] = __builtin_amdgcn_readfirstlane(sg.init_regs[j]);
-    TT<NB> s0;
-    s0.from_regs(ir);
+            for (int j = 0; j < (TT<NB>::NREGS + 3) / 4; j++) { const u32x4 v = p[j]; ir[4 * j] = v.x; ir[4 * j + 1] = v.y; ir[4 * j + 2] = v.z; ir[4 * j + 3] = v.w; }
+        } else {
+            load_init_regs<TT<NB>::NREGS>(sg, ir);
+        }
+        TT<NB> s0;
+        s0.from_regs(ir);
+        return s0;
+    };
     const uint32_t done0 = __builtin_amdgcn_readfirstlane(sg.done0);
     const uint32_t term_mask = __builtin_amdgcn_readfirstlane(sg.term_mask);
     const uint32_t turn0 = a.turn0 + (a.turn_dev ? *a.turn_dev : 0u);
@@ -253,7 +308,7 @@ __device__ __forceinline__ void run_tt(const SegDev *__restrict__ sgp, const Ste
         uint32_t restarted = 0;
         if (a.restart && ((term_mask >> s.phase) & 1u)) {
             const uint32_t g = s.games;
-            s = s0;
+            s = fresh_room();
             s.games = g < 0xFFFFu ? g + 1u : g;
             done = done0;
             restarted = 1;
@@ -266,14 +321,16 @@ __device__ __forceinline__ void run_tt(const SegDev *__restrict__ sgp, const Ste
         if (a.trace && valid) store_event(sg.trace, sg.rooms_padded, 0u, room, turn0, p, s.phase, restarted, ev_newly, ev_choice);
     } else {
         DevRow row = rows[s.phase];
-        const DevRow row0 = rows[sg.phase0_idx];
+        TT<NB> s0;
+        DevRow row0 = row;
+        if (LOWOCC) { s0 = fresh_room(); row0 = rows[sg.phase0_idx]; }
         for (uint32_t t = 0; t < a.n_turns; t++) {
             uint32_t restarted = 0;
             if (a.restart && ((row.r0 >> 11) & 7u) == 0u) {
                 const uint32_t g = s.games;
-                s = s0;
+                s = LOWOCC ? s0 : fresh_room();
                 s.games = g < 0xFFFFu ? g + 1u : g;
-                row = row0;
+                row = LOWOCC ? row0 : rows[sg.phase0_idx];
                 done = done0;
                 restarted = 1;
             }
@@ -307,11 +364,12 @@ __device__ __forceinline__ void run_kind(const SegDev *__restrict__ sg, const St
 // LDS of a step block is sized at launch (a 64-room block must not pay for four wavefronts' queues, or
 // LDS, not registers, caps the wavefronts per CU)
 constexpr uint32_t LDS_NTH8 = 2048;
+static_assert(offsetof(DevTable, ord8) == LDS_ROWS && offsetof(DevTable, nth8) == LDS_ROWS + LDS_ORD8, "DevTable leads with the LDS image");
 static_assert(sizeof(WaveLds) % 16 == 0 && sizeof(WaveLdsLow) % 16 == 0 && LDS_ROWS % 16 == 0 && LDS_ORD8 % 16 == 0, "LDS sections stay 16-byte aligned");
 
 inline uint32_t step_lds_bytes(bool queue, bool lowocc, uint32_t block_threads) {
     if (!queue) return LDS_ROWS;                              // Two-Truths N <= 4: phase rows only
-    return LDS_ROWS + LDS_ORD8 + (lowocc ? 0u : LDS_NTH8) + (uint32_t)(lowocc ? sizeof(WaveLdsLow) : sizeof(WaveLds)) * (block_threads / 64u);
+    return LDS_ROWS + LDS_ORD8 + (lowocc ? 0u : LDS_NTH8 + LDS_S0) + (uint32_t)(lowocc ? sizeof(WaveLdsLow) : sizeof(WaveLds)) * (block_threads / 64u);
 }
 
 extern __shared__ __align__(16) unsigned char ge_lds[];
@@ -334,7 +392,7 @@ __global__ void __launch_bounds__(256, (KIND == K_WW12 && !LOWOCC && !GENERIC) ?
     constexpr bool WWK = KIND == K_WW8 || KIND == K_WW12 || tt_uses_queue(KIND == K_TT4 ? 4 : KIND == K_TT8 ? 8 : 12, LOWOCC);   // uses the action queue
     DevRow *rows = reinterpret_cast<DevRow *>(ge_lds);
     uint8_t *nth8 = ge_lds + LDS_ROWS + LDS_ORD8;
-    auto *wl = reinterpret_cast<typename WaveLdsOf<LOWOCC>::type *>(ge_lds + LDS_ROWS + LDS_ORD8 + (LOWOCC ? 0u : LDS_NTH8));
+    auto *wl = reinterpret_cast<typename WaveLdsOf<LOWOCC>::type *>(ge_lds + LDS_ROWS + LDS_ORD8 + (LOWOCC ? 0u : LDS_NTH8 + LDS_S0));
     const uint64_t room = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     run_kind<KIND, LOWOCC, GENERIC, SINGLE>(segs, a, rows, WWK ? &wl[threadIdx.x >> 6] : nullptr, nth8, tables, room);
 }
@@ -345,7 +403,7 @@ __global__ void __launch_bounds__(256) ge_step_kernel_mixed(const StepArgs a, co
                                                             const DevTable *__restrict__ tables) {
     DevRow *rows = reinterpret_cast<DevRow *>(ge_lds);
     uint8_t *nth8 = ge_lds + LDS_ROWS + LDS_ORD8;
-    auto *wl = reinterpret_cast<typename WaveLdsOf<LOWOCC>::type *>(ge_lds + LDS_ROWS + LDS_ORD8 + (LOWOCC ? 0u : LDS_NTH8));
+    auto *wl = reinterpret_cast<typename WaveLdsOf<LOWOCC>::type *>(ge_lds + LDS_ROWS + LDS_ORD8 + (LOWOCC ? 0u : LDS_NTH8 + LDS_S0));
     uint32_t si = 0;
     for (uint32_t k = 1; k < a.n_seg; k++)
         if (blockIdx.x >= a.block_begin[k]) si = k;

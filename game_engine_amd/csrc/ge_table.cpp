@@ -214,6 +214,26 @@ const char *const TT_SLOT_NAMES[GE_TT_SLOTS][3] = {
 struct Binding {
     int pack = 0, n = 0;
     std::string declared[GE_MAX_SLOTS];
+    // every string of the phase graph except the target conditions themselves (names, descriptions, action texts, branch
+    // keys): what the Referee is told to do.  A field these texts name may be written during play (mentions()).
+    std::string phase_text;
+    void collect_text(const JVal *v, const std::string &key) {
+        if (!v) return;
+        if (v->type == JVal::OBJ) for (auto &kv : v->obj) { phase_text += kv.first; phase_text += '\n'; collect_text(kv.second.get(), kv.first); }
+        else if (v->type == JVal::ARR) for (auto &x : v->arr) collect_text(x.get(), key);
+        else if (v->type == JVal::STR && key != "condition") { phase_text += v->str; phase_text += '\n'; }
+    }
+    // whole-identifier, case-sensitive occurrence ("TIER 1 - PUBLIC" does not name a field `tier`)
+    bool mentions(const std::string &field) const {
+        auto ident = [](char c) { return (c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z') || (c >= '0' && c <= '9') || c == '_'; };
+        if (field.empty()) return false;
+        for (size_t at = phase_text.find(field); at != std::string::npos; at = phase_text.find(field, at + 1)) {
+            const bool left = at == 0 || !ident(phase_text[at - 1]);
+            const bool right = at + field.size() >= phase_text.size() || !ident(phase_text[at + field.size()]);
+            if (left && right) return true;
+        }
+        return false;
+    }
     const char *canonical(int slot) const { return pack == GE_PACK_WEREWOLF ? WW_SLOT_NAMES[slot][0] : TT_SLOT_NAMES[slot][0]; }
     // false: the declaration names one slot twice (two accepted names of the same slot) - `twice` says which
     bool bind(int pack_, const JVal *ps_def, std::string &twice) {
@@ -411,6 +431,13 @@ int parse_term(const Binding &bind, const JVal *tmpl, const std::string &part, s
     if (!pack_models(pack, field) && tmpl && declared_name != "name") {
         const JVal *have = tmpl->get(declared_name.c_str());
         if (have && (have->type == JVal::BOOL || (have->type == JVal::NUM && have->num == (double)(long)have->num) || have->type == JVal::STR)) {
+            // a declared field outside the pack folds to a constant - unless the phase graph's own text names it: a field
+            // the Referee is told to update (the generator prompt's `player.is_current_turn`,
+            // dsl_phases_generation_prompt.txt:121) is state no rule pack carries
+            if (bind.mentions(declared_name)) {
+                why = "condition on '" + declared_name + "': the phases' text names this field (it may be written during play) and the rule pack does not model it: " + p;
+                return -1;
+            }
             const int holds = const_term(*have, op, vals);
             if (holds < 0) { why = "unsupported comparison on a non-numeric field: " + p; return -1; }
             ge_literal l;
@@ -601,6 +628,7 @@ static int compile_impl(const char *dsl_json, size_t len, int rounds, ge_game_ta
     std::string twice;
     if (!bind.bind(t.pack, ps_def, twice)) return err.set("two declared fields bind to one state slot: " + twice);
     for (int s = 0; s < bind.n; s++) copy_name(t.field_names[s], bind.declared[s]);
+    bind.collect_text(phases, std::string());
 
     if (t.pack == GE_PACK_WEREWOLF) {
         const JVal *roles = decl->get("roles");

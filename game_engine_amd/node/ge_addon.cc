@@ -142,28 +142,28 @@ napi_value TableInfo(napi_env env, napi_callback_info info) {
     return out;
 }
 
-// createBatch({seed, firstRoom, device, maxFuse, restart, segments:[{table, nPlayers, nRooms}]}): External<ge_batch>
-napi_value CreateBatch(napi_env env, napi_callback_info info) {
-    size_t argc = 1;
-    napi_value argv[1];
-    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
-    if (argc < 1) return throw_status(env, GE_ERR_ARG, "createBatch");
-    ge_batch_desc d;
+// {seed, firstRoom, device, maxFuse, restart, trace, segments:[{table, nPlayers, nRooms, humanMask}]} -> ge_batch_desc; throws and returns false on a bad argument
+bool parse_desc(napi_env env, napi_value obj, const char *what, ge_batch_desc *out) {
+    ge_batch_desc &d = *out;
     memset(&d, 0, sizeof d);
     uint64_t dev = 0, fuse = 0, restart = 0, trace = 0;
-    if (!get_prop_u64(env, argv[0], "seed", &d.seed, 0) || !get_prop_u64(env, argv[0], "firstRoom", &d.first_room, 0) ||
-        !get_prop_u64(env, argv[0], "device", &dev, 0) || !get_prop_u64(env, argv[0], "maxFuse", &fuse, 0) ||
-        !get_prop_u64(env, argv[0], "restart", &restart, 0) || !get_prop_u64(env, argv[0], "trace", &trace, 0))
-        return throw_status(env, GE_ERR_ARG, "createBatch");
+    if (!get_prop_u64(env, obj, "seed", &d.seed, 0) || !get_prop_u64(env, obj, "firstRoom", &d.first_room, 0) ||
+        !get_prop_u64(env, obj, "device", &dev, 0) || !get_prop_u64(env, obj, "maxFuse", &fuse, 0) ||
+        !get_prop_u64(env, obj, "restart", &restart, 0) || !get_prop_u64(env, obj, "trace", &trace, 0)) {
+        throw_status(env, GE_ERR_ARG, what);
+        return false;
+    }
     d.device = (int32_t)dev; d.max_fuse = (uint32_t)fuse;
     d.flags = (restart ? GE_FLAG_RESTART : GE_FLAG_NONE) | (trace ? GE_FLAG_TRACE : GE_FLAG_NONE);
     napi_value segs;
     uint32_t n = 0;
     bool is_arr = false;
-    if (napi_get_named_property(env, argv[0], "segments", &segs) != napi_ok ||
+    if (napi_get_named_property(env, obj, "segments", &segs) != napi_ok ||
         napi_is_array(env, segs, &is_arr) != napi_ok || !is_arr ||
-        napi_get_array_length(env, segs, &n) != napi_ok || n == 0 || n > GE_MAX_SEGMENTS)
-        return throw_status(env, GE_ERR_ARG, "createBatch", "segments");
+        napi_get_array_length(env, segs, &n) != napi_ok || n == 0 || n > GE_MAX_SEGMENTS) {
+        throw_status(env, GE_ERR_ARG, what, "segments");
+        return false;
+    }
     d.n_segments = n;
     for (uint32_t k = 0; k < n; k++) {
         napi_value sg, tv;
@@ -173,10 +173,23 @@ napi_value CreateBatch(napi_env env, napi_callback_info info) {
             napi_get_named_property(env, sg, "table", &tv) != napi_ok ||
             napi_get_value_external(env, tv, reinterpret_cast<void **>(&t)) != napi_ok || !t ||
             !get_prop_u64(env, sg, "nPlayers", &np, 0) || !get_prop_u64(env, sg, "nRooms", &nr, 0) ||
-            !get_prop_u64(env, sg, "humanMask", &hm, 0))
-            return throw_status(env, GE_ERR_ARG, "createBatch", "segment");
+            !get_prop_u64(env, sg, "humanMask", &hm, 0)) {
+            throw_status(env, GE_ERR_ARG, what, "segment");
+            return false;
+        }
         d.seg[k].table = t; d.seg[k].n_players = (uint32_t)np; d.seg[k].n_rooms = nr; d.seg[k].human_mask = (uint32_t)hm;
     }
+    return true;
+}
+
+// createBatch({seed, firstRoom, device, maxFuse, restart, segments:[{table, nPlayers, nRooms}]}): External<ge_batch>
+napi_value CreateBatch(napi_env env, napi_callback_info info) {
+    size_t argc = 1;
+    napi_value argv[1];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    if (argc < 1) return throw_status(env, GE_ERR_ARG, "createBatch");
+    ge_batch_desc d;
+    if (!parse_desc(env, argv[0], "createBatch", &d)) return nullptr;
     ge_batch *b = nullptr;
     int st = ge_batch_create(&d, &b);
     if (st != GE_OK) return throw_status(env, st, "createBatch");
@@ -465,6 +478,175 @@ napi_value RoomViewSize(napi_env env, napi_callback_info) {
     return v;
 }
 
+// ---- device group: ONE Node process, N GPUs (ge_group_*, include/ge_step.h): rooms sharded over the devices, stepped
+// concurrently, one RCCL all-gather of the per-device summaries inside the native library
+struct GroupBox {
+    ge_group *g = nullptr;
+    bool busy = false;
+};
+void finalize_group(napi_env, void *data, void *) {
+    GroupBox *box = static_cast<GroupBox *>(data);
+    if (box->g) ge_group_destroy(box->g);
+    delete box;
+}
+GroupBox *group_box(napi_env env, napi_value v) {
+    GroupBox *box = nullptr;
+    if (napi_get_value_external(env, v, reinterpret_cast<void **>(&box)) != napi_ok) return nullptr;
+    return box;
+}
+ge_group *group_arg(napi_env env, napi_value v) {
+    GroupBox *box = group_box(env, v);
+    if (!box || !box->g) return nullptr;
+    if (box->busy) {
+        napi_throw_error(env, "GE_BUSY", "an async step() of this group is in flight: await it first (a ge_group handle is not thread-safe)");
+        return nullptr;
+    }
+    return box->g;
+}
+
+// createGroup({seed, firstRoom, maxFuse, restart, trace, segments (the WHOLE job), devices: [0, 1, ...]}): External<ge_group>
+napi_value CreateGroup(napi_env env, napi_callback_info info) {
+    size_t argc = 1;
+    napi_value argv[1];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    if (argc < 1) return throw_status(env, GE_ERR_ARG, "createGroup");
+    ge_batch_desc d;
+    if (!parse_desc(env, argv[0], "createGroup", &d)) return nullptr;
+    napi_value devs;
+    uint32_t n = 0;
+    bool is_arr = false;
+    if (napi_get_named_property(env, argv[0], "devices", &devs) != napi_ok || napi_is_array(env, devs, &is_arr) != napi_ok || !is_arr ||
+        napi_get_array_length(env, devs, &n) != napi_ok || n == 0 || n > 64)
+        return throw_status(env, GE_ERR_ARG, "createGroup", "devices");
+    std::vector<int> devices(n);
+    for (uint32_t i = 0; i < n; i++) {
+        napi_value v;
+        uint64_t x = 0;
+        if (napi_get_element(env, devs, i, &v) != napi_ok || !get_u64(env, v, &x)) return throw_status(env, GE_ERR_ARG, "createGroup", "devices");
+        devices[i] = (int)x;
+    }
+    ge_group *g = nullptr;
+    int st = ge_group_create(&d, devices.data(), (int)n, &g);
+    if (st != GE_OK) return throw_status(env, st, "createGroup");
+    GroupBox *box = new GroupBox();
+    box->g = g;
+    napi_value ext;
+    if (napi_create_external(env, box, finalize_group, nullptr, &ext) != napi_ok) {
+        ge_group_destroy(g);
+        delete box;
+        napi_throw_error(env, "GE_NAPI", "napi_create_external failed");
+        return nullptr;
+    }
+    return ext;
+}
+
+struct GroupStepWork {
+    napi_async_work work;
+    napi_deferred deferred;
+    napi_ref keep;
+    GroupBox *box;
+    uint32_t turns;
+    int status;
+};
+void group_step_execute(napi_env, void *data) {
+    GroupStepWork *w = static_cast<GroupStepWork *>(data);
+    w->status = ge_group_step(w->box->g, w->turns);            // all devices step concurrently
+    if (w->status == GE_OK) w->status = ge_group_sync(w->box->g);
+}
+void group_step_complete(napi_env env, napi_status, void *data) {
+    GroupStepWork *w = static_cast<GroupStepWork *>(data);
+    w->box->busy = false;
+    napi_value v;
+    if (w->status == GE_OK) {
+        napi_get_undefined(env, &v);
+        napi_resolve_deferred(env, w->deferred, v);
+    } else {
+        napi_value msg;
+        napi_create_string_utf8(env, ge_strerror(w->status), NAPI_AUTO_LENGTH, &msg);
+        napi_create_error(env, nullptr, msg, &v);
+        napi_reject_deferred(env, w->deferred, v);
+    }
+    napi_delete_async_work(env, w->work);
+    napi_delete_reference(env, w->keep);
+    delete w;
+}
+
+// groupStep(group, nTurns): Promise<void> - on the libuv pool, like step()
+napi_value GroupStep(napi_env env, napi_callback_info info) {
+    size_t argc = 2;
+    napi_value argv[2];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    ge_group *g = argc >= 1 ? group_arg(env, argv[0]) : nullptr;
+    uint64_t turns = 1;
+    if (!g || (argc > 1 && !get_u64(env, argv[1], &turns))) return throw_status(env, GE_ERR_ARG, "groupStep");
+    GroupStepWork *w = new GroupStepWork();
+    w->box = group_box(env, argv[0]); w->turns = (uint32_t)turns; w->status = GE_OK;
+    napi_value promise, name;
+    if (napi_create_reference(env, argv[0], 1, &w->keep) != napi_ok) { delete w; return throw_status(env, GE_ERR_ARG, "groupStep"); }
+    if (napi_create_promise(env, &w->deferred, &promise) != napi_ok ||
+        napi_create_string_utf8(env, "ge_group_step", NAPI_AUTO_LENGTH, &name) != napi_ok ||
+        napi_create_async_work(env, nullptr, name, group_step_execute, group_step_complete, w, &w->work) != napi_ok) {
+        napi_delete_reference(env, w->keep);
+        delete w;
+        return throw_status(env, GE_ERR_ARG, "groupStep");
+    }
+    w->box->busy = true;
+    if (napi_queue_async_work(env, w->work) != napi_ok) {
+        w->box->busy = false;
+        napi_delete_async_work(env, w->work);
+        napi_delete_reference(env, w->keep);
+        delete w;
+        return throw_status(env, GE_ERR_ARG, "groupStep");
+    }
+    return promise;
+}
+
+// groupSummary(group): ArrayBuffer holding the whole job's ge_summary (per-device reductions + ONE ncclAllGather + sum)
+napi_value GroupSummary(napi_env env, napi_callback_info info) {
+    size_t argc = 1;
+    napi_value argv[1];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    ge_group *g = argc >= 1 ? group_arg(env, argv[0]) : nullptr;
+    if (!g) return throw_status(env, GE_ERR_ARG, "groupSummary");
+    void *data = nullptr;
+    napi_value buf;
+    NAPI_OK(napi_create_arraybuffer(env, sizeof(ge_summary), &data, &buf));
+    int st = ge_group_summary(g, static_cast<ge_summary *>(data));
+    if (st != GE_OK) return throw_status(env, st, "groupSummary");
+    return buf;
+}
+
+// groupReadRooms(group, shard, first, count): ArrayBuffer of ge_room_view from device `shard`'s batch (local indices)
+napi_value GroupReadRooms(napi_env env, napi_callback_info info) {
+    size_t argc = 4;
+    napi_value argv[4];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    ge_group *g = argc >= 1 ? group_arg(env, argv[0]) : nullptr;
+    uint64_t shard = 0, first = 0, count = 0;
+    if (!g || argc < 4 || !get_u64(env, argv[1], &shard) || !get_u64(env, argv[2], &first) || !get_u64(env, argv[3], &count))
+        return throw_status(env, GE_ERR_ARG, "groupReadRooms");
+    ge_batch *b = nullptr;
+    int st = ge_group_shard(g, (int)shard, &b);
+    if (st != GE_OK) return throw_status(env, st, "groupReadRooms");
+    void *data = nullptr;
+    napi_value buf;
+    NAPI_OK(napi_create_arraybuffer(env, (size_t)count * sizeof(ge_room_view), &data, &buf));
+    st = ge_batch_read_rooms(b, first, count, static_cast<ge_room_view *>(data), (size_t)count * sizeof(ge_room_view));
+    if (st != GE_OK) return throw_status(env, st, "groupReadRooms");
+    return buf;
+}
+
+napi_value DestroyGroup(napi_env env, napi_callback_info info) {
+    size_t argc = 1;
+    napi_value argv[1];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    GroupBox *box = argc >= 1 ? group_box(env, argv[0]) : nullptr;
+    if (!box) return throw_status(env, GE_ERR_ARG, "destroyGroup");
+    if (box->busy) { napi_throw_error(env, "GE_BUSY", "destroyGroup while an async step() is in flight"); return nullptr; }
+    if (box->g) { ge_group_destroy(box->g); box->g = nullptr; }
+    return nullptr;
+}
+
 napi_value Init(napi_env env, napi_value exports) {
     napi_property_descriptor props[] = {
         {"compileTable", nullptr, CompileTable, nullptr, nullptr, nullptr, napi_default, nullptr},
@@ -483,6 +665,11 @@ napi_value Init(napi_env env, napi_value exports) {
         {"reset", nullptr, Reset, nullptr, nullptr, nullptr, napi_default, nullptr},
         {"deviceCount", nullptr, DeviceCount, nullptr, nullptr, nullptr, napi_default, nullptr},
         {"roomViewSize", nullptr, RoomViewSize, nullptr, nullptr, nullptr, napi_default, nullptr},
+        {"createGroup", nullptr, CreateGroup, nullptr, nullptr, nullptr, napi_default, nullptr},
+        {"groupStep", nullptr, GroupStep, nullptr, nullptr, nullptr, napi_default, nullptr},
+        {"groupSummary", nullptr, GroupSummary, nullptr, nullptr, nullptr, napi_default, nullptr},
+        {"groupReadRooms", nullptr, GroupReadRooms, nullptr, nullptr, nullptr, napi_default, nullptr},
+        {"destroyGroup", nullptr, DestroyGroup, nullptr, nullptr, nullptr, napi_default, nullptr},
     };
     napi_define_properties(env, exports, sizeof props / sizeof props[0], props);
     return exports;

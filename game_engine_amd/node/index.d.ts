@@ -81,6 +81,21 @@ export class ShardedBatch {
   injectAction(room: number, playerId: number, choice: number): void;
   summary(): Summary;
 }
+/** The native device group (ge_group_*): ONE Node process, N distinct GPUs.  `segments` = the WHOLE job, split per segment
+ * over the devices with the global room indices of one RoomBatch; summary() = per-device reductions + ONE RCCL all-gather
+ * inside libge_step.so.  (ShardedBatch is the host-side form: host-summed, also runs several shards on one device.) */
+export class DeviceGroup {
+  constructor(opts: { segments: Segment[]; devices: number[]; seed?: bigint; firstRoom?: bigint; maxFuse?: number; restart?: boolean; trace?: boolean });
+  readonly nRooms: number;
+  readonly devices: number[];
+  step(nTurns?: number): Promise<void>;
+  whenIdle<T>(fn: () => T): Promise<T>;
+  summary(): Summary;
+  /** room = index in segment-major order, as in one RoomBatch of the same segments */
+  readRoom(room: number): RoomState;
+  locate(room: number): [number, number, GameTable];
+  close(): void;
+}
 export function turnToolCalls(table: GameTable, before: RoomState, after: RoomState, event: TurnEvent): ToolCall[];
 /** What _execute_add_game_note appends: '<mark> <TYPE>: <content>' (backend_tools.py:175-198). */
 export function formatNote(noteType: string, content: string): string;

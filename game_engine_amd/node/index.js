@@ -356,14 +356,7 @@ class RoomBatch {
     }
     return out;
   }
-  summary() {
-    const w = new BigUint64Array(addon.summary(this.handle));
-    return {
-      rooms: w[0], finished: w[1], village_wins: w[2], wolf_wins: w[3], alive_players: w[4],
-      sum_end_turn: w[5], end_turn_hist: Array.from(w.slice(6, 22)), score_hist: Array.from(w.slice(22, 38)),
-      checksum: w[38], turn: w[39], games_recycled: w[40],
-    };
-  }
+  summary() { return decodeSummary(addon.summary(this.handle)); }
 }
 
 /**
@@ -408,7 +401,78 @@ class ShardedBatch {
   }
 }
 
+function decodeSummary(buffer) {
+  const w = new BigUint64Array(buffer);
+  return {
+    rooms: w[0], finished: w[1], village_wins: w[2], wolf_wins: w[3], alive_players: w[4],
+    sum_end_turn: w[5], end_turn_hist: Array.from(w.slice(6, 22)), score_hist: Array.from(w.slice(22, 38)),
+    checksum: w[38], turn: w[39], games_recycled: w[40],
+  };
+}
+
+/**
+ * The native device group (ge_group_*, include/ge_step.h; SURVEY §8e process model): ONE Node process drives N
+ * distinct GPUs of a node.  `segments` describe the WHOLE job; device i of n owns the i-th of n contiguous parts of
+ * every segment, and every room keeps the global index it has in one RoomBatch of the same arguments - results are
+ * identical to that batch's for any device count.  step() runs all devices concurrently on the libuv pool; summary()
+ * is the per-device reductions + ONE RCCL all-gather over xGMI + the sum, all inside libge_step.so (RCCL is loaded at
+ * run time; there is none in the host).  ShardedBatch above is the host-side form of the same thing (its summary is a
+ * host sum): it also runs with several shards on ONE device, which RCCL refuses, and serves as the cross-check.
+ */
+class DeviceGroup {
+  constructor({ segments, devices, seed = 0n, firstRoom = 0n, maxFuse = 0, restart = false, trace = false }) {
+    if (!devices || !devices.length) throw new RangeError('devices');
+    this.segments = segments;
+    this.devices = devices.slice();
+    this.handle = addon.createGroup({
+      seed, firstRoom, maxFuse, restart, trace, devices,
+      segments: segments.map((s) => ({ table: s.table.handle, nPlayers: s.nPlayers, nRooms: s.nRooms, humanMask: s.humanMask || 0 })),
+    });
+    this.nRooms = segments.reduce((a, s) => a + s.nRooms, 0);
+    this._tail = Promise.resolve();
+  }
+  /** Advance every room of every device by nTurns turns (async steps of one group are chained, as for RoomBatch). */
+  step(nTurns = 1) {
+    const p = this._tail.then(() => addon.groupStep(this.handle, nTurns));
+    this._tail = p.catch(() => {});
+    return p;
+  }
+  whenIdle(fn) {
+    const p = this._tail.then(fn);
+    this._tail = p.catch(() => {});
+    return p;
+  }
+  /** whole-job summary: per-device reductions, one ncclAllGather of the ge_summary records, the sum */
+  summary() { return decodeSummary(addon.groupSummary(this.handle)); }
+  /** [shard, local index, table] of a room given by its index in segment-major order (the order of one RoomBatch) */
+  locate(room) {
+    const n = this.devices.length;
+    let base = 0;
+    for (let k = 0; k < this.segments.length; k++) {
+      const R = this.segments[k].nRooms;
+      if (room < base + R) {
+        const r = room - base;
+        for (let i = 0; i < n; i++) {
+          const lo = Math.floor(R * i / n), hi = Math.floor(R * (i + 1) / n);
+          if (r >= lo && r < hi) {
+            let local = r - lo;                          // rooms of the earlier segments on this device come first
+            for (let j = 0; j < k; j++) { const Rj = this.segments[j].nRooms; local += Math.floor(Rj * (i + 1) / n) - Math.floor(Rj * i / n); }
+            return [i, local, this.segments[k].table];
+          }
+        }
+      }
+      base += R;
+    }
+    throw new RangeError(`room ${room}`);
+  }
+  readRoom(room) {
+    const [shard, local, table] = this.locate(room);
+    return decodeRoom(table, addon.groupReadRooms(this.handle, shard, local, 1), 0);
+  }
+  close() { if (this.handle) { addon.destroyGroup(this.handle); this.handle = null; } }
+}
+
 const { compileCriteria, audienceGroups, uiToolCalls } = require('./ui_script.js');
 
-module.exports = { GameTable, RoomBatch, ShardedBatch, RoomLog, formatNote, loadDslByGamename, findGameFile, initializePlayers, turnToolCalls, compileCriteria, audienceGroups, uiToolCalls,
+module.exports = { GameTable, RoomBatch, ShardedBatch, DeviceGroup, RoomLog, formatNote, loadDslByGamename, findGameFile, initializePlayers, turnToolCalls, compileCriteria, audienceGroups, uiToolCalls,
                    deviceCount: addon.deviceCount, addon };

@@ -107,6 +107,21 @@ if (deviceCount() === 0) {
     out.shardRoomsEqual = [0, 2999, 3000, 4567, 8999].every((r) => JSON.stringify(sh.readRoom(r)) === JSON.stringify(one.readRoom(r)));
     out.shardRooms = Number(a.rooms);
   }
+  { // the native device group (one process, RCCL all-gather inside the library) on the one device of this box == one batch,
+    // per room and in the summary; duplicate devices are refused before RCCL is asked
+    const { DeviceGroup } = require('./index.js');
+    const segs = [{ table, nPlayers: golden.n_players, nRooms: 7001 }];
+    const grp = new DeviceGroup({ segments: segs, devices: [0], seed: 11n, firstRoom: 1000n, restart: true });
+    const one = new RoomBatch({ segments: segs, seed: 11n, firstRoom: 1000n, restart: true });
+    await Promise.all([grp.step(60), one.step(60)]);
+    await grp.step(40); await one.step(40);
+    const a = grp.summary(), b = one.summary();
+    out.groupSummaryEqual = ['rooms', 'finished', 'village_wins', 'wolf_wins', 'alive_players', 'sum_end_turn', 'checksum', 'turn', 'games_recycled']
+      .every((f) => a[f] === b[f]) && a.end_turn_hist.every((x, i) => x === b.end_turn_hist[i]);
+    out.groupRoomsEqual = [0, 1, 3500, 7000].every((r) => JSON.stringify(grp.readRoom(r)) === JSON.stringify(one.readRoom(r)));
+    try { new DeviceGroup({ segments: segs, devices: [0, 0] }); out.groupDuplicate = 'accepted'; } catch (e) { out.groupDuplicate = e.code; }
+    grp.close(); one.close();
+  }
   out.checked = checked; out.finished = Number(s.finished); out.turn = Number(s.turn);
   out.sample = big.readRoom(123).current_phase_name;
   console.log(JSON.stringify(out));

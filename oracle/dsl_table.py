@@ -252,8 +252,32 @@ def _const_holds(have: Any, op: str, vals: list, part: str) -> bool:
     return {"<": have < k, "<=": have <= k, ">": have > k, ">=": have >= k}[op]
 
 
+def phase_text(dsl: dict) -> str:
+    """Every string of the phase graph (names, descriptions, action texts, branch keys) except the target conditions
+    themselves: what the Referee is told to do.  A field these texts name may be written during play."""
+    out: List[str] = []
+
+    def walk(v, key=None):
+        if isinstance(v, dict):
+            for k, x in v.items():
+                out.append(str(k))
+                walk(x, k)
+        elif isinstance(v, list):
+            for x in v:
+                walk(x, key)
+        elif isinstance(v, str) and key != "condition":
+            out.append(v)
+    walk(dsl.get("phases") or {})
+    return "\n".join(out)
+
+
+def mentions(text: Optional[str], field: str) -> bool:
+    """whole-identifier, case-sensitive occurrence of a declared field name ("TIER 1 - PUBLIC" does not name a field `tier`)"""
+    return bool(text) and re.search(r"(?<![A-Za-z0-9_])" + re.escape(field) + r"(?![A-Za-z0-9_])", text) is not None
+
+
 def parse_clauses(pack: int, cond: Optional[str], template: Optional[dict] = None,
-                  names: Optional[Dict[str, Optional[str]]] = None) -> List[List[Literal]]:
+                  names: Optional[Dict[str, Optional[str]]] = None, text: Optional[str] = None) -> List[List[Literal]]:
     """The condition grammar the DSL generator is told to use (dsl_phases_generation_prompt.txt:120-132):
     terms `player.<field> <op> <value>` with == != < <= > >= `in [...]` `not in [...]`, joined by `and`,
     alternatives joined by `or` (`and` binds tighter; no parentheses).  Result: OR of AND-clauses of
@@ -293,7 +317,12 @@ def parse_clauses(pack: int, cond: Optional[str], template: Optional[dict] = Non
             modelled = fld in nums or fld in ("role", "team", "wolf_chat_enabled") or (fld, True) in base
             if not modelled and template is not None and declared_name != "name" and \
                     isinstance(template.get(declared_name), (bool, int, str)):
-                # a declared field outside the pack: constant (empty base set = never, negated = always)
+                # a declared field outside the pack: constant (empty base set = never, negated = always) - but only if
+                # nothing in the phase graph's own text names the field: one the Referee is told to update (the generator
+                # prompt's `player.is_current_turn`, dsl_phases_generation_prompt.txt:121) is state no rule pack carries
+                if mentions(text, declared_name):
+                    raise DslError(f"condition on {declared_name!r}: the phases' text names this field (it may be written during "
+                                   f"play) and the rule pack does not model it: {part!r}")
                 options = [Literal("base", _const_holds(template[declared_name], op, vals, part), bases=(), field=declared_name)]
             elif fld in nums and all(isinstance(v, int) and not isinstance(v, bool) for v in vals):
                 idx, top = nums[fld]
@@ -415,6 +444,7 @@ def compile_dsl(dsl: dict, rounds: int = 1) -> Table:
     tmpl_all = ((decl.get("player_states_template") or {}).get("player_states") or {})
     # utils.py:603-609: .get('1') misses yaml's int key, "first available id" is what runs
     template = dict(tmpl_all.get("1") or (tmpl_all[next(iter(tmpl_all))] if tmpl_all else {}))
+    ptext = phase_text(dsl)
     if pack == PACK_WEREWOLF:
         role_names = [""] * 5
         for r in decl.get("roles") or []:
@@ -448,7 +478,7 @@ def compile_dsl(dsl: dict, rounds: int = 1) -> Table:
             if wf is not None and wf not in WAIT_FOR:
                 raise DslError(f"phase {pid}: unknown wait_for {wf!r}")
             try:
-                p.clauses = parse_clauses(pack, (cc.get("target_players") or {}).get("condition"), template, names)
+                p.clauses = parse_clauses(pack, (cc.get("target_players") or {}).get("condition"), template, names, ptext)
             except DslError as e:
                 raise DslError(f"phase {pid}: {e}") from None
             plain = plain_terms(p.clauses) if p.clauses else []

@@ -87,3 +87,22 @@ def test_gpus_2_rehearsal_on_one_card_reports_two_ranks():
     assert d["summary"]["rooms"] == 2 * 65536
     assert d["config"]["room_phase_steps_per_bench_step"] == 2 * 65536 * 1024
     assert d["value"] > 1e9 and "cpu_baseline" not in d
+    # one --gpus N command also yields BASELINE configs[3] (C4) and configs[4] (C5): every rank's share, timed all-gather
+    ow = d["other_workloads"]
+    assert set(ow) == {"c4", "c5"}
+    for key, rooms_per_gpu in (("c4", 2097152), ("c5", 1048576)):
+        w = ow[key]
+        for k in ("rooms_total", "value", "algorithmic_frac", "summary_allgather_ms", "checksum", "turns_stepped", "ms_per_launch"):
+            assert k in w, (key, k)
+        assert w["rooms_total"] == 2 * rooms_per_gpu == w["summary"]["rooms"] and w["value"] > 1e9
+    # the C4 checksum of the two-rank job = the sum of the two shards stepped on their own (rooms keep their global index)
+    from conftest import load_dsl
+    from game_engine_amd import GameTable, RoomBatch
+    c4 = ow["c4"]
+    tb = GameTable(load_dsl("werewolf-(mafia)"))
+    total = 0
+    for r in range(2):
+        with RoomBatch([(tb, 12, 2097152)], seed=c4["seed"], first_room=r * 2097152, max_fuse=c4["turns_fused_per_launch"], restart=True) as b:
+            b.step(c4["turns_stepped"])
+            total = (total + b.summary()["checksum"]) % (1 << 64)
+    assert total == c4["checksum"]

@@ -109,6 +109,26 @@ def test_declared_fields_outside_the_pack_are_constants(dsl_ww):
         assert needle in str(oe.value)
 
 
+def test_a_field_the_phase_text_writes_is_not_folded(dsl_ww):
+    """The generator prompt's own example `player.is_current_turn == true` (dsl_phases_generation_prompt.txt:121) is a
+    field the Referee rewrites every turn.  Declared, outside the rule pack and named by a phase's text, it must be a
+    compile error in both compilers - folded to the template's value it would target nobody (or everybody) for the
+    whole game.  Declared but mentioned nowhere in the phase graph (nobody is told to write it) it still folds."""
+    d = copy.deepcopy(dsl_ww)
+    d["declaration"]["player_states"]["is_current_turn"] = {"type": "boolean", "description": "whose turn it is", "example": False}
+    for tmpl in d["declaration"]["player_states_template"]["player_states"].values():
+        tmpl["is_current_turn"] = False
+    d["phases"]["7"]["completion_criteria"]["target_players"]["condition"] = "player.can_vote == true and player.is_alive == true and player.is_current_turn == false"
+    _assert_same_table(d)                                                     # nobody writes it: a constant, as before
+    d["phases"]["6"]["actions"][0]["description"] += " Then set is_current_turn to true for the next speaker."
+    with pytest.raises(GeError) as e:
+        GameTable(d)
+    assert e.value.status == -2 and "is_current_turn" in str(e.value) and "may be written" in str(e.value)
+    with pytest.raises(T.DslError) as oe:
+        T.compile_dsl(d)
+    assert "is_current_turn" in str(oe.value) and "may be written" in str(oe.value)
+
+
 def test_minimal_schema_keeps_the_other_slots_as_engine_state(dsl_ww):
     """A Werewolf DSL that declares only name / role / team / is_alive / can_vote: both compilers bind five slots and leave
     the rest undeclared; rooms then have exactly those fields, and the rules still run (the reference-run goldens

@@ -80,6 +80,8 @@ def test_node_host_matches_golden(dsl, gold):
     assert r["injectBatch"]["same"] and r["injectBatch"]["equal"] and r["injectBatch"]["applied"] > 30
     # ShardedBatch (one Node process, several devices): shard-count invariance per room and in the summary
     assert r["shardRooms"] == 9000 and r["shardSummaryEqual"] and r["shardRoomsEqual"]
+    # DeviceGroup: the native ge_group_* path (RCCL all-gather of the summaries inside libge_step.so) from Node
+    assert r["groupSummaryEqual"] and r["groupRoomsEqual"] and r["groupDuplicate"] == "GE-1"
     # the JS host renders the same backend tool calls as the Python host for the same traced room
     from conftest import load_dsl
     from game_engine_amd import GameTable, RoomBatch

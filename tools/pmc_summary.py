@@ -65,7 +65,9 @@ for name, vals in allc.items():
     med = statistics.median(v for v, _ in big)
     res[name] = {"median": med, "n": len(big), "per_wave_turn": med / waves / fuse,
                  "median_duration_ns_profiled": statistics.median(d for _, d in big)}
-pmc = {"tag": tag, "key": key, "rooms": rooms, "turns_per_launch": fuse,
+sys.path.insert(0, root)
+from game_engine_amd._lib import kernel_source_hash
+pmc = {"tag": tag, "key": key, "rooms": rooms, "turns_per_launch": fuse, "kernel_src_sha256": kernel_source_hash(),
        "state_bytes_read_plus_written": 2.0 * bpr * rooms,
        "command": "bench.py " + " ".join(sys.argv[4:]) if len(sys.argv) > 4 else None}
 if "FETCH_SIZE" in res and "WRITE_SIZE" in res:
