@@ -340,11 +340,15 @@ struct DevCond { uint32_t lit[4][4]; uint32_t meta, pad[3]; DevLit prep[4][4]; }
 // the generic rows' common shape, read once per launch into scalar registers (wave-uniform loop bounds and skips)
 struct CondShape { uint32_t shape, slots, f0, f1; };
 
-// rows | ord8 | nth8 lead the structure, contiguous and in the order of a step block's LDS: one linear copy fills it
+// rows | ord8 | nth8 | spread8 | tally64 lead the structure, contiguous and in the order of a step block's LDS: one linear
+// copy of the first IMG_* bytes fills it (the lone-wavefront builds take rows (+ ord8), Two-Truths up to nth8)
+constexpr uint32_t IMG_ROWS = 0, IMG_ORD8 = 1024, IMG_NTH8 = 2048, IMG_SPREAD8 = 4096, IMG_TALLY = 5120, IMG_END = 7168;
 struct DevTable {
     DevRow rows[32];
     uint32_t ord8[256];      // ord8[mask] = the positions of the set bits of an 8-bit mask, ascending, one nibble each
     uint8_t nth8[2048];      // n-th-set-bit table (ge_device.h), copied to LDS by the large-batch build
+    uint32_t spread8[256];   // spread8[mask] = 0xF in nibble i for every set bit i of the 8-bit mask (voters -> vote nibbles)
+    uint64_t tally64[256];   // tally64[a | b << 4] = (1 << 4a) + (1 << 4b): two votes' worth of nibble counters per lookup
     int32_t n_phases, rounds, n_players;
     uint32_t cond_shape;     // generic rows: largest clause count [2:0] and clause length [6:4], any base-set literal [8], any numeric literal [9]
     uint32_t cond_slots;     // generic rows: bit 4k + l = some row has a base-set literal in slot l of clause k; bit 16 + 4k + l = a numeric one

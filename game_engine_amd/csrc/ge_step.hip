@@ -22,9 +22,11 @@ using namespace ge;
 
 namespace {
 
-// LDS of a step block: [phase rows][ord8 table][nth8 table, table builds only][one WaveLds per wavefront]
+// LDS of a step block: the table image (DevTable's leading IMG_* bytes: [phase rows][ord8][nth8][spread8][tally64], the last
+// three in the large-batch builds only), the restart template (large-batch), then one WaveLds per wavefront
 constexpr uint32_t LDS_ROWS = sizeof(DevRow) * GE_MAX_PHASES;
 constexpr uint32_t LDS_ORD8 = 1024;
+static_assert(LDS_ROWS == IMG_ORD8 && LDS_ROWS + LDS_ORD8 == IMG_NTH8, "LDS image offsets");
 
 enum Kind { K_WW8 = 0, K_WW12, K_TT4, K_TT8, K_TT12, K_COUNT };
 
@@ -107,8 +109,8 @@ constexpr uint32_t LDS_S0 = 128;       // 20 words of init_regs, padded
 __device__ __forceinline__ void load_rows(DevRow *rows, const DevTable *tables, uint32_t table_idx, uint32_t n16, const SegDev *sg = nullptr) {
     const u32x4 *src = reinterpret_cast<const u32x4 *>(tables + table_idx);
     u32x4 *dst = reinterpret_cast<u32x4 *>(rows);
-    if (sg && n16 == 256u && threadIdx.x < 5u)
-        dst[256u + threadIdx.x] = reinterpret_cast<const u32x4 *>(sg->init_regs)[threadIdx.x];
+    if (sg && n16 >= 256u && threadIdx.x < 5u)                 // large-batch builds: the restart template behind the image
+        dst[IMG_END / 16u + threadIdx.x] = reinterpret_cast<const u32x4 *>(sg->init_regs)[threadIdx.x];
     for (uint32_t base = 0; base < n16; base += blockDim.x) {   // uniform trip count: 1 for 256-room blocks
         const uint32_t i = base + threadIdx.x;
         if (i < n16) dst[i] = src[i];
@@ -152,7 +154,7 @@ __device__ __forceinline__ void run_ww(const SegDev *__restrict__ sgp, const Ste
     load_words<L::WORDS>(sg.base, sg.rooms_padded, room, w);      // in flight while the block fills its LDS tables
     // the slot -> player table of the action queue sits right behind the phase rows (step_lds_bytes)
     uint32_t *ord8 = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(rows) + LDS_ROWS);
-    load_rows(rows, tables, sg.table_idx, B::TABLE ? 256u : B::ORD ? 128u : 64u, sgp);
+    load_rows(rows, tables, sg.table_idx, B::TABLE ? IMG_END / 16u : B::ORD ? 128u : 64u, sgp);
     WWR<NB> s;
     uint32_t cache;
     if (NB <= 8 && !SINGLE) {
@@ -170,7 +172,7 @@ __device__ __forceinline__ void run_ww(const SegDev *__restrict__ sgp, const Ste
     auto fresh_room = [&]() {
         uint32_t ir[20];
         if (!LOWOCC && !SINGLE) {
-            const u32x4 *p = reinterpret_cast<const u32x4 *>(rows) + 256;
+            const u32x4 *p = reinterpret_cast<const u32x4 *>(rows) + IMG_END / 16u;
 #pragma unroll
             for (int j = 0; j < (WWR<NB>::NREGS + 3) / 4; j++) { const u32x4 v = p[j]; ir[4 * j] = v.x; ir[4 * j + 1] = v.y; ir[4 * j + 2] = v.z; ir[4 * j + 3] = v.w; }
         } else {
@@ -287,7 +289,7 @@ __device__ __forceinline__ void run_tt(const SegDev *__restrict__ sgp, const Ste
     auto fresh_room = [&]() {
         uint32_t ir[20];
         if (QUEUE && !LOWOCC && !SINGLE) {
-            const u32x4 *p = reinterpret_cast<const u32x4 *>(rows) + 256;
+            const u32x4 *p = reinterpret_cast<const u32x4 *>(rows) + IMG_END / 16u;
 #pragma unroll
             for (int j = 0; j < (TT<NB>::NREGS + 3) / 4; j++) { const u32x4 v = p[j]; ir[4 * j] = v.x; ir[4 * j + 1] = v.y; ir[4 * j + 2] = v.z; ir[4 * j + 3] = v.w; }
         } else {
@@ -363,8 +365,9 @@ __device__ __forceinline__ void run_kind(const SegDev *__restrict__ sg, const St
 
 // LDS of a step block is sized at launch (a 64-room block must not pay for four wavefronts' queues, or
 // LDS, not registers, caps the wavefronts per CU)
-constexpr uint32_t LDS_NTH8 = 2048;
-static_assert(offsetof(DevTable, ord8) == LDS_ROWS && offsetof(DevTable, nth8) == LDS_ROWS + LDS_ORD8, "DevTable leads with the LDS image");
+constexpr uint32_t LDS_NTH8 = IMG_END - IMG_NTH8;             // nth8 + the vote tables
+static_assert(offsetof(DevTable, ord8) == IMG_ORD8 && offsetof(DevTable, nth8) == IMG_NTH8 && offsetof(DevTable, spread8) == IMG_SPREAD8 &&
+              offsetof(DevTable, tally64) == IMG_TALLY && offsetof(DevTable, n_phases) == IMG_END, "DevTable leads with the LDS image");
 static_assert(sizeof(WaveLds) % 16 == 0 && sizeof(WaveLdsLow) % 16 == 0 && LDS_ROWS % 16 == 0 && LDS_ORD8 % 16 == 0, "LDS sections stay 16-byte aligned");
 
 inline uint32_t step_lds_bytes(bool queue, bool lowocc, uint32_t block_threads) {
@@ -378,17 +381,18 @@ extern __shared__ __align__(16) unsigned char ge_lds[];
 // gets its own register allocation
 // GENERIC: some row of the table has a generic target condition (DevCond); single-game batches get both forms of those
 // builds as well, a mixed batch with a generic table runs the large-batch form at every size
-// minimum wavefronts per SIMD asked of the register allocator for the large-batch Werewolf builds (see GE_SHADOW_HI)
+// Minimum wavefronts per SIMD asked of the register allocator for the large-batch Werewolf builds (tuning constants;
+// tools/ab_switches.sh builds other values).  Werewolf x 12: 7 = 72 VGPRs, no scratch (round 2 held it to 6 = 80 VGPRs with a
+// 2-register spill); Werewolf x 8 needs 62 VGPRs = 8 wavefronts per SIMD without being asked.
 #ifndef GE_WW12_WAVES
-#define GE_WW12_WAVES 6
+#define GE_WW12_WAVES 7
 #endif
 #ifndef GE_WW8_WAVES
 #define GE_WW8_WAVES 1
 #endif
 // SINGLE: the launch is one turn (a.n_turns == 1) of a single-game batch with shipped-grammar conditions (run_ww / run_tt)
 template <int KIND, bool LOWOCC, bool GENERIC = false, bool SINGLE = false>
-__global__ void __launch_bounds__(256, (KIND == K_WW12 && !LOWOCC && !GENERIC) ? GE_WW12_WAVES : (KIND == K_WW8 && !LOWOCC && !GENERIC) ? GE_WW8_WAVES : 1) ge_step_kernel(const StepArgs a, const SegDev *__restrict__ segs,
-                                                      const DevTable *__restrict__ tables) {
+__global__ void __launch_bounds__(256, (KIND == K_WW12 && !LOWOCC && !GENERIC) ? GE_WW12_WAVES : (KIND == K_WW8 && !LOWOCC && !GENERIC) ? GE_WW8_WAVES : 1) ge_step_kernel(const SegDev *__restrict__ segs, const DevTable *__restrict__ tables, const StepArgs a) {
     constexpr bool WWK = KIND == K_WW8 || KIND == K_WW12 || tt_uses_queue(KIND == K_TT4 ? 4 : KIND == K_TT8 ? 8 : 12, LOWOCC);   // uses the action queue
     DevRow *rows = reinterpret_cast<DevRow *>(ge_lds);
     uint8_t *nth8 = ge_lds + LDS_ROWS + LDS_ORD8;
@@ -399,8 +403,7 @@ __global__ void __launch_bounds__(256, (KIND == K_WW12 && !LOWOCC && !GENERIC) ?
 
 // mixed batch: several segments (games / player counts) in one launch
 template <bool LOWOCC, bool GENERIC = false>
-__global__ void __launch_bounds__(256) ge_step_kernel_mixed(const StepArgs a, const SegDev *__restrict__ segs,
-                                                            const DevTable *__restrict__ tables) {
+__global__ void __launch_bounds__(256) ge_step_kernel_mixed(const SegDev *__restrict__ segs, const DevTable *__restrict__ tables, const StepArgs a) {
     DevRow *rows = reinterpret_cast<DevRow *>(ge_lds);
     uint8_t *nth8 = ge_lds + LDS_ROWS + LDS_ORD8;
     auto *wl = reinterpret_cast<typename WaveLdsOf<LOWOCC>::type *>(ge_lds + LDS_ROWS + LDS_ORD8 + (LOWOCC ? 0u : LDS_NTH8 + LDS_S0));
@@ -1153,6 +1156,7 @@ static int create_impl(const ge_batch_desc *desc, ge_batch **out, const uint64_t
                 dt.n_phases = s.table.n_phases; dt.rounds = s.table.rounds; dt.n_players = (int32_t)s.dev.n_players;
                 fill_nth8_host(dt.nth8);
                 fill_ord8_host(dt.ord8);
+                fill_vote_luts_host(dt.spread8, dt.tally64);
                 // the initial record: player_states_template for every player, phase id 0 (utils.py:642-647)
                 ge_room_view v;
                 memset(&v, 0, sizeof v);
@@ -1212,7 +1216,7 @@ static int reset_impl(ge_batch *b) {
 
 static hipError_t launch_step(const ge_batch *b, const StepArgs &a, hipStream_t st) {
     const dim3 grid(b->n_blocks), block(b->block_threads);
-#define GE_LAUNCH(KERNEL, QUEUE, LOW) hipLaunchKernelGGL(KERNEL, grid, block, step_lds_bytes(QUEUE, LOW, b->block_threads), st, a, b->segs_dev, b->tables)
+#define GE_LAUNCH(KERNEL, QUEUE, LOW) hipLaunchKernelGGL(KERNEL, grid, block, step_lds_bytes(QUEUE, LOW, b->block_threads), st, b->segs_dev, b->tables, a)
     const bool low = a.lowocc != 0u && !(b->generic && b->segs.size() > 1);   // mixed batches with generic tables: the large-batch build serves every size
     if (b->generic) {
         // generic target conditions: single-game batches get both forms too; mixed batches the large-batch one
