@@ -12,7 +12,7 @@ build)
   mkdir -p game_engine_amd/ab
   for v in "${VARIANTS[@]}"; do
     name=${v%%:*}; flag=${v#*:}
-    ( cd game_engine_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -mllvm -amdgpu-kernarg-preload-count=4 $flag -shared -o ../ab/sw_$name.so ge_step.hip ge_table.cpp -ldl ) \
+    ( cd game_engine_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -mllvm -amdgpu-kernarg-preload-count=4 -falign-loops=128 $flag -shared -o ../ab/sw_$name.so ge_step.hip ge_table.cpp -ldl ) \
       && echo "built sw_$name.so ($flag)" || echo "BUILD FAILED $name"
   done ;;
 test)

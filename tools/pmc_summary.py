@@ -7,6 +7,9 @@
                                   guide says: FETCH_SIZE is in KiB and reads HALF the bytes of a 16 B/lane
                                   coalesced stream on gfx950 -> x2; WRITE_SIZE is exact), instructions per
                                   wave-turn and the SQ_WAIT_ANY share of SQ_WAVE_CYCLES
+A key ending in _k1 selects the SINGLE-TURN kernel instantiations (ge_step_kernel<.., true>): the profiled command is the
+plain bench line of the shape, whose `hbm_streaming` part replays hipGraphs of back-to-back single-turn launches - the
+sustained regime - so the kernel-trace average of those launches is what the committed *_k1_kernel_stats.csv holds.
 usage: pmc_summary.py <rocprof output dir> <tag> <key>"""
 import csv, glob, json, os, shutil, statistics, sys
 
@@ -32,13 +35,27 @@ for b in ("bench_kt.json", "bench_sq.json", "bench_fetch.json"):
             pass
 cfg = bench.get("config", {})
 rooms = int(cfg.get("rooms_per_gpu", 65536))
-fuse = int(cfg.get("turns_fused_per_launch", 1024))
-bpr = float(cfg.get("bytes_per_room_record", 32))
-waves = (rooms + 63) // 64
+single = key.endswith("_k1")
+fuse = 1 if single else int(cfg.get("turns_fused_per_launch", 1024))
+
+
+def wanted(kernel_name):
+    """the step kernel instantiations this key is about: ge_step_kernel<KIND, LOWOCC, GENERIC, SINGLE> (or _mixed<..>)"""
+    import re
+    m = re.search(r"ge_step_kernel(_mixed)?<([^>]*)>", kernel_name)
+    if not m:
+        return False
+    args = [a.strip() for a in m.group(2).split(",")]
+    is_single = not m.group(1) and len(args) >= 4 and args[3] == "true"
+    return is_single == single
+
 
 ks = one("kt/**/*_kernel_stats.csv")
 if ks:
     shutil.copy(ks, os.path.join(prof, f"{tag}_{key}_kernel_stats.csv"))
+    for r in csv.DictReader(open(ks)):
+        if wanted(r["Name"]):
+            print(f"kernel-trace: {r['Name'][:70]}... calls {r['Calls']} avg {float(r['AverageNs']):.0f} ns")
 
 
 def counters(sub):
@@ -47,7 +64,7 @@ def counters(sub):
     if not f:
         return out
     for r in csv.DictReader(open(f)):
-        if "ge_step_kernel" not in r["Kernel_Name"]:
+        if not wanted(r["Kernel_Name"]):
             continue
         dur = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
         out.setdefault(r["Counter_Name"], []).append((float(r["Counter_Value"]), dur))
@@ -67,7 +84,12 @@ for name, vals in allc.items():
                  "median_duration_ns_profiled": statistics.median(d for _, d in big)}
 sys.path.insert(0, root)
 from game_engine_amd._lib import kernel_source_hash
-pmc = {"tag": tag, "key": key, "rooms": rooms, "turns_per_launch": fuse, "kernel_src_sha256": kernel_source_hash(),
+kt_avg = None
+if ks:
+    for r in csv.DictReader(open(ks)):
+        if wanted(r["Name"]):
+            kt_avg = {"kernel": r["Name"][:r["Name"].find(">(") + 1], "calls": int(r["Calls"]), "average_ns": float(r["AverageNs"])}
+pmc = {"tag": tag, "key": key, "rooms": rooms, "turns_per_launch": fuse, "kernel_src_sha256": kernel_source_hash(), "kernel_trace": kt_avg,
        "state_bytes_read_plus_written": 2.0 * bpr * rooms,
        "command": "bench.py " + " ".join(sys.argv[4:]) if len(sys.argv) > 4 else None}
 if "FETCH_SIZE" in res and "WRITE_SIZE" in res:
