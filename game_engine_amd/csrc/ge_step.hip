@@ -104,17 +104,32 @@ __device__ __forceinline__ void store_event(uint32_t *trace, uint64_t rooms_padd
 // load inside the branch 8.12 / 21.28 / 4.88 (1 M x 8 / 2 M x 12 / 1 M Two-Truths x 4); LDS copy 7.90 / 21.09 / 4.68.
 constexpr uint32_t LDS_S0 = 128;       // 20 words of init_regs, padded
 
-// Fills the block's LDS tables: DevTable starts with rows | ord8 | nth8 in the LDS order, so the first `n16` 16-byte
-// elements are one linear copy (64 = the phase rows, 128 = + ord8, 256 = + nth8); one element per thread and pass
-__device__ __forceinline__ void load_rows(DevRow *rows, const DevTable *tables, uint32_t table_idx, uint32_t n16, const SegDev *sg = nullptr) {
+// Fills the block's LDS tables: DevTable starts with rows | ord8 | nth8 | spread8 | tally64 in the LDS order, so the first
+// N16 16-byte elements are one linear copy (64 = the phase rows, 128 = + ord8, 256 = + nth8, 448 = + the vote tables), one
+// element per thread and pass.  All passes' loads are issued before the first LDS write (a load -> wait -> write loop
+// serialises one L2 round trip per pass in front of every wavefront of a single-turn launch); the large-batch builds also
+// copy the restart template behind the image.
+template <uint32_t N16, bool WITH_S0>
+__device__ __forceinline__ void load_rows(DevRow *rows, const DevTable *tables, uint32_t table_idx, const SegDev *sg) {
     const u32x4 *src = reinterpret_cast<const u32x4 *>(tables + table_idx);
     u32x4 *dst = reinterpret_cast<u32x4 *>(rows);
-    if (sg && n16 >= 256u && threadIdx.x < 5u)                 // large-batch builds: the restart template behind the image
-        dst[IMG_END / 16u + threadIdx.x] = reinterpret_cast<const u32x4 *>(sg->init_regs)[threadIdx.x];
-    for (uint32_t base = 0; base < n16; base += blockDim.x) {   // uniform trip count: 1 for 256-room blocks
-        const uint32_t i = base + threadIdx.x;
-        if (i < n16) dst[i] = src[i];
+    const uint32_t bd = blockDim.x, tid = threadIdx.x;
+    // the restart template behind the image (large-batch turn loops; a single-turn build reads it through the scalar cache)
+    const u32x4 t0 = WITH_S0 ? reinterpret_cast<const u32x4 *>(sg->init_regs)[tid < 5u ? tid : 4u] : u32x4{0u, 0u, 0u, 0u};
+    if (bd == 256u) {                                          // wave-uniform: the block size of every large batch
+        constexpr uint32_t P = (N16 + 255u) / 256u;
+        u32x4 t[P];
+#pragma unroll
+        for (uint32_t p = 0; p < P; p++) { const uint32_t i = p * 256u + tid; t[p] = src[i < N16 ? i : N16 - 1u]; }   // loads are not predicated (clamped index)
+#pragma unroll
+        for (uint32_t p = 0; p < P; p++) { const uint32_t i = p * 256u + tid; if (i < N16) dst[i] = t[p]; }
+    } else {
+        for (uint32_t base = 0; base < N16; base += bd) {
+            const uint32_t i = base + tid;
+            if (i < N16) dst[i] = src[i];
+        }
     }
+    if (WITH_S0 && tid < 5u) dst[IMG_END / 16u + tid] = t0;
     __syncthreads();
 }
 
@@ -154,7 +169,7 @@ __device__ __forceinline__ void run_ww(const SegDev *__restrict__ sgp, const Ste
     load_words<L::WORDS>(sg.base, sg.rooms_padded, room, w);      // in flight while the block fills its LDS tables
     // the slot -> player table of the action queue sits right behind the phase rows (step_lds_bytes)
     uint32_t *ord8 = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(rows) + LDS_ROWS);
-    load_rows(rows, tables, sg.table_idx, B::TABLE ? IMG_END / 16u : B::ORD ? 128u : 64u, sgp);
+    load_rows<B::TABLE ? IMG_END / 16u : B::ORD ? 128u : 64u, !LOWOCC && !SINGLE>(rows, tables, sg.table_idx, sgp);
     WWR<NB> s;
     uint32_t cache;
     if (NB <= 8 && !SINGLE) {
@@ -281,7 +296,7 @@ __device__ __forceinline__ void run_tt(const SegDev *__restrict__ sgp, const Ste
     const uint64_t room = valid ? room_in : 0;
     uint32_t w[L::WORDS];
     load_words<L::WORDS>(sg.base, sg.rooms_padded, room, w);
-    load_rows(rows, tables, sg.table_idx, (QUEUE && !LOWOCC) ? 256u : 64u, sgp);
+    load_rows<(QUEUE && !LOWOCC) ? 256u : 64u, QUEUE && !LOWOCC && !SINGLE>(rows, tables, sg.table_idx, sgp);
     TT<NB> s;
     L::unpack(w, s);
     const uint32_t rk = room_key_from(a.seed_key, sg.first_global + room);

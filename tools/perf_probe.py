@@ -15,7 +15,9 @@ specs = sys.argv[1:] or ["ww:8:65536", "ww:8:1048576", "ww:12:2097152", "tt:4:10
 for spec in specs:
     g, n, rooms = spec.split(":"); n, rooms = int(n), int(rooms)
     tb = GameTable(dsl(SHORT[g]))
-    for fuse, steps in ((64, 1024), (1, 256)):
+    # PROBE_FUSE="1024:4096,64:1024": fuse:steps pairs (default: 64 turns per launch over 1 024 turns, and single-turn launches)
+    pairs = [tuple(int(x) for x in p.split(":")) for p in os.environ.get("PROBE_FUSE", "64:1024,1:256").split(",")]
+    for fuse, steps in pairs:
         b = RoomBatch([(tb, n, rooms)], seed=0xC0FFEE, max_fuse=fuse, restart=True)
         b.step(256); b.sync()
         b.set_timing(True); b.kernel_time(reset=True)

@@ -37,6 +37,8 @@ cfg = bench.get("config", {})
 rooms = int(cfg.get("rooms_per_gpu", 65536))
 single = key.endswith("_k1")
 fuse = 1 if single else int(cfg.get("turns_fused_per_launch", 1024))
+bpr = float(cfg.get("bytes_per_room_record", 32))
+waves = (rooms + 63) // 64
 
 
 def wanted(kernel_name):
