@@ -418,7 +418,7 @@ __global__ void __launch_bounds__(256, (KIND == K_WW12 && !LOWOCC && !GENERIC) ?
 
 // mixed batch: several segments (games / player counts) in one launch
 template <bool LOWOCC, bool GENERIC = false>
-__global__ void __launch_bounds__(256) ge_step_kernel_mixed(const SegDev *__restrict__ segs, const DevTable *__restrict__ tables, const StepArgs a) {
+__global__ void __launch_bounds__(256, (!LOWOCC && !GENERIC) ? GE_WW12_WAVES : 1) ge_step_kernel_mixed(const SegDev *__restrict__ segs, const DevTable *__restrict__ tables, const StepArgs a) {
     DevRow *rows = reinterpret_cast<DevRow *>(ge_lds);
     uint8_t *nth8 = ge_lds + LDS_ROWS + LDS_ORD8;
     auto *wl = reinterpret_cast<typename WaveLdsOf<LOWOCC>::type *>(ge_lds + LDS_ROWS + LDS_ORD8 + (LOWOCC ? 0u : LDS_NTH8 + LDS_S0));
@@ -549,6 +549,19 @@ __global__ void __launch_bounds__(256) ge_fill_kernel(const SegDev *__restrict__
                 }
             }
         }
+    }
+}
+
+// ---- the prepared-deal cache of the Werewolf x 8 records (word 7, upper half) <- empty.  A cached deal is a function of
+// (seed, global room index, game index); records copied in raw from somewhere else (ge_batch_state) may carry deals of
+// another seed or room range, so ge_batch_set_turn - the call that completes a raw restore - drops them all.
+__global__ void __launch_bounds__(256) ge_clear_deal_cache(const SegDev *__restrict__ segs, uint32_t n_seg) {
+    for (uint32_t k = 0; k < n_seg; k++) {
+        const SegDev &sg = segs[k];
+        if (sg.kind != K_WW8) continue;
+        uint32_t *plane1 = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(sg.base) + plane_offset(sg.rooms_padded, 1));
+        for (uint64_t room = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; room < sg.rooms_padded; room += (uint64_t)gridDim.x * blockDim.x)
+            plane1[4u * room + 3u] &= WWLayout<8>::CHECKSUM_MASK7;            // word 7 = plane 1, element word 3
     }
 }
 
@@ -1549,6 +1562,14 @@ int ge_batch_set_turn(ge_batch *b, uint64_t turn) {
         int st = sync_impl(b);
         if (st != GE_OK) return st;
         b->turn = turn;                                    // the graph path re-seeds its device word when it differs
+        uint64_t most = 0;
+        for (const Segment &sg : b->segs) most = (sg.dev.kind == K_WW8 && sg.dev.rooms_padded > most) ? sg.dev.rooms_padded : most;
+        if (most) {
+            const uint32_t blocks = (uint32_t)((most / 256u) < 2048u ? (most / 256u) : 2048u);
+            hipLaunchKernelGGL(ge_clear_deal_cache, dim3(blocks ? blocks : 1u), dim3(256), 0, b->last_stream, b->segs_dev, (uint32_t)b->segs.size());
+            HIP_TRY(hipGetLastError());
+            return sync_impl(b);
+        }
         return (int)GE_OK;
     });
 }

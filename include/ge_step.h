@@ -251,7 +251,7 @@ int ge_batch_reset(ge_batch *b);
  * the event trace are turn-based, so a checkpoint is (room records, turn): restore = create the
  * batch, ge_batch_write_rooms (or a copy into ge_batch_state), ge_batch_set_turn.  What the
  * reference's LangGraph checkpointer keeps per thread besides the state (the run counter).  Synchronises. */
-int ge_batch_set_turn(ge_batch *b, uint64_t turn);
+int ge_batch_set_turn(ge_batch *b, uint64_t turn);     /* (also drops the records' prepared-deal caches: a raw restore may come from another seed) */
 
 int ge_batch_sync(ge_batch *b);
 int ge_batch_turn(const ge_batch *b, uint64_t *turn);

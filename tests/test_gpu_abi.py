@@ -43,6 +43,34 @@ def test_set_turn_restores_raw_state_checkpoint(dsl_ww):
         assert e.value.status == -6
 
 
+def test_raw_restore_under_another_seed_drops_the_prepared_deals(dsl_ww):
+    """Werewolf x 8 records carry a prepared role deal (a cache keyed by seed, global room and game index) in their spare
+    half-word.  Raw planes copied into a batch with ANOTHER seed and room range must not deal from it: ge_batch_set_turn, the
+    call that completes a raw restore, drops the caches.  The continuation equals the oracle's from the same state."""
+    from parity_util import views_as_oracle_rooms
+    tb = GameTable(dsl_ww)
+    R = 6000
+    with RoomBatch([(tb, 8, R)], seed=9, first_room=77, max_fuse=1, restart=True) as a:
+        a.step(48)                                           # single-turn launches: deals are prepared into the records
+        a.sync()
+        views = a.read_rooms()
+        ptr, nbytes, _ = a.state(0)
+        raw = np.empty(nbytes, dtype=np.uint8)
+        assert _hip().hipMemcpy(C.c_void_p(raw.ctypes.data), C.c_void_p(ptr), C.c_size_t(nbytes), 2) == 0
+    plane1 = raw.view(np.uint32).reshape(2, -1, 4)[1]        # words 4..7 of every (padded) room
+    assert (plane1[:R, 3] >> 16).any()                       # some room does carry a prepared deal
+    orc = Oracle(dsl_ww, 8)
+    for fuse in (1, 64):
+        with RoomBatch([(tb, 8, R)], seed=1234, first_room=5, max_fuse=fuse, restart=True) as b:
+            ptr, nbytes, _ = b.state(0)
+            assert _hip().hipMemcpy(C.c_void_p(ptr), C.c_void_p(raw.ctypes.data), C.c_size_t(nbytes), 1) == 0
+            b.set_turn(48)
+            b.step(60)
+            rooms = views_as_oracle_rooms(orc, views)
+            orc.run(rooms, 1234, 5, 48, 60, threads=0, restart=True)
+            assert_views_equal(b.read_rooms(), oracle_rooms_as_views(orc, rooms), f"raw restore under another seed, fuse {fuse}")
+
+
 def test_steps_on_alternating_streams_are_ordered(dsl_ww):
     """Consecutive ge_batch_step calls on different streams: the library orders them with an event, and
     reads wait for all of it."""

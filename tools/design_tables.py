@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Prints the measurement tables of DESIGN.md §4 / BASELINE.md §5 from the committed records: profiles/pmc_<shape>{,_k1}.json
+(tools/pmc_summary.py) and the driver-flags bench line profiles/<tag>_bench_n1_driver_flags.json.  usage: design_tables.py [tag]"""
+import json, os, sys
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+P = lambda k: json.load(open(os.path.join(root, "profiles", f"pmc_{k}.json")))
+bench = json.loads(open(os.path.join(root, "profiles", f"{tag}_bench_n1_driver_flags.json")).read().strip().splitlines()[-1])
+other = bench["other_shapes"]
+labels = {"c2": "C2: 65 536 Werewolf × 8 (1 wave/SIMD, ceiling 6.1·10¹¹)", "ww8_1048576": "1 048 576 Werewolf × 8",
+          "c4": "C4 share: 2 097 152 Werewolf × 12", "c3": "C3: 1 048 576 Two-Truths × 4"}
+okey = {"ww8_1048576": "1048576 Werewolf x8", "c4": "2097152 Werewolf x12 (one GPU's share of C4)", "c3": "1048576 Two-Truths x4 (C3)"}
+rooms = {"c2": 65536, "ww8_1048576": 1 << 20, "c4": 1 << 21, "c3": 1 << 20}
+
+print("| shape (fused, 1 024 turns/launch) | VALU + SALU + LDS per wave-turn | µs per turn | room-phase steps/s | issue frac (all / VALU only) | `SQ_WAIT_ANY` of wave cycles |\n|---|---|---|---|---|---|")
+for k in ("c2", "ww8_1048576", "c4", "c3"):
+    p = P(k); i = p["instructions_per_wave_turn"]
+    us = bench["roofline"]["avg_launch_us"] / 1024 if k == "c2" else other[okey[k]]["us_per_turn"]
+    waves = rooms[k] // 64
+    ceil = 1024 * 2.4e9 / (4.0 if waves / 1024 < 2 else 2.0)
+    wt = waves / (us * 1e-6)
+    tot = i["valu"] + i["salu"] + i["lds"]
+    print(f"| {labels[k]} | {i['valu']:.0f} + {i['salu']:.0f} + {i['lds']:.0f} | {us:.3f} | {rooms[k] / (us * 1e-6):.3g} | {tot * wt / ceil:.2f} / {i['valu'] * wt / ceil:.2f} | {100 * p['wait_any_frac']:.0f} % |")
+print()
+print("| shape (single-turn launches) | VALU + SALU + LDS per wave-turn | measured HBM bytes per launch (state read + written) | kernel-trace average (sustained) | % of 8 TB/s by kernel-trace | bench line: sustained / per-launch events | `SQ_WAIT_ANY` |\n|---|---|---|---|---|---|---|")
+for k in ("c2", "ww8_1048576", "c4", "c3"):
+    p = P(k + "_k1"); i = p["instructions_per_wave_turn"]; kt = p["kernel_trace"]
+    hs = bench["hbm_streaming"] if k == "c2" else other[okey[k]]["hbm_streaming"]
+    st = p["state_bytes_read_plus_written"]
+    print(f"| {labels[k].split(' (1 wave')[0]} | {i['valu']:.0f} + {i['salu']:.0f} + {i['lds']:.0f} | {p['hbm_bytes_per_launch'] / 1e6:.1f} MB ({st / 1e6:.1f}) | {kt['average_ns'] / 1e3:.2f} µs ({kt['calls']} launches) | **{100 * st / kt['average_ns'] / 8e3:.1f}** | {100 * hs['frac']:.1f} / {100 * hs['frac_kernel']:.1f} | {100 * p['wait_any_frac']:.0f} % |")
+print()
+print("| shape | fused (1 024 turns/launch): steps/s | alg. GB/s (% of 8 TB/s: a yardstick, not traffic) | single-turn launches: real HBM % of 8 TB/s (sustained) | CPU: oracle, steps/s (cores) |\n|---|---|---|---|---|")
+print(f"| C2: 65 536 Werewolf × 8 — the `bench.py` line | **{bench['value']:.3g}** (wall) | {bench['roofline']['achieved']:.0f} ({100 * bench['roofline']['frac']:.1f}) | {100 * bench['hbm_streaming']['frac']:.1f} (launch-bound: {bench['hbm_streaming']['us_per_launch_sustained']:.1f} µs per launch) | {bench['cpu_baseline']['value']:.3g} ({bench['cpu_baseline']['cores']}); one thread {bench['cpu_baseline']['single_thread_value']:.3g} |")
+for k in ("ww8_1048576", "c4", "c3"):
+    v = other[okey[k]]
+    print(f"| {labels[k]} | {v['value']:.3g} | {v['algorithmic_GBs']:.0f} ({100 * v['algorithmic_frac']:.0f}) | **{100 * v['hbm_streaming']['frac']:.1f}** ({v['hbm_streaming']['us_per_launch_sustained']:.2f} µs per launch) | {v['cpu_baseline']['value']:.3g} ({v['cpu_baseline']['cores']}) |")
