@@ -95,6 +95,33 @@ def _init_fields(table: T.Table) -> List[int]:
     return f + [0]
 
 
+_CORES = None
+
+
+def usable_cores() -> int:
+    """Threads this process may run at once: the affinity mask, capped by the cgroup CPU quota."""
+    global _CORES
+    if _CORES is None:
+        n = len(os.sched_getaffinity(0))
+        for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+            try:
+                with open(path) as f:
+                    parts = f.read().split()
+                if path.endswith("cpu.max"):
+                    if parts[0] != "max":
+                        n = min(n, max(1, -(-int(parts[0]) // int(parts[1]))))
+                else:
+                    q = int(parts[0])
+                    if q > 0:
+                        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                            n = min(n, max(1, -(-q // int(g.read().split()[0]))))
+                break
+            except (OSError, ValueError, IndexError):
+                continue
+        _CORES = n
+    return _CORES
+
+
 class Oracle:
     def __init__(self, dsl: dict, n_players: int, rounds: int = 1):
         self.table = T.compile_dsl(dsl, rounds=rounds)
@@ -134,7 +161,12 @@ class Oracle:
 
     def run(self, rooms: np.ndarray, seed: int, first_room: int, first_turn: int, n_turns: int,
             threads: int = 1, restart: bool = False, human_mask: int = 0) -> None:
+        """threads = 0: as many as this process may really run at once (affinity mask capped by the cgroup CPU quota - a
+        GPU box grants 16 cores of a 256-thread host, and an OpenMP team of 256 costs 0.1 s per call), and no more than
+        the work is worth (one per 4 096 room-turns)."""
         assert rooms.dtype == ROOM_DTYPE and rooms.flags.c_contiguous
+        if threads == 0:
+            threads = max(1, min(usable_cores(), len(rooms) * max(n_turns, 1) // 4096))
         lib().orc_run(C.byref(self.ct), seed, first_room, len(rooms), first_turn, n_turns,
                       rooms.ctypes.data, threads, int(restart), human_mask)
 
