@@ -155,6 +155,10 @@ __device__ __forceinline__ void load_init_regs(const SegDev &sg, uint32_t *ir) {
     }
 }
 
+// a 12-player game lasts ~65 turns against ~40 for 8 players: deals are prepared half as often there
+// (profiles/r03_ab_deal_period_12.txt: every 16th / 32nd / 64th turn = 18.37 / 18.21 / 19.53 us per turn at 2 M x 12)
+template <int NB> constexpr uint32_t deal_period() { return NB <= 8 ? GE_DEAL_PERIOD : 2u * GE_DEAL_PERIOD; }
+
 template <int NB, bool LOWOCC, bool GENERIC, bool SINGLE>
 __device__ __forceinline__ void run_ww(const SegDev *__restrict__ sgp, const StepArgs &a, DevRow *rows, void *lw,
                                        uint8_t *nth8, const DevTable *__restrict__ tables, uint64_t room_in) {
@@ -257,7 +261,7 @@ __device__ __forceinline__ void run_ww(const SegDev *__restrict__ sgp, const Ste
                 const uint32_t p = s.phase;
                 uint32_t ev_newly = 0;
                 uint64_t ev_choice = 0;
-                const bool deal_now = ahead && ((deal_phase + t) & (GE_DEAL_PERIOD - 1u)) == 0u;        // wave-uniform
+                const bool deal_now = ahead && ((deal_phase + t) & (deal_period<NB>() - 1u)) == 0u;    // wave-uniform
                 ww_turn<NB, LOWOCC, GENERIC, false>(s, row, ctx, turn0 + t, tk, trace, deal, deal_now, ev_newly, ev_choice, (GE_STAMPS && a.stamps) ? &stamps : nullptr);
                 if (trace && valid) store_event(sg.trace, sg.rooms_padded, t, room, turn0 + t, p, s.phase, restarted, ev_newly, ev_choice);
             }
