@@ -87,6 +87,26 @@ def test_werewolf_from_random_states(dsl_ww, n, consistent, R):
             assert_views_equal(b.read_rooms(), oracle_rooms_as_views(orc, rooms), f"n={n} after turn {b.turn}")
 
 
+@pytest.mark.parametrize("n,R,fuse", [(8, 20000, 1), (8, 20000, 16), (8, 150000, 1), (12, 20000, 1), (12, 120000, 8), (5, 20000, 1)])
+def test_werewolf_random_states_played_on_in_steady_state(dsl_ww, n, R, fuse):
+    """From random (mostly unreachable) states through whole games with recycling: single-turn launches (their own kernel
+    builds; for N <= 8 they prepare role deals into the records' spare half-word) mixed with fused ones, finished rooms
+    restarted from the template, roles dealt again - every block of turns against the oracle."""
+    seed, first = 4242, 1 << 35
+    rng = np.random.default_rng(n * 31 + R % 7 + fuse)
+    orc = _oracle(dsl_ww, n)
+    views = _random_ww_views(orc, n, R, rng, consistent=False)
+    rooms = views_as_oracle_rooms(orc, views)
+    with RoomBatch([(GameTable(dsl_ww), n, R)], seed=seed, first_room=first, max_fuse=fuse, restart=True) as b:
+        b.step(3)
+        b.write_rooms(0, views)
+        for chunk in (1, 1, 17, 1, 40, 2, 64, 1, 33):
+            b.step(chunk)
+            orc.run(rooms, seed, first, b.turn - chunk, chunk, threads=0, restart=True)
+            assert_views_equal(b.read_rooms(), oracle_rooms_as_views(orc, rooms), f"n={n} fuse={fuse} after turn {b.turn}")
+        assert int(rooms["games"].max()) >= 2                       # rooms did finish and start again
+
+
 @pytest.mark.parametrize("n,rounds", [(4, 1), (3, 2), (8, 3), (12, 2)])
 def test_two_truths_from_random_states(dsl_tt, n, rounds):
     R, seed, first = 20000, 5, 1 << 40
