@@ -65,13 +65,13 @@ _lib = None
 
 
 def kernel_source_hash() -> str:
-    """sha256 over the sources libge_step.so is built from: what ties a committed counter profile (profiles/pmc_*.json,
+    """sha256 over the sources libge_step.so is built from (and the Makefile, whose compiler flags shape the kernels): what ties a committed counter profile (profiles/pmc_*.json,
     tools/pmc_summary.py) to the kernels it was measured on (bench.py does not quote a profile of other sources)."""
     import hashlib
     h = hashlib.sha256()
     src = os.path.join(_HERE, "csrc")
     for name in sorted(os.listdir(src)):
-        if name.endswith((".hip", ".h", ".inl", ".cpp")):
+        if name.endswith((".hip", ".h", ".inl", ".cpp")) or name == "Makefile":
             with open(os.path.join(src, name), "rb") as f:
                 h.update(name.encode() + b"\0" + f.read())
     return h.hexdigest()
