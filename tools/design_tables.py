@@ -34,3 +34,23 @@ print(f"| C2: 65 536 Werewolf × 8 — the `bench.py` line | **{bench['value']:.
 for k in ("ww8_1048576", "c4", "c3"):
     v = other[okey[k]]
     print(f"| {labels[k]} | {v['value']:.3g} | {v['algorithmic_GBs']:.0f} ({100 * v['algorithmic_frac']:.0f}) | **{100 * v['hbm_streaming']['frac']:.1f}** ({v['hbm_streaming']['us_per_launch_sustained']:.2f} µs per launch) | {v['cpu_baseline']['value']:.3g} ({v['cpu_baseline']['cores']}) |")
+print()
+# BASELINE.md's round table: one row per shape
+blabels = {"c2": "C2 65 536 Werewolf×8", "ww8_1048576": "1 048 576 Werewolf×8", "c4": "C4 share 2 097 152 Werewolf×12", "c3": "C3 1 048 576 Two-Truths×4"}
+for k in ("c2", "ww8_1048576", "c4", "c3"):
+    p = P(k); i = p["instructions_per_wave_turn"]; q = P(k + "_k1")
+    us = bench["roofline"]["avg_launch_us"] / 1024 if k == "c2" else other[okey[k]]["us_per_turn"]
+    waves = rooms[k] // 64
+    ceil = 1024 * 2.4e9 / (4.0 if waves / 1024 < 2 else 2.0)
+    wt = waves / (us * 1e-6)
+    issue = f"{(i['valu'] + i['salu'] + i['lds']) * wt / ceil:.2f} / {i['valu'] * wt / ceil:.2f}"
+    kt = 100 * q["state_bytes_read_plus_written"] / q["kernel_trace"]["average_ns"] / 8e3
+    fused_mb = f"{p['hbm_bytes_per_launch'] / 1e6:.2f} MB" if k == "c2" else f"{p['hbm_bytes_per_launch'] / 1e6:.1f} MB"
+    if k == "c2":
+        r = bench["roofline"]; hs = bench["hbm_streaming"]; cb = bench["cpu_baseline"]
+        print(f"| {blabels[k]} | **{bench['value']:.3g}** (`roofline.frac` {r['frac']:.4f}; {r['avg_launch_us']:.0f} µs per 1 024-turn launch) | {r['achieved']:.0f} ({100 * r['frac']:.1f}) | {issue} | "
+              f"{kt:.1f} / {100 * hs['frac']:.1f} (launch-bound: {hs['us_per_launch_sustained']:.1f} µs per launch) | {fused_mb} | {cb['value']:.3g} (one thread {cb['single_thread_value']:.3g}) |")
+    else:
+        v = other[okey[k]]
+        note = " (= the state: no scratch any more)" if k == "c4" else ""
+        print(f"| {blabels[k]} | {v['value']:.3g} | {v['algorithmic_GBs']:.0f} ({100 * v['algorithmic_frac']:.0f}) | {issue} | **{kt:.1f}** / {100 * v['hbm_streaming']['frac']:.1f} | {fused_mb}{note} | {v['cpu_baseline']['value']:.3g} |")
