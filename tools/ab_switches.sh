@@ -12,7 +12,8 @@ build)
   mkdir -p game_engine_amd/ab
   for v in "${VARIANTS[@]}"; do
     name=${v%%:*}; flag=${v#*:}
-    ( cd game_engine_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -mllvm -amdgpu-kernarg-preload-count=4 -falign-loops=128 $flag -shared -o ../ab/sw_$name.so ge_step.hip ge_table.cpp -ldl ) \
+    # the Makefile's own compile line (make -n), with the switch added and the output beside the product library
+    ( cd game_engine_amd/csrc && cmd=$(make -n -B | grep -m1 -- "-shared") && eval "${cmd/-shared -o ..\/libge_step.so/$flag -shared -o ../ab/sw_$name.so}" ) \
       && echo "built sw_$name.so ($flag)" || echo "BUILD FAILED $name"
   done ;;
 test)
