@@ -9,8 +9,11 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sched.h>
 #include <algorithm>
+#include <atomic>
 #include <new>
+#include <thread>
 #include <type_traits>
 #include <vector>
 
@@ -983,6 +986,8 @@ struct ge_batch {
     unsigned long long *stamps_dev = nullptr;   // GE_STAMPS diagnostic build only
     void *inj_buf = nullptr;          // device scratch of ge_batch_inject_actions
     size_t inj_cap = 0;
+    void *io_buf = nullptr;           // pinned staging of ge_batch_read_rooms / write_rooms (packed planes of the range)
+    size_t io_cap = 0;
     // hipGraph replay of launch-bound step sequences (many short launches per ge_batch_step call)
     uint32_t *turn_dev = nullptr;     // turn base the captured launches read
     uint64_t turn_dev_value = ~0ull;  // what *turn_dev holds (host mirror)
@@ -1389,43 +1394,108 @@ static int kernel_time_impl(ge_batch *b, int reset, double *total_ms, uint64_t *
     return GE_OK;
 }
 
+// Host side of ge_batch_read_rooms / write_rooms.  What crosses PCIe is the packed record (32 - 48 B per room, plane by plane,
+// through a pinned staging buffer); the canonical view (228 B per room) is built from it / folded into it by the host cores, rooms
+// split over a few threads - a single thread converts ~20 M rooms/s, which made a 1 M-room read 53 ms against 3 ms of copies.
+static unsigned io_workers(uint64_t rooms) {
+    unsigned n = 16;
+    if (const char *e = getenv("GE_IO_THREADS")) n = (unsigned)atoi(e);
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) n = std::min<unsigned>(n, (unsigned)CPU_COUNT(&set));
+    const uint64_t by_size = rooms / 16384u + 1u;                 // a thread is worth starting for >= 16 K rooms
+    return (unsigned)std::max<uint64_t>(1u, std::min<uint64_t>(n, by_size));
+}
+
+template <class F> static void for_room_ranges(uint64_t rooms, F &&f) {   // f(lo, hi) over disjoint ranges, on the calling thread too
+    const unsigned n = io_workers(rooms);
+    if (n <= 1) { f((uint64_t)0, rooms); return; }
+    const uint64_t per = (rooms + n - 1) / n;
+    std::vector<std::thread> th;
+    th.reserve(n - 1);
+    for (unsigned t = 1; t < n; t++) {
+        const uint64_t lo = std::min<uint64_t>(rooms, t * per), hi = std::min<uint64_t>(rooms, lo + per);
+        if (lo < hi) th.emplace_back([&f, lo, hi] { f(lo, hi); });
+    }
+    f((uint64_t)0, std::min<uint64_t>(rooms, per));
+    for (std::thread &x : th) x.join();
+}
+
+static int io_stage(ge_batch *b, size_t bytes, uint32_t **out) {          // pinned, grown on demand, freed with the batch
+    if (bytes > b->io_cap) {
+        if (b->io_buf) (void)hipHostFree(b->io_buf);
+        b->io_buf = nullptr; b->io_cap = 0;
+        HIP_TRY(hipHostMalloc(&b->io_buf, bytes, hipHostMallocDefault));
+        b->io_cap = bytes;
+    }
+    *out = static_cast<uint32_t *>(b->io_buf);
+    return GE_OK;
+}
+
 static int rooms_io(ge_batch *b, uint64_t first, uint64_t count, ge_room_view *dst, const ge_room_view *src) {
     if (first + count > b->n_rooms || first + count < first) return GE_ERR_RANGE;
     GE_ON_DEVICE(b);
     int st = sync_impl(b);
     if (st != GE_OK) return st;
+    struct Part { Segment *s; uint64_t lo, r0, nr; };
+    std::vector<Part> parts;
     for (Segment &s : b->segs) {
         const uint64_t lo = first > s.local_first ? first : s.local_first;
         const uint64_t hi = (first + count) < (s.local_first + s.dev.rooms) ? (first + count) : (s.local_first + s.dev.rooms);
-        if (lo >= hi) continue;
-        const uint64_t r0 = lo - s.local_first, nr = hi - lo;
+        if (lo < hi) parts.push_back({&s, lo, lo - s.local_first, hi - lo});
+    }
+    if (src) {                                                   // nothing is written unless every view fits its segment
+        for (const Part &p : parts) {
+            std::atomic<int> bad{0};
+            const ge_room_view *v = src + (p.lo - first);
+            const uint32_t n = p.s->dev.n_players;
+            for_room_ranges(p.nr, [&](uint64_t a, uint64_t z) {
+                for (uint64_t r = a; r < z; r++) {
+                    bool ok = v[r].n_players == n;
+                    if (ok && v[r].pack == GE_PACK_WEREWOLF)             // werewolf role classes are 0 (unassigned) .. 4
+                        for (uint32_t i = 0; i < n && i < 16u; i++) ok &= v[r].players[i][0] <= 4;
+                    if (!ok) { bad.store(1, std::memory_order_relaxed); return; }
+                }
+            });
+            if (bad.load()) return GE_ERR_ARG;
+        }
+    }
+    for (const Part &p : parts) {
+        Segment &s = *p.s;
         const int W = (int)s.dev.words, np = planes_of(W);
-        std::vector<uint32_t> buf((size_t)nr * 12);
-        std::vector<uint32_t> plane;
+        // plane j of the range at word offset nr * (words of planes < j); a few rooms (the single-room latency path) go through
+        // the stack, large ranges through the pinned buffer
+        uint32_t small[1024];
+        uint32_t *stage = small;
+        const size_t stage_bytes = (size_t)p.nr * (size_t)W * 4u;
+        if (stage_bytes > sizeof small && (st = io_stage(b, stage_bytes, &stage)) != GE_OK) return st;
+        size_t off[4] = {0, 0, 0, 0};
+        for (int j = 0, acc = 0; j < np; j++) { off[j] = (size_t)p.nr * acc; acc += plane_words(W, j); }
+        auto dev_of = [&](int j) { return reinterpret_cast<char *>(s.dev.base) + plane_offset(s.dev.rooms_padded, j) + p.r0 * (uint64_t)plane_words(W, j) * 4u; };
         if (src) {
-            for (uint64_t r = 0; r < nr; r++) {
-                const ge_room_view &v = src[lo - first + r];
-                if (v.n_players != s.dev.n_players) return GE_ERR_ARG;
-                view_to_words(s.dev.kind, v, s.table, &buf[r * 12]);
-            }
+            const ge_room_view *v = src + (p.lo - first);
+            for_room_ranges(p.nr, [&](uint64_t a, uint64_t z) {
+                uint32_t w[12];
+                for (uint64_t r = a; r < z; r++) {
+                    view_to_words(s.dev.kind, v[r], s.table, w);
+                    for (int j = 0; j < np; j++)
+                        for (int x = 0, pw = plane_words(W, j); x < pw; x++) stage[off[j] + r * pw + x] = w[4 * j + x];
+                }
+            });
+            for (int j = 0; j < np; j++)
+                HIP_TRY(hipMemcpy(dev_of(j), stage + off[j], (size_t)p.nr * plane_words(W, j) * 4u, hipMemcpyHostToDevice));
+        } else {
+            for (int j = 0; j < np; j++)     // synchronous: a 16-byte hipMemcpyAsync into pinned memory faulted inside the runtime (ROCm 7.2)
+                HIP_TRY(hipMemcpy(stage + off[j], dev_of(j), (size_t)p.nr * plane_words(W, j) * 4u, hipMemcpyDeviceToHost));
+            ge_room_view *v = dst + (p.lo - first);
+            for_room_ranges(p.nr, [&](uint64_t a, uint64_t z) {
+                uint32_t w[12] = {0};
+                for (uint64_t r = a; r < z; r++) {
+                    for (int j = 0; j < np; j++)
+                        for (int x = 0, pw = plane_words(W, j); x < pw; x++) w[4 * j + x] = stage[off[j] + r * pw + x];
+                    words_to_view(s.dev.kind, w, s.table, (int)s.dev.n_players, v[r]);
+                }
+            });
         }
-        for (int j = 0; j < np; j++) {
-            const int pw = plane_words(W, j);
-            plane.resize((size_t)nr * pw);
-            char *dev = reinterpret_cast<char *>(s.dev.base) + plane_offset(s.dev.rooms_padded, j) + r0 * (uint64_t)pw * 4u;
-            if (src) {
-                for (uint64_t r = 0; r < nr; r++)
-                    for (int x = 0; x < pw; x++) plane[r * pw + x] = buf[r * 12 + 4 * j + x];
-                HIP_TRY(hipMemcpy(dev, plane.data(), plane.size() * 4, hipMemcpyHostToDevice));
-            } else {
-                HIP_TRY(hipMemcpy(plane.data(), dev, plane.size() * 4, hipMemcpyDeviceToHost));
-                for (uint64_t r = 0; r < nr; r++)
-                    for (int x = 0; x < pw; x++) buf[r * 12 + 4 * j + x] = plane[r * pw + x];
-            }
-        }
-        if (dst)
-            for (uint64_t r = 0; r < nr; r++)
-                words_to_view(s.dev.kind, &buf[r * 12], s.table, (int)s.dev.n_players, dst[lo - first + r]);
     }
     return GE_OK;
 }
@@ -1456,6 +1526,7 @@ static int inject_impl(ge_batch *b, uint64_t n, const uint64_t *rooms, const uin
     h_gr[groups] = (uint32_t)n;
     if (b->inj_cap < total) {
         if (b->inj_buf) (void)hipFree(b->inj_buf);
+        if (b->io_buf) (void)hipHostFree(b->io_buf);
         b->inj_buf = nullptr; b->inj_cap = 0;
         const size_t cap = total < 4096 ? 4096 : total * 2;
         if (hipMalloc(&b->inj_buf, cap) != hipSuccess) return GE_ERR_NOMEM;
@@ -1619,10 +1690,6 @@ int ge_batch_read_rooms(ge_batch *b, uint64_t first, uint64_t count, ge_room_vie
 
 int ge_batch_write_rooms(ge_batch *b, uint64_t first, uint64_t count, const ge_room_view *src) {
     if (!b || (!src && count)) return GE_ERR_ARG;
-    for (uint64_t k = 0; k < count; k++)                       // werewolf role classes are 0 (unassigned) .. 4
-        if (src[k].pack == GE_PACK_WEREWOLF)
-            for (int i = 0; i < src[k].n_players && i < 16; i++)
-                if (src[k].players[i][0] > 4) return GE_ERR_ARG;
     return guarded([&] { return rooms_io(b, first, count, nullptr, src); });
 }
 
@@ -1679,6 +1746,7 @@ void ge_batch_destroy(ge_batch *b) {
         if (b->cap_stream) (void)hipStreamDestroy(b->cap_stream);
         if (b->turn_dev) (void)hipFree(b->turn_dev);
         if (b->inj_buf) (void)hipFree(b->inj_buf);
+        if (b->io_buf) (void)hipHostFree(b->io_buf);
         if (b->state) (void)hipFree(b->state);
         if (b->trace) (void)hipFree(b->trace);
         if (b->tables) (void)hipFree(b->tables);

@@ -218,9 +218,13 @@ class RoomBatch:
         return ms.value, n.value
 
     # ---- state access
-    def read_rooms(self, first: int = 0, count: Optional[int] = None) -> np.ndarray:
+    def read_rooms(self, first: int = 0, count: Optional[int] = None, out: Optional[np.ndarray] = None) -> np.ndarray:
+        """Canonical views of `count` rooms from `first` on.  `out`: an array of a previous call to fill again (a fresh
+        228-byte-per-room array costs its page faults on top of the read)."""
         count = self.n_rooms - first if count is None else count
-        out = np.zeros(count, dtype=ROOM_VIEW_DTYPE)
+        if out is None:
+            out = np.empty(count, dtype=ROOM_VIEW_DTYPE)        # the library writes every byte of every view
+        assert out.dtype == ROOM_VIEW_DTYPE and out.flags.c_contiguous and len(out) == count
         _check(self._lib.ge_batch_read_rooms(self._h, first, count, out.ctypes.data, out.nbytes), "ge_batch_read_rooms")
         return out
 

@@ -159,3 +159,44 @@ def test_batched_injection_equals_oracle(game, n, mask):
         assert lib.ge_batch_inject_actions(h, 0, None, None, None, None) == 0
         assert lib.ge_batch_inject_actions(h, 1, None, p3, c3, None) == -1
     assert applied > 1000 and refused > 1000
+
+
+def test_room_views_through_the_threaded_host_conversion(dsl_ww, dsl_tt, monkeypatch):
+    """ge_batch_read_rooms / write_rooms convert between packed planes and canonical views on several host threads from 16 K
+    rooms on (GE_IO_THREADS caps them).  A mixed batch large enough for that: one thread and many give the same bytes, sub-ranges
+    across the segment boundary equal slices of the whole, a reused `out` array is overwritten completely, write -> read is the
+    identity, and a write with one bad view anywhere changes nothing."""
+    segs = [(GameTable(dsl_ww), 12, 70001), (GameTable(dsl_tt), 4, 50000), (GameTable(dsl_ww), 8, 33333)]
+    total = sum(r for _, _, r in segs)
+    with RoomBatch(segs, seed=21, first_room=5, restart=True) as b:
+        b.step(37)
+        monkeypatch.setenv("GE_IO_THREADS", "1")
+        one = b.read_rooms()
+        monkeypatch.setenv("GE_IO_THREADS", "7")
+        many = b.read_rooms()
+        assert len(one) == total and one.tobytes() == many.tobytes()
+        out = np.frombuffer(bytearray(b"\xAB" * (60000 * one.itemsize)), dtype=one.dtype)
+        part = b.read_rooms(65000, 60000, out=out)           # spans all three segments
+        assert part is out and part.tobytes() == one[65000:125000].tobytes()
+        assert b.read_rooms(total - 1, 1).tobytes() == one[-1:].tobytes()
+        # write -> read is the identity, whatever the thread count, also for a sub-range
+        b.step(5)
+        later = b.read_rooms()
+        assert later.tobytes() != one.tobytes()
+        b.write_rooms(0, one)
+        assert b.read_rooms().tobytes() == one.tobytes()
+        b.write_rooms(69990, later[69990:120011].copy())
+        mixed = one.copy(); mixed[69990:120011] = later[69990:120011]
+        assert b.read_rooms().tobytes() == mixed.tobytes()
+        # one bad view in the last segment: GE_ERR_ARG, and no room of any segment was touched
+        bad = later.copy()
+        bad["players"][total - 7, 0, 0] = 9                  # werewolf role class out of range
+        with pytest.raises(GeError) as e:
+            b.write_rooms(0, bad)
+        assert e.value.status == -1
+        bad = later.copy()
+        bad["n_players"][80000] = 5                          # a view that does not fit its segment
+        with pytest.raises(GeError) as e:
+            b.write_rooms(0, bad)
+        assert e.value.status == -1
+        assert b.read_rooms().tobytes() == mixed.tobytes()
