@@ -86,7 +86,7 @@ def test_product_does_not_import_the_oracle():
     pkg = os.path.join(ROOT, "game_engine_amd")
     for d, _, files in os.walk(pkg):
         for f in files:
-            if f.endswith((".py", ".hip", ".cpp", ".h", ".js", ".ts", ".cc")):
+            if f.endswith((".py", ".hip", ".inl", ".cpp", ".h", ".js", ".ts", ".cc")):
                 src = open(os.path.join(d, f), encoding="utf-8").read()
                 for bad in ("import oracle", "from oracle", "libge_oracle", "ge_oracle", "orc_run", "refharness"):
                     assert bad not in src, (os.path.join(d, f), bad)

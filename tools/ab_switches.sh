@@ -1,5 +1,5 @@
 #!/bin/bash
-# Every compile-time switch that is left in the kernels (ge_device.h, ge_step.hip) is built once with a non-default value
+# Every compile-time switch that is left in the kernels (ge_device.h, ge_kernels.inl) is built once with a non-default value
 # and run through the parity subset, so that no switch value rots untested.
 #   tools/ab_switches.sh build        in the container: game_engine_amd/ab/sw_*.so (they travel with the gpurun snapshot)
 #   tools/ab_switches.sh test <tag>   on the GPU box: parity subset + timing probe per variant -> gpurun_out/<tag>/switches.txt
