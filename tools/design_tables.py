@@ -1,9 +1,16 @@
 #!/usr/bin/env python3
-"""Prints the measurement tables of DESIGN.md §4 / BASELINE.md §5 from the committed records: profiles/pmc_<shape>{,_k1}.json
-(tools/pmc_summary.py) and the driver-flags bench line profiles/<tag>_bench_n1_driver_flags.json.  usage: design_tables.py [tag]"""
-import json, os, sys
+"""The measurement tables of DESIGN.md §4 / BASELINE.md §5 from the committed records: profiles/pmc_<shape>{,_k1}.json
+(tools/pmc_summary.py) and the driver-flags bench line profiles/<tag>_bench_n1_driver_flags.json.
+usage: design_tables.py [tag] [--write]    (--write: rewrite the marked blocks of DESIGN.md / BASELINE.md in place -
+`<!-- gen:NAME -->` ... `<!-- /gen -->` blocks and `<!--g:NAME-->value<!--/g-->` spans - instead of printing)"""
+import io, json, os, re, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+tag = args[0] if args else "r03"
+_blocks, _real_print, _cur = {}, print, [None]
+def begin(name): _cur[0] = name; _blocks[name] = []
+def print(*a):                                                   # rows go to the current block
+    if a: _blocks[_cur[0]].append(" ".join(str(x) for x in a))
 P = lambda k: json.load(open(os.path.join(root, "profiles", f"pmc_{k}.json")))
 bench = json.loads(open(os.path.join(root, "profiles", f"{tag}_bench_n1_driver_flags.json")).read().strip().splitlines()[-1])
 other = bench["other_shapes"]
@@ -12,6 +19,7 @@ labels = {"c2": "C2: 65 536 Werewolf × 8 (1 wave/SIMD, ceiling 6.1·10¹¹)", "
 okey = {"ww8_1048576": "1048576 Werewolf x8", "c4": "2097152 Werewolf x12 (one GPU's share of C4)", "c3": "1048576 Two-Truths x4 (C3)"}
 rooms = {"c2": 65536, "ww8_1048576": 1 << 20, "c4": 1 << 21, "c3": 1 << 20}
 
+begin("fused_table")
 print("| shape (fused, 1 024 turns/launch) | VALU + SALU + LDS per wave-turn | µs per turn | room-phase steps/s | issue frac (all / VALU only) | `SQ_WAIT_ANY` of wave cycles |\n|---|---|---|---|---|---|")
 for k in ("c2", "ww8_1048576", "c4", "c3"):
     p = P(k); i = p["instructions_per_wave_turn"]
@@ -21,20 +29,20 @@ for k in ("c2", "ww8_1048576", "c4", "c3"):
     wt = waves / (us * 1e-6)
     tot = i["valu"] + i["salu"] + i["lds"]
     print(f"| {labels[k]} | {i['valu']:.0f} + {i['salu']:.0f} + {i['lds']:.0f} | {us:.3f} | {rooms[k] / (us * 1e-6):.3g} | {tot * wt / ceil:.2f} / {i['valu'] * wt / ceil:.2f} | {100 * p['wait_any_frac']:.0f} % |")
-print()
+begin("k1_table")
 print("| shape (single-turn launches) | VALU + SALU + LDS per wave-turn | measured HBM bytes per launch (state read + written) | kernel-trace average (sustained) | % of 8 TB/s by kernel-trace | bench line: sustained / per-launch events | `SQ_WAIT_ANY` |\n|---|---|---|---|---|---|---|")
 for k in ("c2", "ww8_1048576", "c4", "c3"):
     p = P(k + "_k1"); i = p["instructions_per_wave_turn"]; kt = p["kernel_trace"]
     hs = bench["hbm_streaming"] if k == "c2" else other[okey[k]]["hbm_streaming"]
     st = p["state_bytes_read_plus_written"]
     print(f"| {labels[k].split(' (1 wave')[0]} | {i['valu']:.0f} + {i['salu']:.0f} + {i['lds']:.0f} | {p['hbm_bytes_per_launch'] / 1e6:.1f} MB ({st / 1e6:.1f}) | {kt['average_ns'] / 1e3:.2f} µs ({kt['calls']} launches) | **{100 * st / kt['average_ns'] / 8e3:.1f}** | {100 * hs['frac']:.1f} / {100 * hs['frac_kernel']:.1f} | {100 * p['wait_any_frac']:.0f} % |")
-print()
+begin("result_table")
 print("| shape | fused (1 024 turns/launch): steps/s | alg. GB/s (% of 8 TB/s: a yardstick, not traffic) | single-turn launches: real HBM % of 8 TB/s (sustained) | CPU: oracle, steps/s (cores) |\n|---|---|---|---|---|")
 print(f"| C2: 65 536 Werewolf × 8 — the `bench.py` line | **{bench['value']:.3g}** (wall) | {bench['roofline']['achieved']:.0f} ({100 * bench['roofline']['frac']:.1f}) | {100 * bench['hbm_streaming']['frac']:.1f} (launch-bound: {bench['hbm_streaming']['us_per_launch_sustained']:.1f} µs per launch) | {bench['cpu_baseline']['value']:.3g} ({bench['cpu_baseline']['cores']}); one thread {bench['cpu_baseline']['single_thread_value']:.3g} |")
 for k in ("ww8_1048576", "c4", "c3"):
     v = other[okey[k]]
     print(f"| {labels[k]} | {v['value']:.3g} | {v['algorithmic_GBs']:.0f} ({100 * v['algorithmic_frac']:.0f}) | **{100 * v['hbm_streaming']['frac']:.1f}** ({v['hbm_streaming']['us_per_launch_sustained']:.2f} µs per launch) | {v['cpu_baseline']['value']:.3g} ({v['cpu_baseline']['cores']}) |")
-print()
+begin("baseline_rows")
 # BASELINE.md's round table: one row per shape
 blabels = {"c2": "C2 65 536 Werewolf×8", "ww8_1048576": "1 048 576 Werewolf×8", "c4": "C4 share 2 097 152 Werewolf×12", "c3": "C3 1 048 576 Two-Truths×4"}
 for k in ("c2", "ww8_1048576", "c4", "c3"):
@@ -54,3 +62,27 @@ for k in ("c2", "ww8_1048576", "c4", "c3"):
         v = other[okey[k]]
         note = " (= the state: no scratch any more)" if k == "c4" else ""
         print(f"| {blabels[k]} | {v['value']:.3g} | {v['algorithmic_GBs']:.0f} ({100 * v['algorithmic_frac']:.0f}) | {issue} | **{kt:.1f}** / {100 * v['hbm_streaming']['frac']:.1f} | {fused_mb}{note} | {v['cpu_baseline']['value']:.3g} |")
+
+# single values quoted in the prose
+_i = P("c2")["instructions_per_wave_turn"]
+_vals = {
+    "ww8": "%.1f" % (other[okey["ww8_1048576"]]["value"] / 1e10), "c4": "%.1f" % (other[okey["c4"]]["value"] / 1e10),
+    "c2": "%.2f" % (bench["value"] / 1e10), "c4fused": "%.3g" % other[okey["c4"]]["value"],
+    "c2cpi": "%.1f" % (bench["roofline"]["avg_launch_us"] / 1024 * 1e-6 * 2.4e9 / (_i["valu"] + _i["salu"] + _i["lds"])),
+    **{"k1_" + k.split("_")[0]: "%.1f" % (100 * P(k + "_k1")["state_bytes_read_plus_written"] / P(k + "_k1")["kernel_trace"]["average_ns"] / 8e3)
+       for k in ("ww8_1048576", "c4", "c3")},
+    "k1pct": " / ".join("%.1f" % (100 * P(k + "_k1")["state_bytes_read_plus_written"] / P(k + "_k1")["kernel_trace"]["average_ns"] / 8e3)
+                        for k in ("ww8_1048576", "c4", "c3")) + " %",
+}
+if "--write" in sys.argv:
+    for doc in ("DESIGN.md", "BASELINE.md", "README.md", os.path.join("profiles", "README.md")):
+        path = os.path.join(root, doc); s = open(path, encoding="utf-8").read(); before = s
+        for name, rows in _blocks.items():
+            s = re.sub(r"(<!-- gen:%s -->\n).*?(\n<!-- /gen -->)" % name, lambda m: m.group(1) + "\n".join(rows) + m.group(2), s, flags=re.S)
+        for name, v in _vals.items():
+            s = re.sub(r"(<!--g:%s-->).*?(<!--/g-->)" % name, lambda m: m.group(1) + v + m.group(2), s)
+        if s != before:
+            open(path, "w", encoding="utf-8").write(s); _real_print("rewrote", doc)
+else:
+    _real_print("\n\n".join("\n".join(rows) for rows in _blocks.values()))
+    _real_print("\n" + json.dumps(_vals, ensure_ascii=False))
