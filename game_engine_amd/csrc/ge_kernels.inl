@@ -36,7 +36,12 @@ struct StepArgs {
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
-template <int WORDS>
+// NT: non-temporal (streaming) accesses.  The step kernels touch every record once per launch; measured on the single-turn
+// launches in their sustained regime (bench.py hbm_streaming, % of 8 TB/s, profiles/r03_ab_nontemporal.txt): Two-Truths x 4
+// 59.4 -> 63.0 and Werewolf x 12 58.4 -> 60.0 with both loads and stores streaming (either alone: nothing); Werewolf x 8
+// 57.8 -> 58.7 with streaming stores only (with both: 57.5).  Fused launches do not notice.  So the step kernels stream their
+// stores, and their loads except for the 8-word Werewolf record (run_ww / run_tt); summary, fill and injection do not.
+template <int WORDS, bool NT = false>
 __device__ __forceinline__ void load_words(const uint32_t *base, uint64_t rooms_padded, uint64_t room, uint32_t *w) {
     constexpr int NP = (WORDS + 3) / 4;
 #pragma unroll
@@ -44,16 +49,18 @@ __device__ __forceinline__ void load_words(const uint32_t *base, uint64_t rooms_
         // global (address space 1), not flat, accesses: the base pointer was itself loaded from memory
         const char *plane = reinterpret_cast<const char *>(base) + plane_offset(rooms_padded, j);
         if (WORDS - 4 * j >= 4) {
-            const u32x4 v = ((const __attribute__((address_space(1))) u32x4 *)(uintptr_t)plane)[room];
+            const auto *p = &((const __attribute__((address_space(1))) u32x4 *)(uintptr_t)plane)[room];
+            const u32x4 v = NT ? __builtin_nontemporal_load(p) : *p;
             w[4 * j] = v.x; w[4 * j + 1] = v.y; w[4 * j + 2] = v.z; w[4 * j + 3] = v.w;
         } else {
-            const u32x2 v = ((const __attribute__((address_space(1))) u32x2 *)(uintptr_t)plane)[room];
+            const auto *p = &((const __attribute__((address_space(1))) u32x2 *)(uintptr_t)plane)[room];
+            const u32x2 v = NT ? __builtin_nontemporal_load(p) : *p;
             w[4 * j] = v.x; w[4 * j + 1] = v.y;
         }
     }
 }
 
-template <int WORDS>
+template <int WORDS, bool NT = false>
 __device__ __forceinline__ void store_words(uint32_t *base, uint64_t rooms_padded, uint64_t room, const uint32_t *w) {
     constexpr int NP = (WORDS + 3) / 4;
 #pragma unroll
@@ -61,10 +68,12 @@ __device__ __forceinline__ void store_words(uint32_t *base, uint64_t rooms_padde
         char *plane = reinterpret_cast<char *>(base) + plane_offset(rooms_padded, j);
         if (WORDS - 4 * j >= 4) {
             u32x4 v; v.x = w[4 * j]; v.y = w[4 * j + 1]; v.z = w[4 * j + 2]; v.w = w[4 * j + 3];
-            ((__attribute__((address_space(1))) u32x4 *)(uintptr_t)plane)[room] = v;
+            auto *p = &((__attribute__((address_space(1))) u32x4 *)(uintptr_t)plane)[room];
+            if (NT) __builtin_nontemporal_store(v, p); else *p = v;
         } else {
             u32x2 v; v.x = w[4 * j]; v.y = w[4 * j + 1];
-            ((__attribute__((address_space(1))) u32x2 *)(uintptr_t)plane)[room] = v;
+            auto *p = &((__attribute__((address_space(1))) u32x2 *)(uintptr_t)plane)[room];
+            if (NT) __builtin_nontemporal_store(v, p); else *p = v;
         }
     }
 }
@@ -150,7 +159,7 @@ __device__ __forceinline__ void run_ww(const SegDev *__restrict__ sgp, const Ste
     const bool valid = room_in < sg.rooms;
     const uint64_t room = valid ? room_in : 0;
     uint32_t w[L::WORDS];
-    load_words<L::WORDS>(sg.base, sg.rooms_padded, room, w);      // in flight while the block fills its LDS tables
+    load_words<L::WORDS, (NB > 8)>(sg.base, sg.rooms_padded, room, w);   // in flight while the block fills its LDS tables; streaming: see load_words
     // the slot -> player table of the action queue sits right behind the phase rows (step_lds_bytes)
     uint32_t *ord8 = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(rows) + LDS_ROWS);
     load_rows<B::TABLE ? IMG_END / 16u : B::ORD ? 128u : 64u, !LOWOCC && !SINGLE>(rows, tables, sg.table_idx, sgp);
@@ -259,7 +268,7 @@ __device__ __forceinline__ void run_ww(const SegDev *__restrict__ sgp, const Ste
     }
     if (!valid) return;
     ww_store_regs<NB>(s, deal_to_cache<NB, B::DEAL_FORM>(deal, s), w);
-    store_words<L::WORDS>(sg.base, sg.rooms_padded, room, w);
+    store_words<L::WORDS, true>(sg.base, sg.rooms_padded, room, w);
 }
 
 // Two-Truths: which builds route bot actions through the wavefront queue.  Many wavefronts per SIMD:
@@ -279,7 +288,7 @@ __device__ __forceinline__ void run_tt(const SegDev *__restrict__ sgp, const Ste
     const bool valid = room_in < sg.rooms;
     const uint64_t room = valid ? room_in : 0;
     uint32_t w[L::WORDS];
-    load_words<L::WORDS>(sg.base, sg.rooms_padded, room, w);
+    load_words<L::WORDS, true>(sg.base, sg.rooms_padded, room, w);
     load_rows<(QUEUE && !LOWOCC) ? 256u : 64u, QUEUE && !LOWOCC && !SINGLE>(rows, tables, sg.table_idx, sgp);
     TT<NB> s;
     L::unpack(w, s);
@@ -344,7 +353,7 @@ __device__ __forceinline__ void run_tt(const SegDev *__restrict__ sgp, const Ste
     }
     if (!valid) return;
     L::pack(s, w);
-    store_words<L::WORDS>(sg.base, sg.rooms_padded, room, w);
+    store_words<L::WORDS, true>(sg.base, sg.rooms_padded, room, w);
 }
 
 // One launch advances every room of every segment by a.n_turns turns.  Blocks are
