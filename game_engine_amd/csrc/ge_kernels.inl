@@ -84,7 +84,8 @@ __device__ __forceinline__ void store_event(uint32_t *trace, uint64_t rooms_padd
     u32x4 v;
     v.x = turn; v.y = p | (q << 8) | (restarted << 16) | (newly << 20);
     v.z = (uint32_t)choice; v.w = (uint32_t)(choice >> 32);
-    ((__attribute__((address_space(1))) u32x4 *)(uintptr_t)trace)[(uint64_t)t * rooms_padded + room] = v;
+    // streaming store: written once, read by the host (traced 1 M x 8: +6.0 -> +4.6 % over the untraced turn, profiles/r03_ab_nontemporal.txt)
+    __builtin_nontemporal_store(v, &((__attribute__((address_space(1))) u32x4 *)(uintptr_t)trace)[(uint64_t)t * rooms_padded + room]);
 }
 
 // The large-batch turn loops take the restart template (SegDev::init_regs) from a copy in the block's LDS when a room
