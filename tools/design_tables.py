@@ -71,9 +71,17 @@ _vals = {
     "c2cpi": "%.1f" % (bench["roofline"]["avg_launch_us"] / 1024 * 1e-6 * 2.4e9 / (_i["valu"] + _i["salu"] + _i["lds"])),
     **{"k1_" + k.split("_")[0]: "%.1f" % (100 * P(k + "_k1")["state_bytes_read_plus_written"] / P(k + "_k1")["kernel_trace"]["average_ns"] / 8e3)
        for k in ("ww8_1048576", "c4", "c3")},
+    "ww8f": "%.2f" % (other[okey["ww8_1048576"]]["value"] / 1e11), "c3f": "%.2f" % (other[okey["c3"]]["value"] / 1e11),
     "k1pct": " / ".join("%.1f" % (100 * P(k + "_k1")["state_bytes_read_plus_written"] / P(k + "_k1")["kernel_trace"]["average_ns"] / 8e3)
                         for k in ("ww8_1048576", "c4", "c3")) + " %",
 }
+_n2 = os.path.join(root, "profiles", f"{tag}_bench_n2_gloo_rehearsal.json")
+if os.path.exists(_n2):                                           # the 2-rank rehearsal's whole-job figures
+    n2 = json.loads(open(_n2).read().strip().splitlines()[-1]); ow = n2.get("other_workloads") or {}
+    _vals["n2_c2"] = "%.3g" % n2["value"]
+    for k in ("c4", "c5"):
+        if k in ow: _vals["n2_" + k] = "%.3g" % ow[k]["value"]
+    if "c4" in ow: _vals["n2_ag"] = "%.2f" % ow["c4"]["summary_allgather_ms"]
 if "--write" in sys.argv:
     for doc in ("DESIGN.md", "BASELINE.md", "README.md", os.path.join("profiles", "README.md")):
         path = os.path.join(root, doc); s = open(path, encoding="utf-8").read(); before = s
