@@ -422,7 +422,7 @@ __global__ void __launch_bounds__(256, (!LOWOCC && !GENERIC) ? GE_WW12_WAVES : 1
     si = __builtin_amdgcn_readfirstlane(si);
     const SegDev *sg = segs + si;
     const uint64_t room = (uint64_t)(blockIdx.x - a.block_begin[si]) * blockDim.x + threadIdx.x;
-    void *lw = &wl[threadIdx.x >> 6];
+    void *lw = &wl[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)];    // wave-uniform: kept in a scalar register across the kind switch
     switch (sg->kind) {
     case K_WW8: run_kind<K_WW8, LOWOCC, GENERIC>(sg, a, rows, lw, nth8, tables, room); break;
     case K_WW12: run_kind<K_WW12, LOWOCC, GENERIC>(sg, a, rows, lw, nth8, tables, room); break;

@@ -10,6 +10,7 @@ cp gpurun_out/profiles_out/pmc_*.json profiles/
 cp gpurun_out/$TAG/bench_n1.json profiles/${ROUND}_bench_n1_driver_flags.json
 cp gpurun_out/$TAG/bench_n2_gloo.json profiles/${ROUND}_bench_n2_gloo_rehearsal.json
 cp gpurun_out/$TAG/bench_rccl_one_rank.json profiles/${ROUND}_bench_rccl_one_rank.json
+[ -s gpurun_out/$TAG/bench_c5.json ] && cp gpurun_out/$TAG/bench_c5.json profiles/${ROUND}_bench_c5_share.json
 python - <<'PY'
 import glob, json, sys
 sys.path.insert(0, ".")

@@ -29,6 +29,13 @@ for k in ("c2", "ww8_1048576", "c4", "c3"):
     wt = waves / (us * 1e-6)
     tot = i["valu"] + i["salu"] + i["lds"]
     print(f"| {labels[k]} | {i['valu']:.0f} + {i['salu']:.0f} + {i['lds']:.0f} | {us:.3f} | {rooms[k] / (us * 1e-6):.3g} | {tot * wt / ceil:.2f} / {i['valu'] * wt / ceil:.2f} | {100 * p['wait_any_frac']:.0f} % |")
+_c5b = os.path.join(root, "profiles", f"{tag}_bench_c5_share.json")
+if os.path.exists(os.path.join(root, "profiles", "pmc_c5.json")) and os.path.exists(_c5b):
+    # one GPU's share of the mixed batch (BASELINE configs[4]): its own bench line (python bench.py --workload c5) and counter passes
+    c5 = json.loads(open(_c5b).read().strip().splitlines()[-1]); p = P("c5"); i = p["instructions_per_wave_turn"]
+    us = c5["roofline"]["avg_launch_us"] / 1024; rooms5 = c5["config"]["rooms_per_gpu"]; wt = rooms5 // 64 / (us * 1e-6)
+    tot = i["valu"] + i["salu"] + i["lds"]; ceil5 = 1024 * 2.4e9 / 2.0
+    print(f"| C5 share: 524 288 Werewolf × 8 + 524 288 Two-Truths × 4, one launch | {i['valu']:.0f} + {i['salu']:.0f} + {i['lds']:.0f} | {us:.3f} | {rooms5 / (us * 1e-6):.3g} | {tot * wt / ceil5:.2f} / {i['valu'] * wt / ceil5:.2f} | {100 * p['wait_any_frac']:.0f} % |")
 begin("k1_table")
 print("| shape (single-turn launches) | VALU + SALU + LDS per wave-turn | measured HBM bytes per launch (state read + written) | kernel-trace average (sustained) | % of 8 TB/s by kernel-trace | bench line: sustained / per-launch events | `SQ_WAIT_ANY` |\n|---|---|---|---|---|---|---|")
 for k in ("c2", "ww8_1048576", "c4", "c3"):

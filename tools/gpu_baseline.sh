@@ -11,6 +11,7 @@ bash tools/profile.sh $TAG c2 --steps 4 --warmup 1
 bash tools/profile.sh $TAG ww8_1048576 --rooms 1048576 --steps 2 --warmup 0
 bash tools/profile.sh $TAG c4 --workload c4 --steps 2 --warmup 0
 bash tools/profile.sh $TAG c3 --workload c3 --steps 2 --warmup 0
+bash tools/profile.sh $TAG c5 --workload c5 --steps 2 --warmup 0        # one GPU's share of the mixed batch (ge_step_kernel_mixed)
 bash tools/profile.sh $TAG c2_k1
 bash tools/profile.sh $TAG ww8_1048576_k1 --rooms 1048576
 bash tools/profile.sh $TAG c4_k1 --workload c4
@@ -25,5 +26,6 @@ print("issue", d["issue"].get("frac"), "streaming", d["hbm_streaming"] and d["hb
 for k, v in (d.get("other_shapes") or {}).items():
     print("%-46s %.3g steps/s, single-turn %.3f of 8 TB/s" % (k, v["value"], v["hbm_streaming"]["frac"]))
 PY
+timeout -k 10 300 python bench.py --gpus 1 --workload c5 --steps 8 --warmup 2 --no-cpu-baseline --no-other-shapes --no-from-init > gpurun_out/$TAG/bench_c5.json 2> gpurun_out/$TAG/bench_c5.err; echo "bench c5 rc=$?"
 GE_DIST_BACKEND=gloo timeout -k 10 400 python bench.py --gpus 2 --steps 4 --warmup 1 > gpurun_out/$TAG/bench_n2_gloo.json 2> gpurun_out/$TAG/bench_n2.err; echo "bench2 rc=$?"
 GE_FORCE_DIST=1 timeout -k 10 300 python bench.py --gpus 1 --steps 4 --warmup 1 --no-cpu-baseline --no-other-shapes --no-from-init --no-unfused > gpurun_out/$TAG/bench_rccl_one_rank.json 2> gpurun_out/$TAG/bench_rccl.err; echo "bench rccl rc=$?"
