@@ -661,7 +661,10 @@ template <int NB> __device__ int inject_tt(TT<NB> &s, const DevRow &row, const D
                               if (f == 1u) return (s.lie >> (2u * i)) & 3u;
                               if (f == 2u) return (s.vote >> (2u * i)) & 3u;
                               if (f == 4u) return (uint32_t)(s.rounds >> (4u * i)) & 15u;
-                              return (s.score[i / 4u] >> (8u * (i % 4u))) & 255u;
+                              uint32_t sc = s.score[0];                            // no dynamic index: the record stays in registers
+                              if (NB > 4 && i >= 4u) sc = s.score[NB > 4 ? 1 : 0];
+                              if (NB > 8 && i >= 8u) sc = s.score[NB > 8 ? 2 : 0];
+                              return (sc >> (8u * (i % 4u))) & 255u;
                           })) return GE_ERR_ARG;
     }
     const uint32_t nt = (row.r0 & ROW_GENERIC) ? 0u : (row.r0 >> 8) & 7u;
@@ -688,8 +691,8 @@ template <int NB> __device__ void inject_group_ww(const SegDev &sg, const DevTab
     load_words<L::WORDS>(sg.base, sg.rooms_padded, room, w);
     WW<NB> s;
     L::unpack(w, s);
-    const DevRow row = tables[sg.table_idx].rows[s.phase];
-    const DevCond cond = tables[sg.table_idx].conds[s.phase];
+    const DevRow &row = tables[sg.table_idx].rows[s.phase];
+    const DevCond &cond = tables[sg.table_idx].conds[s.phase];   // read in place: a private copy of the clause table is indexed dynamically and would live in scratch
     for (uint32_t k = lo; k < hi; k++) a.status[k] = inject_ww<NB>(s, row, cond, sg.n_players, a.players[k], a.choices[k]);
     L::pack(s, w);
     store_words<L::WORDS>(sg.base, sg.rooms_padded, room, w);
@@ -700,8 +703,8 @@ template <int NB> __device__ void inject_group_tt(const SegDev &sg, const DevTab
     load_words<L::WORDS>(sg.base, sg.rooms_padded, room, w);
     TT<NB> s;
     L::unpack(w, s);
-    const DevRow row = tables[sg.table_idx].rows[s.phase];
-    const DevCond cond = tables[sg.table_idx].conds[s.phase];
+    const DevRow &row = tables[sg.table_idx].rows[s.phase];
+    const DevCond &cond = tables[sg.table_idx].conds[s.phase];   // read in place: a private copy of the clause table is indexed dynamically and would live in scratch
     for (uint32_t k = lo; k < hi; k++) a.status[k] = inject_tt<NB>(s, row, cond, sg.n_players, a.players[k], a.choices[k]);
     L::pack(s, w);
     store_words<L::WORDS>(sg.base, sg.rooms_padded, room, w);
