@@ -395,7 +395,7 @@ class RoomGroup:
             for k, seg in enumerate(self.segments):
                 R = seg[2]
                 cnt = R * (i + 1) // self.n_devices - R * i // self.n_devices
-                out = np.zeros(cnt, dtype=ROOM_VIEW_DTYPE)
+                out = np.empty(cnt, dtype=ROOM_VIEW_DTYPE)          # the library writes every byte of every view
                 _check(self._lib.ge_batch_read_rooms(b, first, cnt, out.ctypes.data, out.nbytes), "ge_batch_read_rooms")
                 per_seg[k].append(out)
                 first += cnt
