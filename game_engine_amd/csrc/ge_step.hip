@@ -695,7 +695,12 @@ template <class F> static void for_room_ranges(uint64_t rooms, F &&f) {   // f(l
     th.reserve(n - 1);
     for (unsigned t = 1; t < n; t++) {
         const uint64_t lo = std::min<uint64_t>(rooms, t * per), hi = std::min<uint64_t>(rooms, lo + per);
-        if (lo < hi) th.emplace_back([&f, lo, hi] { f(lo, hi); });
+        if (lo >= hi) continue;
+        try {
+            th.emplace_back([&f, lo, hi] { f(lo, hi); });
+        } catch (...) {                                          // no thread to be had: this range on the calling thread
+            f(lo, hi);
+        }
     }
     f((uint64_t)0, std::min<uint64_t>(rooms, per));
     for (std::thread &x : th) x.join();
