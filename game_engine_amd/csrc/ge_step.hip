@@ -734,9 +734,17 @@ static int rooms_io(ge_batch *b, uint64_t first, uint64_t count, ge_room_view *d
             std::atomic<int> bad{0};
             const ge_room_view *v = src + (p.lo - first);
             const uint32_t n = p.s->dev.n_players;
+            const ge_game_table &tb = p.s->table;
+            // a view belongs to its segment's rule pack, and both phase ids name a row of that segment's table
+            // (an id outside dsl['phases'] is never stored by the reference either: v2:1173-1191)
+            auto known_phase = [&tb](int32_t id) {
+                for (int k = 0; k < tb.n_phases; k++) if (tb.rows[k].phase_id == id) return true;
+                return false;
+            };
             for_room_ranges(p.nr, [&](uint64_t a, uint64_t z) {
                 for (uint64_t r = a; r < z; r++) {
-                    bool ok = v[r].n_players == n;
+                    bool ok = v[r].n_players == n && v[r].pack == (uint8_t)tb.pack &&
+                              known_phase(v[r].phase_id) && known_phase(v[r].prev_phase_id);
                     if (ok && v[r].pack == GE_PACK_WEREWOLF)             // werewolf role classes are 0 (unassigned) .. 4
                         for (uint32_t i = 0; i < n && i < 16u; i++) ok &= v[r].players[i][0] <= 4;
                     if (!ok) { bad.store(1, std::memory_order_relaxed); return; }
@@ -770,7 +778,7 @@ static int rooms_io(ge_batch *b, uint64_t first, uint64_t count, ge_room_view *d
             for (int j = 0; j < np; j++)
                 HIP_TRY(hipMemcpy(dev_of(j), stage + off[j], (size_t)p.nr * plane_words(W, j) * 4u, hipMemcpyHostToDevice));
         } else {
-            for (int j = 0; j < np; j++)     // synchronous: a 16-byte hipMemcpyAsync into pinned memory faulted inside the runtime (ROCm 7.2)
+            for (int j = 0; j < np; j++)     // synchronous: the conversion below needs every plane, and the batch was drained above
                 HIP_TRY(hipMemcpy(stage + off[j], dev_of(j), (size_t)p.nr * plane_words(W, j) * 4u, hipMemcpyDeviceToHost));
             ge_room_view *v = dst + (p.lo - first);
             for_room_ranges(p.nr, [&](uint64_t a, uint64_t z) {
@@ -811,8 +819,7 @@ static int inject_impl(ge_batch *b, uint64_t n, const uint64_t *rooms, const uin
     }
     h_gr[groups] = (uint32_t)n;
     if (b->inj_cap < total) {
-        if (b->inj_buf) (void)hipFree(b->inj_buf);
-        if (b->io_buf) (void)hipHostFree(b->io_buf);
+        if (b->inj_buf) (void)hipFree(b->inj_buf);     // inj_buf only: io_buf belongs to io_stage and ge_batch_destroy
         b->inj_buf = nullptr; b->inj_cap = 0;
         const size_t cap = total < 4096 ? 4096 : total * 2;
         if (hipMalloc(&b->inj_buf, cap) != hipSuccess) return GE_ERR_NOMEM;

@@ -265,7 +265,9 @@ int ge_batch_n_rooms(const ge_batch *b, uint64_t *n_rooms);
 int ge_batch_read_rooms(ge_batch *b, uint64_t first, uint64_t count, ge_room_view *dst, size_t cap_bytes);
 
 /* Overwrites rooms from canonical views (checkpoint restore, tests of hand-built states).  All views are checked first
- * (n_players of the segment, werewolf role classes 0 .. 4): GE_ERR_ARG leaves every room as it was.  Threads as above. */
+ * (n_players and pack of the segment the room lies in, phase_id / prev_phase_id naming phases of that segment's table - the
+ * reference never stores an id outside dsl['phases'] either, v2:1173-1191 - werewolf role classes 0 .. 4): GE_ERR_ARG leaves
+ * every room as it was.  Threads as above. */
 int ge_batch_write_rooms(ge_batch *b, uint64_t first, uint64_t count, const ge_room_view *src);
 
 /* Logs an action of a host-driven player between turns, exactly as if the player had acted in the

@@ -199,4 +199,12 @@ def test_room_views_through_the_threaded_host_conversion(dsl_ww, dsl_tt, monkeyp
         with pytest.raises(GeError) as e:
             b.write_rooms(0, bad)
         assert e.value.status == -1
+        # a Two-Truths view inside the Werewolf x 12 segment; phase ids no table row has (either of the two)
+        for room, field, value in ((100, "pack", 2), (70001 + 17, "pack", 1), (total - 1, "phase_id", 1234),
+                                   (3, "prev_phase_id", -5), (70001 + 49999, "phase_id", 16)):
+            bad = later.copy()
+            bad[field][room] = value
+            with pytest.raises(GeError) as e:
+                b.write_rooms(0, bad)
+            assert e.value.status == -1, (room, field)
         assert b.read_rooms().tobytes() == mixed.tobytes()
