@@ -726,8 +726,8 @@ __device__ __forceinline__ void ww_phase_branch(const WWR<NB> &s, const DevRow &
 template <int NB, bool LOWOCC, bool SINGLE>
 __device__ __forceinline__ void ww_prepare_deal(const WWR<NB> &s, const WwCtx &c, Deal &deal, bool deal_now, uint32_t ALL, WWR<NB> &dealt) {
     using B = WwBuild<NB, LOWOCC, SINGLE>;
-    if (deal_now && !(deal.gv & DEAL_VALID)) {
-        const uint32_t g = deal_next_game<NB>(s);
+    const uint32_t g = deal_next_game<NB>(s);
+    if (deal_now && deal.gv != (g | DEAL_VALID)) {             // no deal, or (single-turn Werewolf x 12: an entry of the side plane) one for another game
         deal_roles<NB, B::TABLE, B::DEAL_FORM>(deal, deal_key(c.rkey, g), g, c.n, c.nw, c.nth8);
     }
     if (B::DEAL_FORM != DEAL_PACKED) deal_words<NB, B::DEAL_FORM>(deal, ALL, dealt);

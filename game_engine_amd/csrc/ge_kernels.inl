@@ -24,6 +24,7 @@ struct SegDev {
     uint32_t term_mask;        // bit r = table row r is terminal (no next_phase branch)
     uint32_t done0;            // two-truths: tt_done_mask of the initial record
     uint32_t *trace;           // GE_FLAG_TRACE: [turn in launch][rooms_padded] x 4 words, else null
+    uint32_t *deal_side;       // Werewolf x 12: prepared role deals of the single-turn launches, [rooms_padded] x 2 words (else null); see run_ww
 };
 
 struct StepArgs {
@@ -106,7 +107,10 @@ __device__ __forceinline__ void load_rows(DevRow *rows, const DevTable *tables, 
     const uint32_t bd = blockDim.x, tid = threadIdx.x;
     // the restart template behind the image (large-batch turn loops; a single-turn build reads it through the scalar cache)
     const u32x4 t0 = WITH_S0 ? reinterpret_cast<const u32x4 *>(sg->init_regs)[tid < 5u ? tid : 4u] : u32x4{0u, 0u, 0u, 0u};
-    if (bd == 256u) {                                          // wave-uniform: the block size of every large batch
+    if (bd >= 512u) {                                          // wave-uniform: a single-turn launch's larger block - one pass (N16 <= 448)
+        const u32x4 t = src[tid < N16 ? tid : N16 - 1u];
+        if (tid < N16) dst[tid] = t;
+    } else if (bd == 256u) {                                   // the block size of every large batch
         constexpr uint32_t P = (N16 + 255u) / 256u;
         u32x4 t[P];
 #pragma unroll
@@ -226,8 +230,34 @@ __device__ __forceinline__ void run_ww(const SegDev *__restrict__ sgp, const Ste
         uint32_t ev_newly = 0;
         uint64_t ev_choice = 0;
         const bool trace = a.trace != 0u;
-        const bool deal_now = NB <= 8 && (turn0 & (GE_DEAL_PERIOD - 1u)) == 0u;       // wave-uniform
+        // Werewolf x 12 has no room in its record for a prepared deal (ge_layout.h), and a wavefront of single-turn launches paid
+        // a whole deal (~130 vector instructions) whenever one of its 64 rooms was assigned roles - on ~2 of 3 turns, 8 % of the
+        // launch (profiles/r04_ab_deal12_upper_bound.txt).  So those deals live in a side plane beside the records: {DealPk, game
+        // index | DEAL_VALID} per room, a cache of a pure function of (seed, global room, game index) whose tag is the whole game
+        // index - a stale entry (in `deal.gv`: the game it was made for) can only miss, never mislead.  Every deal_period-th turn all lanes load their entry, the ones
+        // without a deal for their next game compute it together, and all store; on the other turns only the lanes whose row
+        // has a branch into a role assignment load theirs (a few scattered 8-byte loads per wavefront, issued here, used at the
+        // end of the turn).  A miss deals on the spot (ww_apply_effect), as before.
+        const bool side = NB > 8 && sg.deal_side != nullptr;                            // wave-uniform
+        const bool refill = side && (turn0 & (deal_period<NB>() - 1u)) == 0u;
+        auto *side_p = &((__attribute__((address_space(1))) u32x2 *)(uintptr_t)sg.deal_side)[room];
+        if (NB > 8 && side) {
+            uint32_t x = ((row.r3 >> 5) & 0x07070707u) ^ (0x01010101u * (uint32_t)EFF_ASSIGN_ROLES);   // a zero byte = a branch whose target assigns roles
+            const bool may_assign = ((x - 0x01010101u) & ~x & 0x80808080u) != 0u;
+            if (refill || may_assign) {
+                // taken as it is: the tag is compared where the deal is used (ww_prepare_deal, ww_apply_effect), at the end of the
+                // turn - a compare here would make the wavefront wait for this load before it has done anything else
+                const u32x2 v = *side_p;
+                deal.a = v.x;
+                deal.gv = v.y;
+            }
+        }
+        const bool deal_now = NB <= 8 ? (turn0 & (GE_DEAL_PERIOD - 1u)) == 0u : refill;   // wave-uniform
         ww_turn<NB, LOWOCC, GENERIC, true>(s, row, ctx, turn0, tk, trace, deal, deal_now, ev_newly, ev_choice, nullptr);
+        if (NB > 8 && refill && valid) {
+            u32x2 v; v.x = deal.a; v.y = deal.gv == (deal_next_game<NB>(s) | DEAL_VALID) ? deal.gv : 0u;
+            *side_p = v;
+        }
         if (trace && valid) store_event(sg.trace, sg.rooms_padded, 0u, room, turn0, p, s.phase, restarted, ev_newly, ev_choice);
     } else {
         DevRow row = rows[s.phase];
@@ -401,7 +431,7 @@ extern __shared__ __align__(16) unsigned char ge_lds[];
 #endif
 // SINGLE: the launch is one turn (a.n_turns == 1) of a single-game batch with shipped-grammar conditions (run_ww / run_tt)
 template <int KIND, bool LOWOCC, bool GENERIC = false, bool SINGLE = false>
-__global__ void __launch_bounds__(256, (KIND == K_WW12 && !LOWOCC && !GENERIC) ? GE_WW12_WAVES : (KIND == K_WW8 && !LOWOCC && !GENERIC) ? GE_WW8_WAVES : 1) ge_step_kernel(const SegDev *__restrict__ segs, const DevTable *__restrict__ tables, const StepArgs a) {
+__global__ void __launch_bounds__(SINGLE ? 1024 : 256, SINGLE ? 8 : (KIND == K_WW12 && !LOWOCC && !GENERIC) ? GE_WW12_WAVES : (KIND == K_WW8 && !LOWOCC && !GENERIC) ? GE_WW8_WAVES : 1) ge_step_kernel(const SegDev *__restrict__ segs, const DevTable *__restrict__ tables, const StepArgs a) {
     constexpr bool WWK = KIND == K_WW8 || KIND == K_WW12 || tt_uses_queue(KIND == K_TT4 ? 4 : KIND == K_TT8 ? 8 : 12, LOWOCC);   // uses the action queue
     DevRow *rows = reinterpret_cast<DevRow *>(ge_lds);
     uint8_t *nth8 = ge_lds + LDS_ROWS + LDS_ORD8;
@@ -532,6 +562,7 @@ __global__ void __launch_bounds__(256) ge_fill_kernel(const SegDev *__restrict__
         const SegDev &sg = segs[k];
         const int np = planes_of((int)sg.words);
         for (uint64_t room = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; room < sg.rooms_padded; room += (uint64_t)gridDim.x * blockDim.x) {
+            if (sg.deal_side) { u32x2 z; z.x = 0u; z.y = 0u; ((__attribute__((address_space(1))) u32x2 *)(uintptr_t)sg.deal_side)[room] = z; }
             for (int j = 0; j < np; j++) {
                 char *plane = reinterpret_cast<char *>(sg.base) + plane_offset(sg.rooms_padded, j);
                 if ((int)sg.words - 4 * j >= 4) {
@@ -546,12 +577,17 @@ __global__ void __launch_bounds__(256) ge_fill_kernel(const SegDev *__restrict__
     }
 }
 
-// ---- the prepared-deal cache of the Werewolf x 8 records (word 7, upper half) <- empty.  A cached deal is a function of
+// ---- the prepared-deal caches (Werewolf x 8: word 7 of the records, upper half; Werewolf x 12: the side plane) <- empty.  A cached deal is a function of
 // (seed, global room index, game index); records copied in raw from somewhere else (ge_batch_state) may carry deals of
 // another seed or room range, so ge_batch_set_turn - the call that completes a raw restore - drops them all.
 __global__ void __launch_bounds__(256) ge_clear_deal_cache(const SegDev *__restrict__ segs, uint32_t n_seg) {
     for (uint32_t k = 0; k < n_seg; k++) {
         const SegDev &sg = segs[k];
+        if (sg.deal_side)                                                     // Werewolf x 12: the side plane of prepared deals
+            for (uint64_t room = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; room < sg.rooms_padded; room += (uint64_t)gridDim.x * blockDim.x) {
+                u32x2 z; z.x = 0u; z.y = 0u;
+                ((__attribute__((address_space(1))) u32x2 *)(uintptr_t)sg.deal_side)[room] = z;
+            }
         if (sg.kind != K_WW8) continue;
         uint32_t *plane1 = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(sg.base) + plane_offset(sg.rooms_padded, 1));
         for (uint64_t room = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; room < sg.rooms_padded; room += (uint64_t)gridDim.x * blockDim.x)

@@ -255,6 +255,7 @@ struct ge_batch {
     std::vector<Segment> segs;
     void *state = nullptr;            // one allocation, segments back to back
     void *trace = nullptr;            // GE_FLAG_TRACE: per segment [max_fuse][rooms_padded] x 16 B
+    void *deal_side = nullptr;        // Werewolf x 12 segments: prepared role deals of the single-turn launches, [rooms_padded] x 8 B each (ge_kernels.inl run_ww)
     uint32_t last_step_turns = 0;     // turns of the most recent ge_batch_step (what the trace holds)
     size_t state_bytes = 0;
     DevTable *tables = nullptr;
@@ -443,6 +444,18 @@ static int create_impl(const ge_batch_desc *desc, ge_batch **out, const uint64_t
                     off += (size_t)b->max_fuse * s.dev.rooms_padded * 16u;
                 }
             }
+            {
+                // a cache, not state: ge_batch_state does not show it, a checkpoint does not carry it, the fill zeroes it
+                size_t sb = 0;
+                for (Segment &s : b->segs) if (s.dev.kind == K_WW12) sb += (size_t)s.dev.rooms_padded * 8u;
+                if (sb && hipMalloc(&b->deal_side, sb) != hipSuccess) { st = GE_ERR_NOMEM; break; }
+                size_t off = 0;
+                for (Segment &s : b->segs)
+                    if (s.dev.kind == K_WW12) {
+                        s.dev.deal_side = reinterpret_cast<uint32_t *>(static_cast<char *>(b->deal_side) + off);
+                        off += (size_t)s.dev.rooms_padded * 8u;
+                    }
+            }
             std::vector<DevTable> host_tables(b->segs.size());
             for (size_t k = 0; k < b->segs.size(); k++) {
                 Segment &s = b->segs[k];
@@ -533,8 +546,9 @@ static int reset_impl(ge_batch *b) {
 }
 
 static hipError_t launch_step(const ge_batch *b, const StepArgs &a, hipStream_t st) {
-    const dim3 grid(b->n_blocks), block(b->block_threads);
-#define GE_LAUNCH(KERNEL, QUEUE, LOW) hipLaunchKernelGGL(KERNEL, grid, block, step_lds_bytes(QUEUE, LOW, b->block_threads), st, b->segs_dev, b->tables, a)
+    dim3 grid(b->n_blocks), block(b->block_threads);
+    uint32_t bt = b->block_threads;                           // rooms per block
+#define GE_LAUNCH(KERNEL, QUEUE, LOW) hipLaunchKernelGGL(KERNEL, grid, block, step_lds_bytes(QUEUE, LOW, bt), st, b->segs_dev, b->tables, a)
     const bool low = a.lowocc != 0u && !(b->generic && b->segs.size() > 1);   // mixed batches with generic tables: the large-batch build serves every size
     if (b->generic) {
         // generic target conditions: single-game batches get both forms too; mixed batches the large-batch one
@@ -549,7 +563,22 @@ static hipError_t launch_step(const ge_batch *b, const StepArgs &a, hipStream_t 
     } else if (b->segs.size() > 1) {
         if (low) GE_LAUNCH(ge_step_kernel_mixed<true>, true, true); else GE_LAUNCH(ge_step_kernel_mixed<false>, true, false);
     } else if (a.n_turns == 1u) {
-        // one turn per launch (max_fuse = 1, or the tail of a step): the single-turn builds
+        // one turn per launch (max_fuse = 1, or the tail of a step): the single-turn builds.  A block's first act is to fill its 7 KB
+        // of LDS tables behind a barrier - the fewer blocks, the less of that per launch - so a large Werewolf x 8 batch runs them in
+        // blocks of 512 rooms (GE_SINGLE_BLOCK = 256 / 512 / 1024 overrides, for A/B runs); a single game's rooms start at block 0,
+        // so the grid is just the rooms over the block size
+        // (profiles/r04_ab_single_block.txt, sustained us per launch at 256 / 512 / 1 024 rooms per block: Werewolf x 8 14.23 / 14.01 /
+        // 14.22 at 1 M rooms and 386 / 373 / 377 at 33 M; Werewolf x 12 34.4 / 34.6 / 37.9 at 2 M; Two-Truths x 4 10.2 / 10.2 / 10.4)
+        static const uint32_t single_block_env = [] {
+            const char *e = getenv("GE_SINGLE_BLOCK");
+            const unsigned long v = e ? strtoul(e, nullptr, 10) : 0ul;
+            return (v == 256 || v == 512 || v == 1024) ? (uint32_t)v : 0u;
+        }();
+        if (!low && b->block_threads == 256u) {
+            bt = single_block_env ? single_block_env : (b->segs[0].dev.kind == K_WW8 ? 512u : 256u);
+            grid = dim3((uint32_t)((b->segs[0].dev.rooms + bt - 1u) / bt));
+            block = dim3(bt);
+        }
         switch (b->segs[0].dev.kind) {
         case K_WW8: if (low) GE_LAUNCH((ge_step_kernel<K_WW8, true, false, true>), true, true); else GE_LAUNCH((ge_step_kernel<K_WW8, false, false, true>), true, false); break;
         case K_WW12: if (low) GE_LAUNCH((ge_step_kernel<K_WW12, true, false, true>), true, true); else GE_LAUNCH((ge_step_kernel<K_WW12, false, false, true>), true, false); break;
@@ -574,6 +603,7 @@ static hipError_t launch_step(const ge_batch *b, const StepArgs &a, hipStream_t 
 // launch-bound for small batches; the sequence is captured once per n_turns into a hipGraph whose
 // launches take their first turn relative to a device word, and replayed.
 constexpr uint32_t GRAPH_MIN_LAUNCHES = 4;
+
 
 static hipGraphExec_t graph_for(ge_batch *b, uint32_t n_turns) {
     for (auto &g : b->graphs)
@@ -931,7 +961,7 @@ int ge_batch_set_turn(ge_batch *b, uint64_t turn) {
         if (st != GE_OK) return st;
         b->turn = turn;                                    // the graph path re-seeds its device word when it differs
         uint64_t most = 0;
-        for (const Segment &sg : b->segs) most = (sg.dev.kind == K_WW8 && sg.dev.rooms_padded > most) ? sg.dev.rooms_padded : most;
+        for (const Segment &sg : b->segs) most = ((sg.dev.kind == K_WW8 || sg.dev.deal_side) && sg.dev.rooms_padded > most) ? sg.dev.rooms_padded : most;
         if (most) {
             const uint32_t blocks = (uint32_t)((most / 256u) < 2048u ? (most / 256u) : 2048u);
             hipLaunchKernelGGL(ge_clear_deal_cache, dim3(blocks ? blocks : 1u), dim3(256), 0, b->last_stream, b->segs_dev, (uint32_t)b->segs.size());
@@ -1042,6 +1072,7 @@ void ge_batch_destroy(ge_batch *b) {
         if (b->io_buf) (void)hipHostFree(b->io_buf);
         if (b->state) (void)hipFree(b->state);
         if (b->trace) (void)hipFree(b->trace);
+        if (b->deal_side) (void)hipFree(b->deal_side);
         if (b->tables) (void)hipFree(b->tables);
         if (b->segs_dev) (void)hipFree(b->segs_dev);
         if (b->sum_dev) (void)hipFree(b->sum_dev);

@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""Registers, spills, scratch, LDS and occupancy of every kernel of libge_step.so, from the compiler's own remarks
+(`make -C game_engine_amd/csrc asm` = hipcc -S -Rpass-analysis=kernel-resource-usage): the source of DESIGN.md's register
+table, so that the document cannot drift from the build.
+
+    python tools/asm_table.py            run `make asm` and print the table (markdown)
+    python tools/asm_table.py --json     the same as JSON (tools/design_tables.py reads this)
+    python tools/asm_table.py --check    exit 1 unless every shipped (non-GENERIC) build has 0 scratch and 0 spills
+"""
+import json
+import os
+import re
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "game_engine_amd", "csrc")
+KINDS = ["Werewolf x 8", "Werewolf x 12", "Two-Truths x 4", "Two-Truths x 8", "Two-Truths x 12"]
+KEYS = {"Function Name": "name", "TotalSGPRs": "sgprs", "VGPRs": "vgprs", "AGPRs": "agprs", "ScratchSize [bytes/lane]": "scratch",
+        "Occupancy [waves/SIMD]": "occupancy", "SGPRs Spill": "sgpr_spill", "VGPRs Spill": "vgpr_spill", "LDS Size [bytes/block]": "lds_static"}
+
+
+def describe(mangled: str) -> dict:
+    """ge_step_kernel<KIND, LOWOCC, GENERIC, SINGLE> / ge_step_kernel_mixed<LOWOCC, GENERIC> / the helper kernels"""
+    m = re.search(r"ge_step_kernel_mixedILb([01])ELb([01])E", mangled)
+    if m:
+        low, gen = m.group(1) == "1", m.group(2) == "1"
+        return {"kernel": "ge_step_kernel_mixed", "layout": "mixed batch", "lowocc": low, "generic": gen, "single": False}
+    m = re.search(r"ge_step_kernelILi(\d)ELb([01])ELb([01])ELb([01])E", mangled)
+    if m:
+        return {"kernel": "ge_step_kernel", "layout": KINDS[int(m.group(1))], "lowocc": m.group(2) == "1", "generic": m.group(3) == "1",
+                "single": m.group(4) == "1"}
+    m = re.search(r"N_1\d+(ge_[a-z_0-9]+?)E", mangled)
+    return {"kernel": m.group(1) if m else mangled, "layout": "-", "lowocc": False, "generic": False, "single": False}
+
+
+def collect(rebuild=True):
+    cmd = ["make", "-C", CSRC, "asm"] + (["-B"] if rebuild else [])
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if p.returncode != 0:
+        sys.stderr.write(p.stdout)
+        raise SystemExit("make asm failed")
+    rows, cur = [], None
+    for line in p.stdout.splitlines():
+        m = re.search(r"remark: ([^:]+): (.*?) \[-Rpass-analysis", line)
+        if not m or m.group(1).strip() not in KEYS:
+            continue
+        key, val = KEYS[m.group(1).strip()], m.group(2).strip()
+        if key == "name":
+            cur = {"name": val}
+            cur.update(describe(val))
+            rows.append(cur)
+        elif cur is not None:
+            cur[key] = int(val)
+    return rows
+
+
+def label(r):
+    if r["kernel"] not in ("ge_step_kernel", "ge_step_kernel_mixed"):
+        return r["kernel"]
+    form = "single-turn" if r["single"] else "fused"
+    occ = "lone-wavefront" if r["lowocc"] else "large-batch"
+    return f"{r['layout']}, {occ}, {form}" + (", GENERIC" if r["generic"] else "")
+
+
+def markdown(rows):
+    out = ["| build | VGPRs | SGPRs | SGPR spills | VGPR spills | scratch B/lane | wavefronts / SIMD |", "|---|---|---|---|---|---|---|"]
+    order = sorted(rows, key=lambda r: (r["kernel"] not in ("ge_step_kernel", "ge_step_kernel_mixed"), r["generic"], r["single"], r["layout"], not r["lowocc"]))
+    for r in order:
+        out.append(f"| {label(r)} | {r.get('vgprs', 0)} | {r.get('sgprs', 0)} | {r.get('sgpr_spill', 0)} | {r.get('vgpr_spill', 0)} | "
+                   f"{r.get('scratch', 0)} | {r.get('occupancy', 0)} |")
+    return "\n".join(out)
+
+
+def main():
+    rows = collect(rebuild=True)
+    if "--json" in sys.argv:
+        print(json.dumps(rows, indent=1))
+        return
+    print(markdown(rows))
+    if "--check" in sys.argv:
+        bad = [label(r) for r in rows if not r["generic"] and (r.get("scratch", 0) or r.get("vgpr_spill", 0) or r.get("sgpr_spill", 0))]
+        if bad:
+            raise SystemExit("shipped builds with scratch or spills: " + "; ".join(bad))
+
+
+if __name__ == "__main__":
+    main()
