@@ -26,13 +26,16 @@ Prints ONE JSON line on rank 0 (contract in the task brief):
                   `hbm_frac_of_measured_traffic` what the measured bytes amount to;
   issue           wave-instructions per second against the SIMD issue ceiling (counters of the committed PMC pass of
                   this same shape and fuse; dropped when the kernel sources have changed since);
-  hbm_streaming   the max_fuse = 1 launch, where every turn really streams every record through HBM: the physical
-                  HBM fraction of the path;
+  hbm_streaming   the max_fuse = 1 launch, where every turn reads and writes every record: a memory-side rate for the shapes
+                  whose state fits the 256 MiB Infinity Cache (the contract shape and the BASELINE shapes do);
+  hbm_streaming_beyond_l3  (N = 1) the same launch over 640 MiB - 1 GiB of resident state: the HBM fraction that is provably
+                  HBM, with a parity check (single-turn launches == fused turns, summary checksum) at that size;
   other_shapes    (N = 1) the other BASELINE shapes on this GPU, each with its own fused figure, hbm_streaming block
                   and a bounded CPU row;
   other_workloads (N > 1) BASELINE configs[3] and [4]: every rank steps its share of C4 (16 777 216 Werewolf x 12 over 8
-                  GPUs = 2 097 152 per rank) and C5 (50/50 mix), with the timed summary all-gather;
-  cpu_baseline    the oracle's C restatement on the host cores (the ONLY place bench.py touches oracle/).
+                  GPUs = 2 097 152 per rank) and C5 (50/50 mix), with the timed summary all-gather, each with its own
+                  roofline block, and C4 with the single-turn launches of every rank's share (hbm_streaming);
+  cpu_baseline    the oracle's C restatement on the host cores of rank 0 (the ONLY place bench.py touches oracle/).
 """
 import argparse
 import json
@@ -63,6 +66,14 @@ WORKLOADS = {
     "c4": [(WW, 12, 2097152)],                                   # 16 777 216 rooms over 8 GPUs
     "c5": [(WW, 8, 524288), (TT, 4, 524288)],                    # 50/50 mix, one launch
 }
+L3_BYTES = 256 << 20           # Infinity Cache (MALL) of MI355X, /opt/skills/guides/MI355X_MICROARCH.md:297
+# single-turn launches over a resident state LARGER than the Infinity Cache: what a launch reads and writes cannot have been
+# left in the cache by the launch before it - the HBM figure that is provably HBM (label, profile key, segments)
+BEYOND_L3_SHAPES = (
+    ("33554432 Werewolf x8 (1 GiB of records)", "ww8_33554432", [(WW, 8, 1 << 25)]),
+    ("16777216 Werewolf x12 (the WHOLE of C4 on one GPU, 640 MiB)", "c4_whole", [(WW, 12, 1 << 24)]),
+    ("33554432 Two-Truths x4 (768 MiB)", "tt4_33554432", [(TT, 4, 1 << 25)]),
+)
 # the informational shapes of an N = 1 run: (label, profile key, per-GPU segments)
 OTHER_SHAPES = (
     ("1048576 Werewolf x8", "ww8_1048576", [(WW, 8, 1 << 20)]),
@@ -284,14 +295,14 @@ def main():
 
     stream = torch.cuda.current_stream().cuda_stream
 
-    def streaming_point(spec, launches=256):
+    def streaming_point(spec, launches=256, first_room=0, preroll=PREROLL_TURNS):
         """The HBM-streaming point of a shape: max_fuse = 1, one launch per turn - every turn reads and writes every record
         through HBM.  Device time per launch by HIP events on the launch stream, and the wall clock of hipGraph replays."""
         segs = segments_of(spec)
         rooms = sum(r for _, _, r in spec)
-        b1 = RoomBatch(segs, seed=SEED, device=device_index, max_fuse=1, restart=True)
+        b1 = RoomBatch(segs, seed=SEED, first_room=first_room, device=device_index, max_fuse=1, restart=True)
         bpr = record_bytes(b1, spec)
-        b1.step(PREROLL_TURNS, stream); b1.step(launches, stream); b1.sync()   # pre-roll; the second call builds the graph of `launches` launches
+        b1.step(preroll, stream); b1.step(launches, stream); b1.sync()   # pre-roll; the second call builds the graph of `launches` launches
         # wall clock first, without per-launch events (they serialise the launches; here the launches of a step() call are
         # replayed from a hipGraph), then the kernel time per launch
         t1 = time.perf_counter()
@@ -309,22 +320,29 @@ def main():
         k1, l1 = b1.kernel_time(reset=True)
         b1.close()
         us = k1 * 1e3 / max(l1, 1)
+        state_bytes = bpr * rooms
+        beyond = state_bytes > L3_BYTES
         gbs_wall = 2 * bpr * rooms * launches / w1 / 1e9
         gbs_kernel = 2 * bpr * rooms / (us * 1e-6) / 1e9
         gbs_graph = 2 * bpr * rooms * launches / g1 / 1e9
         return {"value": rooms * launches / w1, "unit": "room-phase steps/s (wall)", "ms_per_turn": w1 * 1e3 / launches,
-                "bound": "hbm", "bytes_per_launch": 2 * bpr * rooms,
+                "bound": "hbm", "bytes_per_launch": 2 * bpr * rooms, "rooms": rooms,
+                "resident_state_MiB": state_bytes / (1 << 20), "fits_infinity_cache": not beyond,
+                "what_frac_is": ("HBM: the resident state is larger than the 256 MiB Infinity Cache, so a launch's reads cannot be served from what the "
+                                 "previous launch left there" if beyond else
+                                 "memory-side rate (Infinity Cache may serve): the resident state fits the 256 MiB Infinity Cache and the launches replay "
+                                 "back to back over the same records - see hbm_streaming_beyond_l3 for the figure that is provably HBM"),
                 # sustained: device time of a replayed graph of back-to-back launches / launches
                 "us_per_launch_sustained": g1 * 1e6 / launches, "achieved_GBs": gbs_graph, "frac": gbs_graph / HBM_PEAK_GBS,
                 "frac_of_measured_copy_peak": gbs_graph / HBM_COPY_GBS,
                 # one launch at a time between two HIP events (includes ~2 us of event / dispatch gap per launch)
                 "kernel_us_per_launch": us, "achieved_GBs_kernel": gbs_kernel, "frac_kernel": gbs_kernel / HBM_PEAK_GBS,
                 "achieved_GBs_wall": gbs_wall, "frac_wall": gbs_wall / HBM_PEAK_GBS,
-                "note": "max_fuse=1: one launch per turn, every turn reads and writes every record through HBM (bytes_per_launch = the "
-                        "state, read + written; the committed FETCH/WRITE passes profiles/pmc_<shape>_k1.json measure the same bytes). "
+                "note": "max_fuse=1: one launch per turn, every turn reads and writes every record (bytes_per_launch = the "
+                        "state, read + written; the committed FETCH/WRITE passes profiles/pmc_<shape>_k1.json measure the same memory-side bytes). "
                         f"frac: HIP events around a hipGraph replay of {launches} launches on the launch stream; frac_kernel: HIP events around "
                         "single launches; frac_wall: host clock over 4 replays; the rocprofv3 kernel-trace average of the same launches is in "
-                        "profiles/r03_<shape>_k1_kernel_stats.csv"}
+                        "profiles/r04_<shape>_k1_kernel_stats.csv"}
 
     spec = [list(x) for x in WORKLOADS[args.workload]]
     if args.rooms:
@@ -366,6 +384,23 @@ def main():
     unfused = None
     if rank == 0 and world == 1 and not args.no_unfused:
         unfused = streaming_point(spec)
+
+    # the same launch over a state larger than the Infinity Cache (N = 1), and parity at that size: 64 single-turn launches
+    # == 64 fused turns (the whole ge_summary, checksum of every packed record included)
+    beyond_l3 = None
+    if rank == 0 and world == 1 and not args.no_unfused and not args.no_other_shapes and args.workload == "c2":
+        beyond_l3 = {}
+        for label, key, sp in BEYOND_L3_SHAPES:
+            r = sum(x[2] for x in sp)
+            pt = streaming_point(sp, launches=max(8, min(64, int(3e9 // r))), preroll=256)
+            with RoomBatch(segments_of(sp), seed=SEED, device=device_index, max_fuse=1, restart=True) as k1, \
+                 RoomBatch(segments_of(sp), seed=SEED, device=device_index, max_fuse=64, restart=True) as fz:
+                k1.step(64, stream); fz.step(64, stream)
+                s1, sf = k1.summary(), fz.summary()
+            pt["parity"] = {"turns": 64, "checksum_single_turn": s1["checksum"], "checksum_fused": sf["checksum"],
+                            "single_turn_equals_fused": s1 == sf}
+            pt["profile"] = f"profiles/r04_{key}_k1_kernel_stats.csv, profiles/pmc_{key}_k1.json"
+            beyond_l3[label] = pt
 
     # BASELINE.md §3 variant: S = 64 turns from the initial state (no recycling), 3 warm-ups, median of 10
     from_init = None
@@ -444,12 +479,26 @@ def main():
             bb.close()
             steps_s = r * world * args.fuse * k_timed / dt
             alg = 2 * bpr * steps_s / 1e9                                    # whole job
+            # every rank streams its share through single-turn launches too (C4: the configuration BASELINE names for 8 GPUs)
+            stream_pt = None
+            if key == "c4" and not args.no_unfused:
+                barrier()
+                stream_pt = streaming_point(sp, launches=64, first_room=shard_first_room(r, rank), preroll=256)
+                stream_pt["us_per_launch_sustained_max_over_ranks"] = max_over_ranks(stream_pt["us_per_launch_sustained"])
+                stream_pt["frac_min_over_ranks"] = 2 * bpr * r / (stream_pt["us_per_launch_sustained_max_over_ranks"] * 1e-6) / 1e9 / HBM_PEAK_GBS
+                barrier()
             other_workloads[key] = {
                 "workload": " + ".join(f"{x[2]} {x[0]} rooms x {x[1]} players" for x in sp) + f" per GPU, x{world} GPUs, steady state",
                 "rooms_total": r * world, "rooms_per_gpu": r, "turns_fused_per_launch": args.fuse, "launches_timed": k_timed,
                 "turns_stepped": turns_total, "seed": SEED,
                 "value": steps_s, "unit": "room-phase steps/s (whole job, wall, max over ranks)", "ms_per_launch": dt * 1e3 / k_timed,
                 "bytes_per_room_record": bpr, "algorithmic_GBs": alg, "algorithmic_frac": alg / (HBM_PEAK_GBS * world),
+                "roofline": {"bound": "hbm", "achieved": alg, "peak": HBM_PEAK_GBS * world, "unit": "GB/s", "frac": alg / (HBM_PEAK_GBS * world),
+                             "algorithmic": True, "bound_actual": "valu-issue", "traffic": None,
+                             "issue": issue_block(committed_profile(key, args.fuse), r, args.fuse * k_timed, dt),
+                             "note": "whole job over all ranks, wall clock (max over ranks); ALGORITHMIC bytes as in the top-level roofline block - "
+                                     "fused turns keep the state in registers; per-GPU issue fraction from the committed SQ pass of this shape"},
+                "hbm_streaming": stream_pt,
                 "summary_allgather_ms": ag_ms,
                 "checksum": sm["checksum"], "summary": {k: sm[k] for k in ("rooms", "finished", "village_wins", "wolf_wins", "games_recycled")}}
 
@@ -493,15 +542,21 @@ def main():
                                  "`other_shapes[*].hbm_streaming`"},
             "issue": issue,
             "hbm_streaming": unfused,
+            "hbm_streaming_beyond_l3": beyond_l3,
             "from_init_64": from_init,
             "other_shapes": other,
             "other_workloads": other_workloads,
             "summary": {k: summary[k] for k in ("rooms", "finished", "village_wins", "wolf_wins", "games_recycled", "checksum")},
             "summary_allgather_ms": summary_ms,
         }
-        if not args.no_cpu_baseline and args.workload == "c2" and world == 1:   # rank 0 at N=1 only (contract)
-            out["cpu_baseline"] = cpu_baseline(spec)
+        if not args.no_cpu_baseline and args.workload == "c2":
+            # rank 0 only.  N = 1: the contract's ~12 s sample; N > 1: a shorter one (the other ranks wait at the barrier below),
+            # so that a multi-GPU record carries its own CPU row, plus one for the C4 shape
+            out["cpu_baseline"] = cpu_baseline(spec, budget_s=12.0 if world == 1 else 5.0)
+            if world > 1 and other_workloads:
+                other_workloads["c4"]["cpu_baseline"] = cpu_baseline(WORKLOADS["c4"], budget_s=4.0, sample_rooms=1 << 18, single_thread=False)
         os.write(json_fd, (json.dumps(out) + "\n").encode())
+    barrier()
     batch.close()
     if use_dist:
         dist.destroy_process_group()

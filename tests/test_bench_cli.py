@@ -86,7 +86,12 @@ def test_gpus_2_rehearsal_on_one_card_reports_two_ranks():
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak"
     assert d["summary"]["rooms"] == 2 * 65536
     assert d["config"]["room_phase_steps_per_bench_step"] == 2 * 65536 * 1024
-    assert d["value"] > 1e9 and "cpu_baseline" not in d
+    assert d["value"] > 1e9
+    # a multi-GPU record is self-sufficient: rank 0's CPU row, the roofline block, and per workload a roofline of its own
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 1e5 and "sample" in cb
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "bound_actual"):
+        assert k in d["roofline"], k
     # one --gpus N command also yields BASELINE configs[3] (C4) and configs[4] (C5): every rank's share, timed all-gather
     ow = d["other_workloads"]
     assert set(ow) == {"c4", "c5"}
@@ -95,6 +100,14 @@ def test_gpus_2_rehearsal_on_one_card_reports_two_ranks():
         for k in ("rooms_total", "value", "algorithmic_frac", "summary_allgather_ms", "checksum", "turns_stepped", "ms_per_launch"):
             assert k in w, (key, k)
         assert w["rooms_total"] == 2 * rooms_per_gpu == w["summary"]["rooms"] and w["value"] > 1e9
+        rf = w["roofline"]
+        assert rf["bound"] == "hbm" and rf["algorithmic"] is True and rf["bound_actual"] == "valu-issue" and rf["peak"] == 2 * 8000.0
+        assert abs(rf["frac"] - w["algorithmic_frac"]) < 1e-12 and "issue" in rf
+    # C4, the configuration BASELINE names for 8 GPUs: every rank's share through single-turn launches, and a CPU row
+    hs = ow["c4"]["hbm_streaming"]
+    assert hs["rooms"] == 2097152 and hs["bytes_per_launch"] == 2 * 40 * 2097152 and 0 < hs["frac_min_over_ranks"] <= hs["frac"] * 1.0001
+    assert hs["fits_infinity_cache"] is True and "memory-side" in hs["what_frac_is"]
+    assert ow["c4"]["cpu_baseline"]["kind"] == "port" and ow["c5"]["hbm_streaming"] is None
     # the C4 checksum of the two-rank job = the sum of the two shards stepped on their own (rooms keep their global index)
     from conftest import load_dsl
     from game_engine_amd import GameTable, RoomBatch

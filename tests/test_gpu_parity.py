@@ -448,3 +448,27 @@ def test_checkpoint_file_resumes_bit_exact(tmp_path):
         got_sum = resumed.summary()
     assert got_sum["checksum"] == want_sum["checksum"] and got_sum["turn"] == 67
     assert got_sum["games_recycled"] <= want_sum["games_recycled"]        # (the counter restarts with the new batch; states do not)
+
+
+@pytest.mark.parametrize("game,n,n_rooms", [("werewolf-(mafia)", 8, 1 << 25),       # 1 GiB of records
+                                            ("werewolf-(mafia)", 12, 1 << 24),      # the whole of C4 on one GPU, 640 MiB
+                                            ("two-truths-and-a-lie", 4, 1 << 25)])  # 768 MiB
+def test_single_turn_launches_beyond_the_infinity_cache_equal_fused_and_oracle(game, n, n_rooms):
+    """The sizes bench.py's hbm_streaming_beyond_l3 streams (resident state larger than the 256 MiB Infinity Cache): 70
+    single-turn launches == 70 fused turns (the whole summary, the checksum over every packed record included), and windows
+    of rooms at both ends and in the middle equal the oracle.  70 turns cross the Werewolf x 12 side plane's refill turn and
+    a restart, so prepared deals are written, read back and consumed at this size."""
+    dsl = load_dsl(game)
+    tb = GameTable(dsl)
+    orc = _oracle(dsl, n)
+    seed, first, turns, win = 0xC0FFEE, 1 << 36, 70, 4096
+    with RoomBatch([(tb, n, n_rooms)], seed=seed, first_room=first, max_fuse=1, restart=True) as k1:
+        k1.step(turns)
+        s1 = k1.summary()
+        for lo in (0, n_rooms // 2 - 77, n_rooms - win):
+            assert_views_equal(k1.read_rooms(lo, win), oracle_batch(orc, win, seed, first + lo, turns, restart=True),
+                               f"{game} x{n}: rooms {lo}.. of {n_rooms}, single-turn launches")
+    with RoomBatch([(tb, n, n_rooms)], seed=seed, first_room=first, max_fuse=64, restart=True) as fz:
+        fz.step(turns)
+        sf = fz.summary()
+    assert s1 == sf and s1["rooms"] == n_rooms and s1["turn"] == turns and s1["games_recycled"] > 0
