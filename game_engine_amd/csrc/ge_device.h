@@ -498,140 +498,150 @@ template <int NB, int FORM> __device__ __forceinline__ uint32_t deal_to_cache(co
 }
 
 // ------------------------------------------------------------------ generic target conditions
-// The slow path of `target_players.condition`: an OR of AND-clauses of literals (ge_layout.h DevCond), for DSLs that use
-// the rest of the grammar (or, in [..], numeric comparisons).  Only the GENERIC kernel builds contain it, and only
-// the lanes whose current row is flagged ROW_GENERIC run it; the shipped games never do.
-template <int NB> __device__ __forceinline__ uint32_t ww_base_mask(const WWR<NB> &s, uint32_t set) {
-    uint32_t m = 0;
-    m |= (set >> F_ALIVE) & 1u ? s.template get<F_ALIVE>() : 0u;       m |= (set >> F_CAN_VOTE) & 1u ? s.template get<F_CAN_VOTE>() : 0u;
-    m |= (set >> F_REVEALED) & 1u ? s.template get<F_REVEALED>() : 0u; m |= (set >> F_SECRET) & 1u ? s.template get<F_SECRET>() : 0u;
-    m |= (set >> F_ELIG) & 1u ? s.template get<F_ELIG>() : 0u;         m |= (set >> F_SUB) & 1u ? s.template get<F_SUB>() : 0u;
-    m |= (set >> F_TEAM_V) & 1u ? s.template get<F_TEAM_V>() : 0u;     m |= (set >> F_TEAM_W) & 1u ? s.template get<F_TEAM_W>() : 0u;
-    m |= (set >> F_VIL) & 1u ? s.template get<F_VIL>() : 0u;           m |= (set >> F_WOLF) & 1u ? s.template get<F_WOLF>() : 0u;
-    m |= (set >> F_DOC) & 1u ? s.template get<F_DOC>() : 0u;           m |= (set >> F_DET) & 1u ? s.template get<F_DET>() : 0u;
-    return m;
+// The slow path of `target_players.condition`: an OR of AND-clauses of literals, for DSLs that use the rest of the grammar
+// (or, in [..], numeric comparisons - agent/prompt/dsl_phases_generation_prompt.txt:106-150).  Only the GENERIC kernel
+// builds contain it, and only the lanes whose current row is flagged ROW_GENERIC use its result; the shipped games never do.
+// The literals come from the block's LDS copy of the table's literal image (ge_layout.h CondLit): every generic row padded
+// to the table's common shape, so the loops below are rolled and wave-uniform - two scalar counters, no per-lane clause
+// count or length, no unrolled 4 x 4 slots (what made round 3's form spill 72 - 711 scalar registers).
+
+// the even bits of x (bit 2i -> bit i), NF fields (12 at most)
+template <int NF = 12> __device__ __forceinline__ uint32_t even_bits(uint32_t x) {
+    x &= 0x00555555u;
+    x = (x | (x >> 1)) & 0x00333333u; x = (x | (x >> 2)) & 0x000F0F0Fu;
+    if (NF > 4) x = (x | (x >> 4)) & 0x00FF00FFu;
+    if (NF > 8) x = (x | (x >> 8)) & 0x0000FFFFu;
+    return x;
 }
 
-// players whose small-integer field (FB bits per player in `arr`) lies in [lo, hi]
-template <int NB, int FB, typename arr_t> __device__ __forceinline__ uint32_t range_mask(arr_t arr, uint32_t lo, uint32_t hi) {
-    uint32_t m = 0;
-#pragma unroll
-    for (int i = 0; i < NB; i++) {
-        const uint32_t v = (uint32_t)(arr >> (FB * i)) & ((1u << FB) - 1u);
-        m |= (v >= lo && v <= hi ? 1u : 0u) << i;
+// v in [lo, hi] for small fields, several players per word (SWAR).  Every field sits in a byte (half-word) of its own with
+// the top bit free: (v | G) - lo keeps the top bit iff v >= lo, (hi | G) - v iff v <= hi, and no borrow crosses a field.
+// lo4 = lo in every byte, hi4 = hi | 0x80 in every byte (prepared by the host: ge_step.hip build_cond_image).
+__device__ __forceinline__ uint32_t in_range_bytes(uint32_t v, uint32_t lo4, uint32_t hi4) {
+    return ((v | 0x80808080u) - lo4) & (hi4 - v) & 0x80808080u;
+}
+
+// a nibble array (selected_target_id, rounds_as_speaker): player mask of the nibbles in range
+template <int NB> __device__ __forceinline__ uint32_t range_nibbles(uint64_t arr, uint32_t lo4, uint32_t hi4) {
+    const uint32_t w0 = (uint32_t)arr;
+    if (NB <= 4) {
+        const uint32_t v = (w0 & 0x0F0Fu) | (((w0 >> 4) & 0x0F0Fu) << 16);          // bytes: players 0, 2, 1, 3
+        const uint32_t q = in_range_bytes(v, lo4, hi4) >> 7;
+        return (q | (q >> 15) | (q >> 6) | (q >> 21)) & 0xFu;
     }
-    return m;
+    const uint32_t ie = in_range_bytes(w0 & 0x0F0F0F0Fu, lo4, hi4), io = in_range_bytes((w0 >> 4) & 0x0F0F0F0Fu, lo4, hi4);
+    const uint32_t p = (ie >> 7) | (io >> 6);                    // bits 0 / 1 of byte k = players 2k / 2k + 1
+    uint32_t r = (p | (p >> 6) | (p >> 12) | (p >> 18)) & 0xFFu;
+    if (NB > 8) {
+        const uint32_t w1 = (uint32_t)(arr >> 32) & 0xFFFFu;
+        const uint32_t v = (w1 | (w1 << 12)) & 0x0F0F0F0Fu;      // bytes: players 8, 10, 9, 11
+        const uint32_t q = in_range_bytes(v, lo4, hi4) >> 7;
+        r |= ((q | (q >> 15) | (q >> 6) | (q >> 21)) & 0xFu) << 8;
+    }
+    return r;
 }
 
-// `shape` (DevTable::cond_shape, wave-uniform): the largest clause count [2:0] and clause length [6:4] among the table's
-// generic rows, and whether any of their literals is a base set [8] / a numeric range [9] - the loops stop there and the
-// literal kind nobody uses is not evaluated (a typical generated condition has two clauses of two or three literals)
-template <typename LITMASK> __device__ __forceinline__ uint32_t eval_clauses(const DevCond &c, uint32_t all, uint32_t shape, LITMASK lit_mask) {
-    const uint32_t ncl = c.meta & 7u;
-    const uint32_t max_ncl = shape & 7u, max_len = (shape >> 4) & 7u;
-    uint32_t T = ncl ? 0u : all;                              // no condition: everybody
+// a 2-bit array (lie_index, vote_choice): the range as its set of allowed values - a0 = allowed(0) in the even bits |
+// allowed(1) in the odd bits, a1 = allowed(2) | allowed(3) likewise; two bit-selects pick the entry of every field
+template <int NB> __device__ __forceinline__ uint32_t range_2bit(uint32_t x, uint32_t a0, uint32_t a1) {
+    const uint32_t b0 = x & 0x00555555u, b1 = (x >> 1) & 0x00555555u;
+    const uint32_t H = b1 | (b1 << 1);
+    const uint32_t t = (H & a1) | (~H & a0);                     // even bits: b1 ? allowed(2) : allowed(0); odd: b1 ? allowed(3) : allowed(1)
+    return even_bits<NB>((b0 & (t >> 1)) | (~b0 & t));
+}
+
+// a byte array (total_score, up to 255): half-word lanes, two players per word; lo2 = lo in both halves, hi2 = hi | 0x8000
+template <int NB> __device__ __forceinline__ uint32_t range_score(const uint32_t *score, uint32_t lo2, uint32_t hi2) {
+    uint32_t r = 0;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        if ((uint32_t)k >= max_ncl) break;                    // wave-uniform
-        const uint32_t len = (c.meta >> (4 + 4 * k)) & 7u;
+    for (int w = 0; w < (NB + 3) / 4; w++) {
+        const uint32_t a = score[w] & 0x00FF00FFu, b = (score[w] >> 8) & 0x00FF00FFu;          // players 4w, 4w + 2 | 4w + 1, 4w + 3
+        const uint32_t ia = ((a | 0x80008000u) - lo2) & (hi2 - a) & 0x80008000u;
+        const uint32_t ib = ((b | 0x80008000u) - lo2) & (hi2 - b) & 0x80008000u;
+        const uint32_t q = ((ia >> 15) & 1u) | ((ib >> 14) & 2u) | ((ia >> 29) & 4u) | ((ib >> 28) & 8u);
+        r |= q << (4 * w);
+    }
+    return r;
+}
+
+// what a launch keeps in scalar registers about the table's generic rows
+struct CondCtx {
+    const unsigned char *img;  // the block's LDS copy of DevTable::cond_img
+    CondShape cs;              // shape [2:0] clauses, [6:4] literals per clause; slots: bit 4k + l = slot (k, l) holds a base set
+                               // in some row, bit 16 + 4k + l = a numeric range; f0 / f1: Two-Truths, nibble per slot = fields compared
+};
+
+// OR over clauses of AND over literals; `lit(d, e, slot)` -> the literal's player mask before negation (d = the literal's
+// first four words, e = its second four: Werewolf x 12 only).  Rolled, wave-uniform loops: two scalar counters.
+// (Issuing the next literal's LDS read before evaluating the current one was measured and is slower at every shape - four
+// to eight more live registers and the copies at the loop's back edge: profiles/r04_generic_probe.txt.)
+template <int STRIDE, typename LIT>
+__device__ __forceinline__ uint32_t eval_cond_image(const CondCtx &cc, uint32_t row_r0, uint32_t all, LIT lit) {
+    const uint32_t ncl = cc.cs.shape & 7u, len = (cc.cs.shape >> 4) & 7u;                     // wave-uniform
+    const unsigned char *p = cc.img + ((row_r0 >> ROW_COND_SLOT_SHIFT) & 31u) * (ncl * len * (uint32_t)STRIDE);
+    uint32_t T = 0;
+#pragma nounroll
+    for (uint32_t k = 0; k < ncl; k++) {
         uint32_t m = all;
-#pragma unroll
-        for (int l = 0; l < 4; l++) {
-            if ((uint32_t)l >= max_len) break;                // wave-uniform
-            const uint32_t w = c.lit[k][l];
-            const uint32_t x = lit_mask(w, k, l) ^ ((w >> 30) & 1u ? all : 0u);
-            m &= (uint32_t)l < len ? x : all;
+#pragma nounroll
+        for (uint32_t l = 0; l < len; l++) {
+            const uint4 d = *reinterpret_cast<const uint4 *>(p);
+            uint4 e = make_uint4(0u, 0u, 0u, 0u);
+            if (STRIDE > 16) e = *reinterpret_cast<const uint4 *>(p + 16);
+            const uint32_t x = lit(d, e, 4u * k + l);
+            m &= x ^ (d.x >> 16);                                                             // negated: 0xFFFF in the top half of w
+            p += STRIDE;
         }
-        T |= (uint32_t)k < ncl ? m : 0u;
+        T |= m;
     }
     return T & all;
 }
 
-// N <= 8: literals prepared for the packed predicate words (DevCond::prep, built by to_dev_cond)
-// `slots` (DevTable::cond_slots, wave-uniform): which (clause, literal) slots hold a base set / a numeric range in some row
-__device__ __forceinline__ uint32_t ww8_cond_generic(const WWR<8> &s, const DevCond &c, uint32_t all, uint32_t shape, uint32_t slots) {
-    const uint32_t ncl = c.meta & 7u;
-    const uint32_t max_ncl = shape & 7u, max_len = (shape >> 4) & 7u;
-    // the selected-target nibbles of the even / odd players, one per byte
-    const uint32_t ev = s.sel & 0x0F0F0F0Fu, od = (s.sel >> 4) & 0x0F0F0F0Fu;
-    uint32_t T = ncl ? 0u : all;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        if ((uint32_t)k >= max_ncl) break;                    // wave-uniform
-        const uint32_t len = (c.meta >> (4 + 4 * k)) & 7u;
-        uint32_t m = all;
-#pragma unroll
-        for (int l = 0; l < 4; l++) {
-            if ((uint32_t)l >= max_len) break;                // wave-uniform
-            const DevLit q = c.prep[k][l];                    // one 16-byte load
-            const uint32_t w = q.w, a0 = q.a0, a1 = q.a1;
-            uint32_t x = 0;
-            const bool any_base = (slots >> (4 * k + l)) & 1u, any_num = (slots >> (16 + 4 * k + l)) & 1u;   // wave-uniform
-            if (any_base) {                                   // gather the set's fields, OR-fold the four bytes
-                uint32_t g = __builtin_amdgcn_perm(s.W[1], s.W[0], a0) | __builtin_amdgcn_perm(s.W[2], s.W[2], a1);
+template <int NB> __device__ __forceinline__ uint32_t ww_cond_generic(const WWR<NB> &s, const CondCtx &cc, uint32_t row_r0, uint32_t all) {
+    constexpr int STRIDE = NB <= 8 ? (int)sizeof(CondLit) : (int)sizeof(CondLit12);
+    return eval_cond_image<STRIDE>(cc, row_r0, all, [&](const uint4 &d, const uint4 &e, uint32_t slot) -> uint32_t {   // d = {w, m0, m1, m2}, e = {m3, m4, m5, -}
+        const bool any_base = (cc.cs.slots >> slot) & 1u, any_num = (cc.cs.slots >> (16u + slot)) & 1u;       // wave-uniform
+        uint32_t x = 0;
+        if (any_base) {
+            uint32_t g;
+            if (NB <= 8) {
+                g = (s.W[0] & d.y) | (s.W[1] & d.z) | (s.W[2] & d.w);
                 g |= g >> 16; g |= g >> 8;
-                x = g & 0xFFu;
+            } else {
+                g = (s.W[0] & d.y) | (s.W[1] & d.z) | (s.W[2] & d.w) | (s.W[WWR<NB>::NW > 3 ? 3 : 0] & e.x) |
+                    (s.W[WWR<NB>::NW > 4 ? 4 : 0] & e.y) | (s.W[WWR<NB>::NW > 5 ? 5 : 0] & e.z);
+                g |= g >> 16;
             }
-            if (any_num) {                                    // lo <= v <= hi, four players per word: bit 7 of a byte = in range
-                const uint32_t ie = ((ev | 0x80808080u) - a0) & (a1 - ev) & 0x80808080u;
-                const uint32_t io = ((od | 0x80808080u) - a0) & (a1 - od) & 0x80808080u;
-                const uint32_t p = (ie >> 7) | (io >> 6);     // bits 0 / 1 of every byte = the byte's even / odd player
-                const uint32_t r = (p | (p >> 6) | (p >> 12) | (p >> 18)) & 0xFFu;
-                x = (any_base && ((w >> 28) & 3u) == 1u) ? x : r;
-            }
-            x ^= (w >> 30) & 1u ? all : 0u;
-            m &= (uint32_t)l < len ? x : all;
+            x = g;
         }
-        T |= (uint32_t)k < ncl ? m : 0u;
-    }
-    return T & all;
-}
-
-template <int NB> __device__ __forceinline__ uint32_t ww_cond_generic(const WWR<NB> &s, const DevCond &c, uint32_t all, CondShape cs) {
-    if constexpr (NB <= 8) {
-        if (!(c.meta >> 31)) return ww8_cond_generic(s, c, all, cs.shape, cs.slots);
-    }
-    return eval_clauses(c, all, cs.shape, [&](uint32_t w, int k, int l) -> uint32_t {
-        const bool any_base = (cs.slots >> (4 * k + l)) & 1u, any_num = (cs.slots >> (16 + 4 * k + l)) & 1u;   // wave-uniform
-        uint32_t m = 0;
-        if (any_base) m = ww_base_mask<NB>(s, w & 0xFFFFu);
-        if (any_num) {
-            const uint32_t r = range_mask<NB, 4>(s.sel, w & 0xFFu, (w >> 8) & 0xFFu);   // GE_NUM_SELECTED_TARGET is the pack's only numeric field
-            m = (any_base && ((w >> 28) & 3u) == 1u) ? m : r;
+        if (any_num) {                                           // GE_NUM_SELECTED_TARGET is the pack's only numeric field
+            const uint32_t r = range_nibbles<NB>((uint64_t)s.sel, d.y, d.z);
+            x = bfi(bit_mask(d.x, 0u), r, x);                     // by the literal's own kind (a neutral literal of another row sits in this slot as a base set)
         }
-        return m;
+        return x;
     });
 }
 
-template <int NB> __device__ __forceinline__ uint32_t tt_cond_generic(const TT<NB> &s, const DevCond &c, uint32_t all, CondShape cs) {
-    return eval_clauses(c, all, cs.shape, [&](uint32_t w, int k, int l) -> uint32_t {
+template <int NB> __device__ __forceinline__ uint32_t tt_cond_generic(const TT<NB> &s, const CondCtx &cc, uint32_t row_r0, uint32_t all) {
+    const uint32_t W0 = s.speaker | (s.submitted << 16), W1 = s.revealed | (s.can_vote << 16), W2 = s.has_voted;
+    return eval_cond_image<(int)sizeof(CondLit)>(cc, row_r0, all, [&](const uint4 &d, const uint4 &, uint32_t slot) -> uint32_t {
         // wave-uniform: what slot (k, l) holds in some row of the table - a base set, and / or a range over which fields
-        const bool any_base = (cs.slots >> (4 * k + l)) & 1u;
-        const uint32_t flds = ((4 * k + l) < 8 ? cs.f0 >> (4 * ((4 * k + l) & 7)) : cs.f1 >> (4 * ((4 * k + l) & 7))) & 15u;
-        uint32_t m = 0;
+        const bool any_base = (cc.cs.slots >> slot) & 1u;
+        const uint32_t flds = (slot < 8u ? cc.cs.f0 >> (4u * slot) : cc.cs.f1 >> (4u * (slot - 8u))) & 15u;
+        uint32_t x = 0;
         if (any_base) {
-            const uint32_t set = w & 0xFFFFu;
-            m = ((set & 1u) ? s.speaker : 0u) | ((set & 2u) ? s.submitted : 0u) | ((set & 4u) ? s.revealed : 0u) |
-                ((set & 8u) ? s.can_vote : 0u) | ((set & 16u) ? s.has_voted : 0u);
+            uint32_t g = (W0 & d.y) | (W1 & d.z) | (W2 & d.w);
+            g |= g >> 16;
+            x = g;
         }
         if (flds) {
-            const uint32_t lo = w & 0xFFu, hi = (w >> 8) & 0xFFu, f = (w >> 16) & 7u;
-            uint32_t r = 0;
-            if (flds & 1u) r = f == 1u ? range_mask<NB, 2>(s.lie, lo, hi) : r;                    // GE_NUM_LIE_INDEX
-            if (flds & 2u) r = f == 2u ? range_mask<NB, 2>(s.vote, lo, hi) : r;                   // GE_NUM_VOTE_CHOICE
-            if (flds & 8u) r = f == 4u ? range_mask<NB, 4>(s.rounds, lo, hi) : r;                 // GE_NUM_ROUNDS_AS_SPEAKER
-            if (flds & 4u) {                                                                      // GE_NUM_TOTAL_SCORE: a byte per player
-                uint32_t q = 0;
-#pragma unroll
-                for (int i = 0; i < NB; i++) {
-                    const uint32_t v = (s.score[i / 4] >> (8 * (i % 4))) & 255u;
-                    q |= (v >= lo && v <= hi ? 1u : 0u) << i;
-                }
-                r = f == 3u ? q : r;
-            }
-            m = (any_base && ((w >> 28) & 3u) == 1u) ? m : r;
+            // the literal's field one-hot in w bits 4..7: bit-selects, no compares and no exec-mask regions
+            if (flds & 1u) x = bfi(bit_mask(d.x, 4u), range_2bit<NB>(s.lie, d.y, d.z), x);       // GE_NUM_LIE_INDEX
+            if (flds & 2u) x = bfi(bit_mask(d.x, 5u), range_2bit<NB>(s.vote, d.y, d.z), x);      // GE_NUM_VOTE_CHOICE
+            if (flds & 4u) x = bfi(bit_mask(d.x, 6u), range_score<NB>(s.score, d.y, d.z), x);    // GE_NUM_TOTAL_SCORE
+            if (flds & 8u) x = bfi(bit_mask(d.x, 7u), range_nibbles<NB>(s.rounds, d.y, d.z), x); // GE_NUM_ROUNDS_AS_SPEAKER
         }
-        return m;
+        return x;
     });
 }
 
@@ -647,8 +657,7 @@ template <int NB> __device__ __forceinline__ uint32_t tt_cond_generic(const TT<N
 // what a launch keeps constant for a lane's turns
 struct WwCtx {
     const DevRow *rows;        // phase table in LDS
-    const DevCond *conds;      // clause forms of the generic rows (global memory; GENERIC builds only)
-    CondShape cs;
+    CondCtx cc;                // the generic rows' literal image in LDS and its shape (GENERIC builds only)
     void *wave_lds;            // this wavefront's WaveLds / WaveLdsLow
     const uint8_t *nth8;       // LDS n-th-set-bit table (large-batch build)
     const uint32_t *ord8;      // LDS slot -> player table (N <= 8)
@@ -694,7 +703,7 @@ __device__ __forceinline__ uint32_t ww_targets(const WWR<NB> &s, const DevRow &r
         T = X & alive & (comp == COMP_ACTION ? ALL : 0u);
     }
     if (GENERIC && (row.r0 & ROW_GENERIC) && comp == COMP_ACTION)        // or / in [..] / numeric comparisons: the clause form
-        T = ww_cond_generic<NB>(s, c.conds[s.phase], ALL, c.cs) & alive;
+        T = ww_cond_generic<NB>(s, c.cc, row.r0, ALL) & alive;
     return T;
 }
 
@@ -1033,19 +1042,11 @@ template <int NB> __device__ __forceinline__ uint32_t tt_done_mask(uint64_t roun
     return m;
 }
 
-// the even bits of x (bit 2i -> bit i), 12 fields at most
-__device__ __forceinline__ uint32_t even_bits(uint32_t x) {
-    x &= 0x00555555u;
-    x = (x | (x >> 1)) & 0x00333333u; x = (x | (x >> 2)) & 0x000F0F0Fu;
-    x = (x | (x >> 4)) & 0x00FF00FFu; x = (x | (x >> 8)) & 0x0000FFFFu;
-    return x;
-}
-
 // QUEUE: bot actions through the wavefront work queue (see ww_turn) - pays from 8 players on, where the
 // first turn of a vote has 7-11 due bots in some room of every wavefront; TABLE: n-th-set-bit from LDS
 // SINGLE: a one-turn launch - the row the room moves to is not fetched (only whether it is terminal: term_mask)
 template <int NB, bool QUEUE, bool TABLE, bool GENERIC = false, bool SINGLE = false>
-__device__ __forceinline__ void tt_turn(TT<NB> &s, uint32_t &done, DevRow &row, const DevRow *rows, const DevCond *conds, CondShape cs, void *wave_lds, const uint8_t *nth8,
+__device__ __forceinline__ void tt_turn(TT<NB> &s, uint32_t &done, DevRow &row, const DevRow *rows, const CondCtx &cc, void *wave_lds, const uint8_t *nth8,
                                         bool valid, uint32_t n, uint32_t rounds,
                                         uint32_t phase0_idx, uint32_t rkey, uint32_t turn,
                                         bool trace, uint32_t human, uint32_t term_mask, uint32_t &ev_newly, uint64_t &ev_choice) {
@@ -1076,7 +1077,7 @@ __device__ __forceinline__ void tt_turn(TT<NB> &s, uint32_t &done, DevRow &row, 
         T = X & ALL;
     }
     if (GENERIC && (row.r0 & ROW_GENERIC) && comp == COMP_ACTION)        // the clause form (see ww_turn)
-        T = tt_cond_generic<NB>(s, conds[s.phase], ALL, cs);
+        T = tt_cond_generic<NB>(s, cc, row.r0, ALL);
 
     uint32_t newly = 0;
     {

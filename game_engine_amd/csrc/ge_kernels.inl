@@ -31,6 +31,7 @@ struct StepArgs {
     const uint32_t *turn_dev;  // launches replayed from a hipGraph: turn0 is relative to this device word (else null)
     unsigned long long *stamps; // GE_STAMPS diagnostic build: 4 segment sums + wave-turn count (else null)
     uint32_t n_seg, turn0, n_turns, seed_key, block_threads, restart, trace, lowocc;
+    uint32_t cond_off;         // GENERIC builds: byte offset of the literal image (DevTable::cond_img) in a block's LDS, behind everything else
     uint32_t block_begin[GE_MAX_SEGMENTS];
 };
 
@@ -100,9 +101,16 @@ constexpr uint32_t LDS_S0 = 128;       // 20 words of init_regs, padded
 // element per thread and pass.  All passes' loads are issued before the first LDS write (a load -> wait -> write loop
 // serialises one L2 round trip per pass in front of every wavefront of a single-turn launch); the large-batch builds also
 // copy the restart template behind the image.
-template <uint32_t N16, bool WITH_S0>
-__device__ __forceinline__ void load_rows(DevRow *rows, const DevTable *tables, uint32_t table_idx, const SegDev *sg) {
+template <uint32_t N16, bool WITH_S0, bool GENERIC = false>
+__device__ __forceinline__ void load_rows(DevRow *rows, const DevTable *tables, uint32_t table_idx, const SegDev *sg, uint32_t cond_off = 0u) {
     const u32x4 *src = reinterpret_cast<const u32x4 *>(tables + table_idx);
+    if (GENERIC) {
+        // the generic rows' literal image (ge_layout.h CondLit): cond_n16 elements, a few hundred bytes for a typical DSL
+        const u32x4 *ci = reinterpret_cast<const u32x4 *>(tables[table_idx].cond_img);
+        u32x4 *cd = reinterpret_cast<u32x4 *>(reinterpret_cast<unsigned char *>(rows) + cond_off);
+        const uint32_t n16 = __builtin_amdgcn_readfirstlane(tables[table_idx].cond_n16);
+        for (uint32_t i = threadIdx.x; i < n16; i += blockDim.x) cd[i] = ci[i];
+    }
     u32x4 *dst = reinterpret_cast<u32x4 *>(rows);
     const uint32_t bd = blockDim.x, tid = threadIdx.x;
     // the restart template behind the image (large-batch turn loops; a single-turn build reads it through the scalar cache)
@@ -167,7 +175,7 @@ __device__ __forceinline__ void run_ww(const SegDev *__restrict__ sgp, const Ste
     load_words<L::WORDS, (NB > 8)>(sg.base, sg.rooms_padded, room, w);   // in flight while the block fills its LDS tables; streaming: see load_words
     // the slot -> player table of the action queue sits right behind the phase rows (step_lds_bytes)
     uint32_t *ord8 = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(rows) + LDS_ROWS);
-    load_rows<B::TABLE ? IMG_END / 16u : B::ORD ? 128u : 64u, !LOWOCC && !SINGLE>(rows, tables, sg.table_idx, sgp);
+    load_rows<B::TABLE ? IMG_END / 16u : B::ORD ? 128u : 64u, !LOWOCC && !SINGLE, GENERIC>(rows, tables, sg.table_idx, sgp, a.cond_off);
     WWR<NB> s;
     uint32_t cache;
     if (NB <= 8 && !SINGLE) {
@@ -214,7 +222,7 @@ __device__ __forceinline__ void run_ww(const SegDev *__restrict__ sgp, const Ste
     uint32_t tk = turn_key(rk, turn0);                        // this turn's key; ww_turn leaves the next turn's (computed in an LDS wait shadow)
     Stamps stamps;
     if (GE_STAMPS) stamps.start();
-    const WwCtx ctx = {rows, tables[sg.table_idx].conds, cs, lw, nth8, ord8, valid, sg.n_players, sg.nw, sg.phase0_idx, rk, sg.human_mask, term_mask};
+    const WwCtx ctx = {rows, CondCtx{reinterpret_cast<const unsigned char *>(rows) + a.cond_off, cs}, lw, nth8, ord8, valid, sg.n_players, sg.nw, sg.phase0_idx, rk, sg.human_mask, term_mask};
     if constexpr (SINGLE) {
         // one turn, no loop: the row is fetched after the restart decision (terminal rows are a bit mask), nothing is
         // prepared for a next turn
@@ -320,7 +328,7 @@ __device__ __forceinline__ void run_tt(const SegDev *__restrict__ sgp, const Ste
     const uint64_t room = valid ? room_in : 0;
     uint32_t w[L::WORDS];
     load_words<L::WORDS, true>(sg.base, sg.rooms_padded, room, w);
-    load_rows<(QUEUE && !LOWOCC) ? 256u : 64u, QUEUE && !LOWOCC && !SINGLE>(rows, tables, sg.table_idx, sgp);
+    load_rows<(QUEUE && !LOWOCC) ? 256u : 64u, QUEUE && !LOWOCC && !SINGLE, GENERIC>(rows, tables, sg.table_idx, sgp, a.cond_off);
     TT<NB> s;
     L::unpack(w, s);
     const uint32_t rk = room_key_from(a.seed_key, sg.first_global + room);
@@ -344,6 +352,7 @@ __device__ __forceinline__ void run_tt(const SegDev *__restrict__ sgp, const Ste
     CondShape cs = {0u, 0u, 0u, 0u};
     if (GENERIC) cs = CondShape{(uint32_t)__builtin_amdgcn_readfirstlane(tables[sg.table_idx].cond_shape), (uint32_t)__builtin_amdgcn_readfirstlane(tables[sg.table_idx].cond_slots),
                                (uint32_t)__builtin_amdgcn_readfirstlane(tables[sg.table_idx].cond_fields[0]), (uint32_t)__builtin_amdgcn_readfirstlane(tables[sg.table_idx].cond_fields[1])};
+    const CondCtx cc = {reinterpret_cast<const unsigned char *>(rows) + a.cond_off, cs};
     uint32_t done = tt_done_mask<NB>(s.rounds, sg.rounds);   // who has spoken all agreed rounds (ge_device.h)
     if constexpr (SINGLE) {
         uint32_t restarted = 0;
@@ -358,7 +367,7 @@ __device__ __forceinline__ void run_tt(const SegDev *__restrict__ sgp, const Ste
         const uint32_t p = s.phase;
         uint32_t ev_newly = 0;
         uint64_t ev_choice = 0;
-        tt_turn<NB, QUEUE, !LOWOCC, GENERIC, true>(s, done, row, rows, tables[sg.table_idx].conds, cs, lw, nth8, valid, sg.n_players, sg.rounds, sg.phase0_idx, rk, turn0, a.trace != 0u, sg.human_mask, term_mask, ev_newly, ev_choice);
+        tt_turn<NB, QUEUE, !LOWOCC, GENERIC, true>(s, done, row, rows, cc, lw, nth8, valid, sg.n_players, sg.rounds, sg.phase0_idx, rk, turn0, a.trace != 0u, sg.human_mask, term_mask, ev_newly, ev_choice);
         if (a.trace && valid) store_event(sg.trace, sg.rooms_padded, 0u, room, turn0, p, s.phase, restarted, ev_newly, ev_choice);
     } else {
         DevRow row = rows[s.phase];
@@ -378,7 +387,7 @@ __device__ __forceinline__ void run_tt(const SegDev *__restrict__ sgp, const Ste
             const uint32_t p = s.phase;
             uint32_t ev_newly = 0;
             uint64_t ev_choice = 0;
-            tt_turn<NB, QUEUE, !LOWOCC, GENERIC, false>(s, done, row, rows, tables[sg.table_idx].conds, cs, lw, nth8, valid, sg.n_players, sg.rounds, sg.phase0_idx, rk, turn0 + t, a.trace != 0u, sg.human_mask, term_mask, ev_newly, ev_choice);
+            tt_turn<NB, QUEUE, !LOWOCC, GENERIC, false>(s, done, row, rows, cc, lw, nth8, valid, sg.n_players, sg.rounds, sg.phase0_idx, rk, turn0 + t, a.trace != 0u, sg.human_mask, term_mask, ev_newly, ev_choice);
             if (a.trace && valid) store_event(sg.trace, sg.rooms_padded, t, room, turn0 + t, p, s.phase, restarted, ev_newly, ev_choice);
         }
     }
@@ -413,6 +422,7 @@ inline uint32_t step_lds_bytes(bool queue, bool lowocc, uint32_t block_threads) 
     if (!queue) return LDS_ROWS;                              // Two-Truths N <= 4: phase rows only
     return LDS_ROWS + LDS_ORD8 + (lowocc ? 0u : LDS_NTH8 + LDS_S0) + (uint32_t)(lowocc ? sizeof(WaveLdsLow) : sizeof(WaveLds)) * (block_threads / 64u);
 }
+// (GENERIC builds: the literal image of the table's generic rows follows at StepArgs::cond_off = this size, cond_bytes more)
 
 extern __shared__ __align__(16) unsigned char ge_lds[];
 
@@ -429,9 +439,13 @@ extern __shared__ __align__(16) unsigned char ge_lds[];
 #ifndef GE_WW8_WAVES
 #define GE_WW8_WAVES 1
 #endif
+// the large-batch builds for tables with generic target conditions (every layout); 7 would mean at most 72 VGPRs
+#ifndef GE_GENERIC_WAVES
+#define GE_GENERIC_WAVES 1
+#endif
 // SINGLE: the launch is one turn (a.n_turns == 1) of a single-game batch with shipped-grammar conditions (run_ww / run_tt)
 template <int KIND, bool LOWOCC, bool GENERIC = false, bool SINGLE = false>
-__global__ void __launch_bounds__(SINGLE ? 1024 : 256, SINGLE ? 8 : (KIND == K_WW12 && !LOWOCC && !GENERIC) ? GE_WW12_WAVES : (KIND == K_WW8 && !LOWOCC && !GENERIC) ? GE_WW8_WAVES : 1) ge_step_kernel(const SegDev *__restrict__ segs, const DevTable *__restrict__ tables, const StepArgs a) {
+__global__ void __launch_bounds__(SINGLE ? 1024 : 256, SINGLE ? 8 : (!LOWOCC && GENERIC) ? GE_GENERIC_WAVES : (KIND == K_WW12 && !LOWOCC) ? GE_WW12_WAVES : (KIND == K_WW8 && !LOWOCC) ? GE_WW8_WAVES : 1) ge_step_kernel(const SegDev *__restrict__ segs, const DevTable *__restrict__ tables, const StepArgs a) {
     constexpr bool WWK = KIND == K_WW8 || KIND == K_WW12 || tt_uses_queue(KIND == K_TT4 ? 4 : KIND == K_TT8 ? 8 : 12, LOWOCC);   // uses the action queue
     DevRow *rows = reinterpret_cast<DevRow *>(ge_lds);
     uint8_t *nth8 = ge_lds + LDS_ROWS + LDS_ORD8;
@@ -442,7 +456,7 @@ __global__ void __launch_bounds__(SINGLE ? 1024 : 256, SINGLE ? 8 : (KIND == K_W
 
 // mixed batch: several segments (games / player counts) in one launch
 template <bool LOWOCC, bool GENERIC = false>
-__global__ void __launch_bounds__(256, (!LOWOCC && !GENERIC) ? GE_WW12_WAVES : 1) ge_step_kernel_mixed(const SegDev *__restrict__ segs, const DevTable *__restrict__ tables, const StepArgs a) {
+__global__ void __launch_bounds__(256, !LOWOCC ? (GENERIC ? GE_GENERIC_WAVES : GE_WW12_WAVES) : 1) ge_step_kernel_mixed(const SegDev *__restrict__ segs, const DevTable *__restrict__ tables, const StepArgs a) {
     DevRow *rows = reinterpret_cast<DevRow *>(ge_lds);
     uint8_t *nth8 = ge_lds + LDS_ROWS + LDS_ORD8;
     auto *wl = reinterpret_cast<typename WaveLdsOf<LOWOCC>::type *>(ge_lds + LDS_ROWS + LDS_ORD8 + (LOWOCC ? 0u : LDS_NTH8 + LDS_S0));

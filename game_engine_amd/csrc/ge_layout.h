@@ -321,21 +321,36 @@ template <> struct TTLayout<12> {
 //       0xFF bytes (selector 0x0D) in the others, so the AND of the three permutes is the term.
 //       N<=8: 4 terms x 1 byte, pair (W2:W2) in r5;  N<=12: terms 0..1 x 2 bytes.
 //   r7: XOR mask of the negated terms (same byte positions)
-//   r0 bit 21: the target condition is generic (or / in [..] / numeric): the row's DevCond describes it, r1/r4..r7 do not
+//   r0 bit 21: the target condition is generic (or / in [..] / numeric): the row's DevCond describes it, r1/r4..r7 do not;
+//   r0 bits 22..26: its slot in the table's literal image (DevTable::cond_img)
 struct DevRow { uint32_t r0, r1, r2, r3, r4, r5, r6, r7; };
 constexpr uint32_t ROW_GENERIC = 1u << 21;
 
 // A target condition in clause form (include/ge_step.h ge_literal), for the rows whose condition is not a plain
 // conjunction of base predicates.  lit[c][l]: bits 0..15 = base-predicate bit set, or lo | hi << 8 of a numeric
 // range; 16..18 = numeric field (GE_NUM_*); 28..29 = kind (1 base set, 2 numeric); 30 = negated.
-// meta: n_clauses [2:0], length of clause c [4 + 4c +: 3].
-// prep[][].a0 / .a1 (werewolf N <= 8 only): the same literal prepared for the packed predicate words - a base set as two
-// v_perm_b32 selectors that gather its fields' bytes out of (W1:W0) and (W2:W2) (0x0C = zero byte where it has none; OR-fold
-// of the gathered bytes = "has any of them"); a numeric range over the selected-target nibbles as lo in every byte and
-// hi | 0x80 in every byte (two byte-wise subtractions answer lo <= v <= hi for four players at once).
-// prep[k][l] = {lit, aux0, aux1, 0}: one 16-byte load per literal.
-struct DevLit { uint32_t w, a0, a1, pad; };
-struct DevCond { uint32_t lit[4][4]; uint32_t meta, pad[3]; DevLit prep[4][4]; };
+// meta: n_clauses [2:0], length of clause c [4 + 4c +: 3].  Read by ge_inject_kernel (one player of one room at a time).
+struct DevCond { uint32_t lit[4][4]; uint32_t meta, pad[3]; };
+
+// The same conditions as the step kernels evaluate them (GENERIC builds): an IMAGE that a block copies into its LDS.
+// Every generic row of a table is padded to the table's common shape - NCL clauses of LEN literals, the largest any of its
+// rows has - with neutral literals (TRUE inside a clause the row uses, FALSE in a clause it does not have), so every lane of
+// a wavefront walks the same NCL x LEN slots whatever row it is in, and no lane tests a clause count or length.  A row
+// finds its literals through its slot number (DevRow r0 bits 22..26): image + slot * NCL * LEN * stride.
+// One literal = 4 words (Werewolf N <= 8, Two-Truths) or 8 (Werewolf N <= 12):
+//   w    bit 0: numeric range (else base set); bits 1..3: the numeric field (GE_NUM_*), bits 4..7: the same one-hot (bit 3 + field,
+//        Two-Truths); bits 16..31: 0xFFFF if negated
+//   base set    m[k] = AND-mask over packed predicate word k (0xFF / 0xFFFF in the fields the set names): the literal is
+//               the OR-fold of (W[k] & m[k]) - any number of fields, three AND / OR per word (Two-Truths packs its five
+//               masks as speaker | submitted << 16, revealed | can_vote << 16, has_voted)
+//   numeric     m[0], m[1] = the bounds prepared for the field's SWAR compare (ge_device.h range_*): lo in every byte and
+//               hi | 0x80 in every byte (nibble arrays), the same in half-words (scores), or the allowed-value masks of a
+//               2-bit field
+// An empty range and the neutral literals are base sets with all-zero masks (FALSE), negated for TRUE.
+struct CondLit { uint32_t w, m[3]; };
+struct CondLit12 { uint32_t w, m[6], pad; };
+constexpr uint32_t COND_IMG_BYTES = 16384;      // 32 rows x 16 literals x 32 B at the very most
+constexpr uint32_t ROW_COND_SLOT_SHIFT = 22;    // DevRow r0 bits 22..26: the generic row's slot in the image
 
 // the generic rows' common shape, read once per launch into scalar registers (wave-uniform loop bounds and skips)
 struct CondShape { uint32_t shape, slots, f0, f1; };
@@ -353,7 +368,10 @@ struct DevTable {
     uint32_t cond_shape;     // generic rows: largest clause count [2:0] and clause length [6:4], any base-set literal [8], any numeric literal [9]
     uint32_t cond_slots;     // generic rows: bit 4k + l = some row has a base-set literal in slot l of clause k; bit 16 + 4k + l = a numeric one
     uint32_t cond_fields[2]; // generic rows: nibble 4k + l (slots 0..7 in [0], 8..15 in [1]) = which numeric fields slot (k, l) compares, bit = GE_NUM_* - 1
-    DevCond conds[32];       // clause form of the generic rows (read from global memory by the generic kernel builds only)
+    uint32_t cond_n16;       // generic rows: 16-byte elements of cond_img in use (what a block copies into its LDS)
+    uint32_t pad_[3];
+    DevCond conds[32];       // clause form of the generic rows, per row (ge_inject_kernel)
+    alignas(16) unsigned char cond_img[COND_IMG_BYTES];   // the same for the step kernels: padded literals, slot-major (CondLit / CondLit12)
 };
 
 // plane geometry of a segment

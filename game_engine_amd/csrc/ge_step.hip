@@ -84,7 +84,7 @@ DevRow to_dev_row(const ge_game_table &tb, const ge_phase_row &r, uint32_t kind)
     return d;
 }
 
-DevCond to_dev_cond(const ge_phase_row &r, bool ww8 = false) {
+DevCond to_dev_cond(const ge_phase_row &r) {                       // the clause form as ge_inject_kernel reads it
     DevCond c;
     memset(&c, 0, sizeof c);
     const uint32_t ncl = r.n_clauses <= GE_MAX_CLAUSES ? r.n_clauses : GE_MAX_CLAUSES;
@@ -96,25 +96,90 @@ DevCond to_dev_cond(const ge_phase_row &r, bool ww8 = false) {
             const ge_literal &x = r.clause[k][l];
             const uint32_t payload = x.kind == GE_LIT_NUM ? ((uint32_t)x.lo | ((uint32_t)x.hi << 8)) : x.bases;
             c.lit[k][l] = payload | ((uint32_t)(x.num_field & 7u) << 16) | ((uint32_t)(x.kind & 3u) << 28) | (x.neg ? 1u << 30 : 0u);
-            c.prep[k][l].w = c.lit[k][l];
-            if (!ww8) continue;
-            if (x.kind == GE_LIT_NUM) {
-                const uint32_t lo = x.lo > 15 ? 15u : x.lo, hi = x.hi > 15 ? 15u : x.hi;
-                c.prep[k][l].a0 = lo * 0x01010101u;
-                c.prep[k][l].a1 = (hi * 0x01010101u) | 0x80808080u;
-                if (x.lo > x.hi) { c.prep[k][l].a0 = 0x7F7F7F7Fu; c.prep[k][l].a1 = 0x80808080u; }      // empty range: lo above every value
-            } else {
-                uint32_t sa = 0x0C0C0C0Cu, sb = 0x0C0C0C0Cu, na = 0, nb = 0;          // 0x0C: constant zero byte
-                for (uint32_t f = 0; f < 8; f++)
-                    if ((x.bases >> f) & 1u) { if (na < 4) sa = (sa & ~(0xFFu << (8 * na))) | (f << (8 * na)); na++; }
-                for (uint32_t f = 8; f < 12; f++)
-                    if ((x.bases >> f) & 1u) { sb = (sb & ~(0xFFu << (8 * nb))) | ((f - 8u) << (8 * nb)); nb++; }
-                c.prep[k][l].a0 = sa; c.prep[k][l].a1 = sb;
-                if (na > 4) c.meta |= 1u << 31;                                       // (no grammar produces this) - marks the row for the mask form
-            }
         }
     }
     return c;
+}
+
+// The generic rows of a table as the step kernels evaluate them: the literal image a block copies into its LDS
+// (ge_layout.h CondLit / CondLit12, ge_device.h eval_cond_image).  Every generic row gets a slot and is padded to the
+// table's common shape with neutral literals; dt.rows[] must already hold the rows (the slot number goes into r0).
+void build_cond_image(const ge_game_table &tb, uint32_t kind, DevTable &dt) {
+    uint32_t ncl = 0, len = 0, kinds = 0, slots = 0, fields[2] = {0, 0}, n_generic = 0;
+    for (int r = 0; r < tb.n_phases; r++) {
+        const ge_phase_row &pr = tb.rows[r];
+        if (!pr.generic) continue;
+        n_generic++;
+        const uint32_t rc = pr.n_clauses <= GE_MAX_CLAUSES ? pr.n_clauses : GE_MAX_CLAUSES;
+        ncl = std::max<uint32_t>(ncl, std::max<uint32_t>(rc, 1u));                      // no clause at all = everybody: one clause of TRUE literals
+        for (uint32_t k = 0; k < rc; k++) {
+            const uint32_t rl = pr.clause_len[k] <= GE_MAX_TERMS ? pr.clause_len[k] : GE_MAX_TERMS;
+            len = std::max<uint32_t>(len, rl);
+            for (uint32_t l = 0; l < rl; l++) {
+                const ge_literal &x = pr.clause[k][l];
+                const uint32_t slot = 4u * k + l;
+                const bool num = x.kind == GE_LIT_NUM && x.lo <= x.hi;                  // an empty range is the constant FALSE: no compare
+                if (x.kind == GE_LIT_NUM && !num) continue;
+                kinds |= num ? 0x200u : 0x100u;
+                slots |= 1u << ((num ? 16u : 0u) + slot);
+                if (num && x.num_field >= 1 && x.num_field <= 4) fields[slot >> 3] |= 1u << (4u * (slot & 7u) + (x.num_field - 1u));
+            }
+        }
+    }
+    dt.cond_shape = 0; dt.cond_slots = 0; dt.cond_fields[0] = dt.cond_fields[1] = 0; dt.cond_n16 = 0;
+    if (!n_generic) return;
+    len = std::max<uint32_t>(len, 1u);
+    dt.cond_shape = ncl | (len << 4) | kinds;
+    dt.cond_slots = slots; dt.cond_fields[0] = fields[0]; dt.cond_fields[1] = fields[1];
+    const bool ww8 = kind == K_WW8, ww12 = kind == K_WW12;
+    const uint32_t stride = ww12 ? sizeof(CondLit12) : sizeof(CondLit);                 // bytes per literal
+    uint32_t *img = reinterpret_cast<uint32_t *>(dt.cond_img);
+    const uint32_t FALSE_W = 0u, TRUE_W = 0xFFFF0000u;                                   // base sets with no field; TRUE = negated
+    uint32_t slot_no = 0;
+    for (int r = 0; r < tb.n_phases; r++) {
+        const ge_phase_row &pr = tb.rows[r];
+        if (!pr.generic) continue;
+        dt.rows[r].r0 |= slot_no << ROW_COND_SLOT_SHIFT;
+        const uint32_t rc = pr.n_clauses <= GE_MAX_CLAUSES ? pr.n_clauses : GE_MAX_CLAUSES;
+        for (uint32_t k = 0; k < ncl; k++)
+            for (uint32_t l = 0; l < len; l++) {
+                uint32_t *d = img + (size_t)((slot_no * ncl + k) * len + l) * (stride / 4u);
+                memset(d, 0, stride);
+                const bool clause_used = rc == 0 ? k == 0 : k < rc;
+                const uint32_t rl = k < rc ? std::min<uint32_t>(pr.clause_len[k], GE_MAX_TERMS) : 0u;
+                if (!clause_used) { d[0] = FALSE_W; continue; }
+                if (l >= rl) { d[0] = TRUE_W; continue; }
+                const ge_literal &x = pr.clause[k][l];
+                const uint32_t neg = x.neg ? 0xFFFF0000u : 0u;
+                if (x.kind == GE_LIT_NUM) {
+                    if (x.lo > x.hi) { d[0] = FALSE_W ^ neg; continue; }                 // never true (negated: always)
+                    const uint32_t f = x.num_field & 7u;
+                    d[0] = 1u | (f << 1) | (f ? 1u << (3u + f) : 0u) | neg;
+                    if (f == GE_NUM_LIE_INDEX || f == GE_NUM_VOTE_CHOICE) {              // 2-bit fields: the allowed values as masks
+                        auto allowed = [&](uint32_t v) { return v >= x.lo && v <= x.hi ? 0x00555555u : 0u; };
+                        d[1] = allowed(0) | (allowed(1) << 1);
+                        d[2] = allowed(2) | (allowed(3) << 1);
+                    } else if (f == GE_NUM_TOTAL_SCORE) {                                // bytes compared in half-word lanes
+                        d[1] = (uint32_t)x.lo * 0x00010001u;
+                        d[2] = ((uint32_t)x.hi * 0x00010001u) | 0x80008000u;
+                    } else {                                                             // nibble arrays (selected_target_id, rounds_as_speaker) in byte lanes
+                        if (x.lo > 15) { d[0] = FALSE_W ^ neg; continue; }
+                        d[1] = (uint32_t)x.lo * 0x01010101u;
+                        d[2] = (std::min<uint32_t>(x.hi, 15u) * 0x01010101u) | 0x80808080u;
+                    }
+                    continue;
+                }
+                d[0] = neg;                                                              // a base set: AND-masks over the packed predicate words
+                for (uint32_t b = 0; b < 16u; b++) {
+                    if (!((x.bases >> b) & 1u)) continue;
+                    if (ww8) { if (b < 12u) d[1 + b / 4u] |= 0xFFu << (8u * (b % 4u)); }
+                    else if (ww12) { if (b < 12u) d[1 + b / 2u] |= 0xFFFFu << (16u * (b % 2u)); }
+                    else if (b < 5u) d[1 + b / 2u] |= 0xFFFFu << (16u * (b % 2u));       // speaker | submitted << 16, revealed | can_vote << 16, has_voted
+                }
+            }
+        slot_no++;
+    }
+    dt.cond_n16 = slot_no * ncl * len * stride / 16u;
 }
 
 // the initial record in the kernels' register form (SegDev::init_regs)
@@ -263,6 +328,7 @@ struct ge_batch {
     unsigned long long *sum_dev = nullptr;
     hipStream_t last_stream = nullptr;
     bool generic = false;             // some phase has a generic target condition: the GENERIC kernel builds are launched
+    uint32_t cond_bytes = 0;          // ... and their blocks keep this much of literal image in LDS (the largest table's)
     bool pending = false;             // work was queued on last_stream since the last synchronisation
     hipEvent_t order_ev = nullptr;    // orders a step on a new stream behind the previous stream's work
     unsigned long long *stamps_dev = nullptr;   // GE_STAMPS diagnostic build only
@@ -464,26 +530,11 @@ static int create_impl(const ge_batch_desc *desc, ge_batch **out, const uint64_t
                 memset(&dt, 0, sizeof dt);
                 for (int r = 0; r < s.table.n_phases; r++) {
                     dt.rows[r] = to_dev_row(s.table, s.table.rows[r], s.dev.kind);
-                    dt.conds[r] = to_dev_cond(s.table.rows[r], s.dev.kind == K_WW8);
-                    if (s.table.rows[r].generic) {
-                        b->generic = true;
-                        const ge_phase_row &pr = s.table.rows[r];
-                        uint32_t ncl = dt.cond_shape & 7u, len = (dt.cond_shape >> 4) & 7u, kinds = dt.cond_shape & 0x300u;
-                        ncl = pr.n_clauses > ncl ? pr.n_clauses : ncl;
-                        for (uint32_t k = 0; k < pr.n_clauses && k < GE_MAX_CLAUSES; k++) {
-                            len = pr.clause_len[k] > len ? pr.clause_len[k] : len;
-                            for (uint32_t l = 0; l < pr.clause_len[k] && l < GE_MAX_TERMS; l++) {
-                                kinds |= pr.clause[k][l].kind == GE_LIT_NUM ? 0x200u : 0x100u;
-                                dt.cond_slots |= 1u << ((pr.clause[k][l].kind == GE_LIT_NUM ? 16u : 0u) + 4u * k + l);
-                                if (pr.clause[k][l].kind == GE_LIT_NUM && pr.clause[k][l].num_field >= 1 && pr.clause[k][l].num_field <= 4) {
-                                    const uint32_t slot = 4u * k + l;
-                                    dt.cond_fields[slot >> 3] |= 1u << (4u * (slot & 7u) + (pr.clause[k][l].num_field - 1u));
-                                }
-                            }
-                        }
-                        dt.cond_shape = (ncl > 4u ? 4u : ncl) | ((len > 4u ? 4u : len) << 4) | kinds;
-                    }
+                    dt.conds[r] = to_dev_cond(s.table.rows[r]);
+                    if (s.table.rows[r].generic) b->generic = true;
                 }
+                build_cond_image(s.table, s.dev.kind, dt);
+                b->cond_bytes = std::max<uint32_t>(b->cond_bytes, dt.cond_n16 * 16u);
                 dt.n_phases = s.table.n_phases; dt.rounds = s.table.rounds; dt.n_players = (int32_t)s.dev.n_players;
                 fill_nth8_host(dt.nth8);
                 fill_ord8_host(dt.ord8);
@@ -551,7 +602,11 @@ static hipError_t launch_step(const ge_batch *b, const StepArgs &a, hipStream_t 
 #define GE_LAUNCH(KERNEL, QUEUE, LOW) hipLaunchKernelGGL(KERNEL, grid, block, step_lds_bytes(QUEUE, LOW, bt), st, b->segs_dev, b->tables, a)
     const bool low = a.lowocc != 0u && !(b->generic && b->segs.size() > 1);   // mixed batches with generic tables: the large-batch build serves every size
     if (b->generic) {
-        // generic target conditions: single-game batches get both forms too; mixed batches the large-batch one
+        // generic target conditions: single-game batches get both forms too; mixed batches the large-batch one.  A block keeps
+        // the generic rows' literal image behind everything else in its LDS (StepArgs::cond_off)
+        StepArgs ag = a;
+#undef GE_LAUNCH
+#define GE_LAUNCH(KERNEL, QUEUE, LOW) do { ag.cond_off = step_lds_bytes(QUEUE, LOW, bt); hipLaunchKernelGGL(KERNEL, grid, block, ag.cond_off + b->cond_bytes, st, b->segs_dev, b->tables, ag); } while (0)
         if (b->segs.size() > 1) GE_LAUNCH((ge_step_kernel_mixed<false, true>), true, false);
         else switch (b->segs[0].dev.kind) {
         case K_WW8: if (low) GE_LAUNCH((ge_step_kernel<K_WW8, true, true>), true, true); else GE_LAUNCH((ge_step_kernel<K_WW8, false, true>), true, false); break;
@@ -560,6 +615,8 @@ static hipError_t launch_step(const ge_batch *b, const StepArgs &a, hipStream_t 
         case K_TT8: if (low) GE_LAUNCH((ge_step_kernel<K_TT8, true, true>), tt_uses_queue(8, true), true); else GE_LAUNCH((ge_step_kernel<K_TT8, false, true>), true, false); break;
         default: if (low) GE_LAUNCH((ge_step_kernel<K_TT12, true, true>), tt_uses_queue(12, true), true); else GE_LAUNCH((ge_step_kernel<K_TT12, false, true>), true, false); break;
         }
+#undef GE_LAUNCH
+#define GE_LAUNCH(KERNEL, QUEUE, LOW) hipLaunchKernelGGL(KERNEL, grid, block, step_lds_bytes(QUEUE, LOW, bt), st, b->segs_dev, b->tables, a)
     } else if (b->segs.size() > 1) {
         if (low) GE_LAUNCH(ge_step_kernel_mixed<true>, true, true); else GE_LAUNCH(ge_step_kernel_mixed<false>, true, false);
     } else if (a.n_turns == 1u) {

@@ -246,3 +246,77 @@ def test_host_driven_players_on_a_generic_dsl():
                 orc.run(rooms, seed, first, t, 1, threads=0, human_mask=mask)
                 assert_views_equal(b.read_rooms(), oracle_rooms_as_views(orc, rooms), f"{name} turn {t}")
         assert ok > 200 and bad > 200
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,rounds", [(4, 15), (7, 9), (12, 11)])
+def test_two_truths_numeric_ranges_over_whole_value_ranges(dsl_tt, n, rounds):
+    """The numeric literals' SWAR compares (ge_device.h range_*) at the edges of every field: scores up to 255 against bounds
+    on both sides of 128 (half-word lanes), rounds up to 14 (byte lanes), subsets of the 2-bit values - from random,
+    mostly unreachable states (ge_batch_write_rooms), in both kernel builds (lone-wavefront / large-batch), against the oracle."""
+    from game_engine_amd import RoomBatch
+    from oracle.oracle import Oracle
+    from parity_util import assert_views_equal, oracle_rooms_as_views, views_as_oracle_rooms
+    from test_gpu_fuzz import _random_tt_views
+    conds = [("player.is_speaker == true and player.total_score >= 128 or player.is_speaker == true and player.rounds_as_speaker <= 13 and player.total_score < 127",
+              "player.is_speaker == true and player.lie_index not in [2, 3] or player.is_speaker == true and player.total_score == 230",
+              "player.is_speaker == false and player.total_score <= 200 and player.rounds_as_speaker >= 3 or player.is_speaker == false and player.vote_choice in [0, 2]"),
+             ("player.is_speaker == true and player.rounds_as_speaker > 13 or player.is_speaker == true and player.total_score != 0",
+              "player.is_speaker == true and player.total_score > 229 or player.is_speaker == true and player.lie_index >= 2",
+              "player.is_speaker == false and player.vote_choice != 3 and player.total_score >= 129 and player.total_score <= 131 or player.is_speaker == false and player.rounds_as_speaker == 14")]
+    for ci, (c2, c3, c5) in enumerate(conds):
+        d = copy.deepcopy(dsl_tt)
+        for pid, c in (("2", c2), ("3", c3), ("5", c5)):
+            d["phases"][pid]["completion_criteria"]["target_players"]["condition"] = c
+        orc = Oracle(d, n, rounds=rounds)
+        tb = GameTable(d, rounds)
+        assert sum(r["generic"] for r in tb.rows()) == 3
+        for R in (5000, 90000):
+            rng = np.random.default_rng(100 * n + ci)
+            views = _random_tt_views(orc, n, R, rng, rounds)
+            p = views["players"]
+            # (kept below the counters' ends: a score byte or a rounds nibble that overflows is outside the packed model)
+            p[:, :n, 7] = rng.choice([0, 1, 126, 127, 128, 129, 130, 131, 199, 200, 201, 229, 230], size=(R, n))
+            p[:, :n, 8] = rng.integers(0, 15, (R, n))
+            rooms = views_as_oracle_rooms(orc, views)
+            seed, first = 31 + ci, 1 << 33
+            with RoomBatch([(tb, n, R)], seed=seed, first_room=first, max_fuse=3) as b:
+                b.step(2)
+                b.write_rooms(0, views)
+                for chunk in (1, 3, 2):
+                    b.step(chunk)
+                    orc.run(rooms, seed, first, b.turn - chunk, chunk, threads=0)
+                    assert_views_equal(b.read_rooms(), oracle_rooms_as_views(orc, rooms), f"tt x{n} conds {ci} R={R} after turn {b.turn}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [5, 8, 12])
+def test_werewolf_numeric_ranges_over_whole_value_ranges(dsl_ww, n):
+    """selected_target_id (a nibble per player, byte lanes; 12 players: three words) against bounds up to 15 and beyond."""
+    from game_engine_amd import RoomBatch
+    from oracle.oracle import Oracle
+    from parity_util import assert_views_equal, oracle_rooms_as_views, views_as_oracle_rooms
+    from test_gpu_fuzz import _random_ww_views
+    conds = {"2": "player.role == 'Werewolf' and player.is_alive == true and player.selected_target_id >= 9 or player.role == 'Werewolf' and player.selected_target_id in [0, 1, 2]",
+             "3": "player.role == 'Doctor' and player.is_alive == true and player.selected_target_id <= 15",
+             "4": "player.role == 'Detective' and player.selected_target_id > 11 or player.role == 'Detective' and player.team not in ['werewolves'] and player.selected_target_id != 7",
+             "7": "player.can_vote == true and player.is_alive == true and player.selected_target_id < 12 and player.role in ['Villager', 'Doctor', 'Detective', 'Werewolf']"}
+    d = copy.deepcopy(dsl_ww)
+    for pid, c in conds.items():
+        d["phases"][pid]["completion_criteria"]["target_players"]["condition"] = c
+    orc = Oracle(d, n)
+    tb = GameTable(d)
+    assert sum(r["generic"] for r in tb.rows()) == 4
+    for R in (6000, 100000):
+        rng = np.random.default_rng(n)
+        views = _random_ww_views(orc, n, R, rng, consistent=False)
+        views["players"][:, :n, 8] = rng.integers(0, min(n, 15) + 1, (R, n))
+        rooms = views_as_oracle_rooms(orc, views)
+        seed, first = 77, 12345
+        with RoomBatch([(tb, n, R)], seed=seed, first_room=first, max_fuse=4) as b:
+            b.step(3)
+            b.write_rooms(0, views)
+            for chunk in (1, 4, 2):
+                b.step(chunk)
+                orc.run(rooms, seed, first, b.turn - chunk, chunk, threads=0)
+                assert_views_equal(b.read_rooms(), oracle_rooms_as_views(orc, rooms), f"ww x{n} R={R} after turn {b.turn}")
