@@ -567,40 +567,43 @@ template <int NB> __device__ __forceinline__ uint32_t range_score(const uint32_t
 // what a launch keeps in scalar registers about the table's generic rows
 struct CondCtx {
     const unsigned char *img;  // the block's LDS copy of DevTable::cond_img
-    CondShape cs;              // shape [2:0] clauses, [6:4] literals per clause; slots: bit 4k + l = slot (k, l) holds a base set
-                               // in some row, bit 16 + 4k + l = a numeric range; f0 / f1: Two-Truths, nibble per slot = fields compared
+    CondShape cs;              // ge_layout.h
 };
 
-// OR over clauses of AND over literals; `lit(d, e, slot)` -> the literal's player mask before negation (d = the literal's
-// first four words, e = its second four: Werewolf x 12 only).  Rolled, wave-uniform loops: two scalar counters.
-// (Issuing the next literal's LDS read before evaluating the current one was measured and is slower at every shape - four
-// to eight more live registers and the copies at the loop's back edge: profiles/r04_generic_probe.txt.)
+// OR over clauses of AND over literals; `lit(d, e, g, f)` -> the literal's player mask before negation (d = the literal's
+// first four words, e = its second four: Werewolf x 12 only; g, f = the slot's wave-uniform flags, CondShape).  One rolled
+// loop over the table's NCL x LEN slots with one scalar counter; the slot flags are shifted out of two scalar registers.
+// (Measured and rejected, profiles/r04_generic_probe.txt: issuing the next literal's LDS read before evaluating the current
+// one, and an unrolled form for up to four slots with the reads grouped - more live registers, the scalar spills back.)
 template <int STRIDE, typename LIT>
 __device__ __forceinline__ uint32_t eval_cond_image(const CondCtx &cc, uint32_t row_r0, uint32_t all, LIT lit) {
-    const uint32_t ncl = cc.cs.shape & 7u, len = (cc.cs.shape >> 4) & 7u;                     // wave-uniform
-    const unsigned char *p = cc.img + ((row_r0 >> ROW_COND_SLOT_SHIFT) & 31u) * (ncl * len * (uint32_t)STRIDE);
-    uint32_t T = 0;
+    const uint32_t n = (cc.cs.shape & 7u) * ((cc.cs.shape >> 4) & 7u);                        // wave-uniform
+    const unsigned char *p = cc.img + ((row_r0 >> ROW_COND_SLOT_SHIFT) & 31u) * (n * (uint32_t)STRIDE);
+    uint64_t G = ((uint64_t)cc.cs.g_hi << 32) | cc.cs.g_lo, F = ((uint64_t)cc.cs.f_hi << 32) | cc.cs.f_lo;
+    uint32_t T = 0, m = all;
 #pragma nounroll
-    for (uint32_t k = 0; k < ncl; k++) {
-        uint32_t m = all;
-#pragma nounroll
-        for (uint32_t l = 0; l < len; l++) {
-            const uint4 d = *reinterpret_cast<const uint4 *>(p);
-            uint4 e = make_uint4(0u, 0u, 0u, 0u);
-            if (STRIDE > 16) e = *reinterpret_cast<const uint4 *>(p + 16);
-            const uint32_t x = lit(d, e, 4u * k + l);
-            m &= x ^ (d.x >> 16);                                                             // negated: 0xFFFF in the top half of w
-            p += STRIDE;
-        }
-        T |= m;
+    for (uint32_t i = n; i != 0u; i--) {
+        const uint32_t g = (uint32_t)G & 15u, f = (uint32_t)F & 15u;
+        G >>= 4; F >>= 4;
+        const uint4 d = *reinterpret_cast<const uint4 *>(p);
+        uint4 e = make_uint4(0u, 0u, 0u, 0u);
+        if (STRIDE > 16) e = *reinterpret_cast<const uint4 *>(p + 16);
+        const uint32_t x = lit(d, e, g, f);
+        m &= x ^ (d.x >> 16);                                                                 // negated: 0xFFFF in the top half of w
+        p += STRIDE;
+        if (g & 4u) { T |= m; m = all; }                                                      // the clause ends here
     }
     return T & all;
 }
 
+// (an input made opaque INSIDE the block that uses it: the compare's loop-invariant half - a third of its instructions - is
+// otherwise hoisted in front of the loop and runs every turn, whether or not any slot of the table compares that field)
+__device__ __forceinline__ uint32_t pin(uint32_t v) { asm volatile("" : "+v"(v)); return v; }
+
 template <int NB> __device__ __forceinline__ uint32_t ww_cond_generic(const WWR<NB> &s, const CondCtx &cc, uint32_t row_r0, uint32_t all) {
     constexpr int STRIDE = NB <= 8 ? (int)sizeof(CondLit) : (int)sizeof(CondLit12);
-    return eval_cond_image<STRIDE>(cc, row_r0, all, [&](const uint4 &d, const uint4 &e, uint32_t slot) -> uint32_t {   // d = {w, m0, m1, m2}, e = {m3, m4, m5, -}
-        const bool any_base = (cc.cs.slots >> slot) & 1u, any_num = (cc.cs.slots >> (16u + slot)) & 1u;       // wave-uniform
+    return eval_cond_image<STRIDE>(cc, row_r0, all, [&](const uint4 &d, const uint4 &e, uint32_t sg, uint32_t) -> uint32_t {   // d = {w, m0, m1, m2}, e = {m3, m4, m5, -}
+        const bool any_base = sg & 1u, any_num = sg & 2u, any_conj = sg & 8u;       // wave-uniform
         uint32_t x = 0;
         if (any_base) {
             uint32_t g;
@@ -614,8 +617,20 @@ template <int NB> __device__ __forceinline__ uint32_t ww_cond_generic(const WWR<
             }
             x = g;
         }
+        if (any_conj) {                                          // single predicates ANDed: permute and fold, like a row's own terms (ww_targets)
+            uint32_t X;
+            if (NB <= 8) {
+                X = (__builtin_amdgcn_perm(s.W[1], s.W[0], d.y) & __builtin_amdgcn_perm(s.W[2], s.W[2], d.z)) ^ d.w;
+                X &= X >> 16; X &= X >> 8;
+            } else {
+                X = (__builtin_amdgcn_perm(s.W[1], s.W[0], d.y) & __builtin_amdgcn_perm(s.W[WWR<NB>::NW > 3 ? 3 : 0], s.W[2], d.z) &
+                     __builtin_amdgcn_perm(s.W[WWR<NB>::NW - 1], s.W[WWR<NB>::NW - 2], d.w)) ^ e.x;
+                X &= X >> 16;
+            }
+            x = any_base ? bfi(bit_mask(d.x, 8u), X, x) : X;     // (a conj-only slot's neutral literals are conj literals too)
+        }
         if (any_num) {                                           // GE_NUM_SELECTED_TARGET is the pack's only numeric field
-            const uint32_t r = range_nibbles<NB>((uint64_t)s.sel, d.y, d.z);
+            const uint32_t r = range_nibbles<NB>(NB <= 8 ? (uint64_t)pin((uint32_t)s.sel) : ((uint64_t)pin((uint32_t)((uint64_t)s.sel >> 32)) << 32) | pin((uint32_t)s.sel), d.y, d.z);
             x = bfi(bit_mask(d.x, 0u), r, x);                     // by the literal's own kind (a neutral literal of another row sits in this slot as a base set)
         }
         return x;
@@ -624,22 +639,32 @@ template <int NB> __device__ __forceinline__ uint32_t ww_cond_generic(const WWR<
 
 template <int NB> __device__ __forceinline__ uint32_t tt_cond_generic(const TT<NB> &s, const CondCtx &cc, uint32_t row_r0, uint32_t all) {
     const uint32_t W0 = s.speaker | (s.submitted << 16), W1 = s.revealed | (s.can_vote << 16), W2 = s.has_voted;
-    return eval_cond_image<(int)sizeof(CondLit)>(cc, row_r0, all, [&](const uint4 &d, const uint4 &, uint32_t slot) -> uint32_t {
-        // wave-uniform: what slot (k, l) holds in some row of the table - a base set, and / or a range over which fields
-        const bool any_base = (cc.cs.slots >> slot) & 1u;
-        const uint32_t flds = (slot < 8u ? cc.cs.f0 >> (4u * slot) : cc.cs.f1 >> (4u * (slot - 8u))) & 15u;
+    return eval_cond_image<(int)sizeof(CondLit)>(cc, row_r0, all, [&](const uint4 &d, const uint4 &, uint32_t g, uint32_t flds) -> uint32_t {
+        // wave-uniform: what the slot holds in some row of the table - a base set, and / or a range over which fields
+        const bool any_base = g & 1u, any_conj = g & 8u;
         uint32_t x = 0;
         if (any_base) {
-            uint32_t g = (W0 & d.y) | (W1 & d.z) | (W2 & d.w);
-            g |= g >> 16;
-            x = g;
+            uint32_t v = (W0 & d.y) | (W1 & d.z) | (W2 & d.w);
+            v |= v >> 16;
+            x = v;
+        }
+        if (any_conj) {                                          // two single predicates ANDed: permute and fold (tt_turn's own terms)
+            uint32_t X = (__builtin_amdgcn_perm(W1, W0, d.y) & __builtin_amdgcn_perm(W2, W2, d.z)) ^ d.w;
+            X &= X >> 16;
+            x = any_base ? bfi(bit_mask(d.x, 8u), X, x) : X;
         }
         if (flds) {
             // the literal's field one-hot in w bits 4..7: bit-selects, no compares and no exec-mask regions
-            if (flds & 1u) x = bfi(bit_mask(d.x, 4u), range_2bit<NB>(s.lie, d.y, d.z), x);       // GE_NUM_LIE_INDEX
-            if (flds & 2u) x = bfi(bit_mask(d.x, 5u), range_2bit<NB>(s.vote, d.y, d.z), x);      // GE_NUM_VOTE_CHOICE
-            if (flds & 4u) x = bfi(bit_mask(d.x, 6u), range_score<NB>(s.score, d.y, d.z), x);    // GE_NUM_TOTAL_SCORE
-            if (flds & 8u) x = bfi(bit_mask(d.x, 7u), range_nibbles<NB>(s.rounds, d.y, d.z), x); // GE_NUM_ROUNDS_AS_SPEAKER
+            if (flds & 1u) x = bfi(bit_mask(d.x, 4u), range_2bit<NB>(pin(s.lie), d.y, d.z), x);  // GE_NUM_LIE_INDEX
+            if (flds & 2u) x = bfi(bit_mask(d.x, 5u), range_2bit<NB>(pin(s.vote), d.y, d.z), x); // GE_NUM_VOTE_CHOICE
+            if (flds & 4u) {                                                                     // GE_NUM_TOTAL_SCORE
+                uint32_t sc[(NB + 3) / 4];
+#pragma unroll
+                for (int w = 0; w < (NB + 3) / 4; w++) sc[w] = pin(s.score[w]);
+                x = bfi(bit_mask(d.x, 6u), range_score<NB>(sc, d.y, d.z), x);
+            }
+            if (flds & 8u)                                                                       // GE_NUM_ROUNDS_AS_SPEAKER
+                x = bfi(bit_mask(d.x, 7u), range_nibbles<NB>(NB <= 8 ? (uint64_t)pin((uint32_t)s.rounds) : ((uint64_t)pin((uint32_t)(s.rounds >> 32)) << 32) | pin((uint32_t)s.rounds), d.y, d.z), x);
         }
         return x;
     });
@@ -676,7 +701,8 @@ __device__ __forceinline__ uint32_t ww_targets(const WWR<NB> &s, const DevRow &r
     using R = WWR<NB>;
     const uint32_t comp = row.r0 & 3u, nterms = (row.r0 >> 8) & 7u;
     uint32_t T = 0;
-    if (LOWOCC || comp == COMP_ACTION) {                       // LOWOCC: always evaluated, masked below (no branch)
+    const bool generic_row = GENERIC && (row.r0 & ROW_GENERIC);   // its condition is the literal image below, not the row's terms
+    if (LOWOCC ? !GENERIC || !generic_row : (comp == COMP_ACTION && !generic_row)) {   // LOWOCC: always evaluated, masked below (no branch)
         uint32_t X;
         if (NB <= 8) {
             X = __builtin_amdgcn_perm(s.W[1], s.W[0], row.r4) & __builtin_amdgcn_perm(s.W[2], s.W[2], row.r5);
@@ -702,7 +728,7 @@ __device__ __forceinline__ uint32_t ww_targets(const WWR<NB> &s, const DevRow &r
         }
         T = X & alive & (comp == COMP_ACTION ? ALL : 0u);
     }
-    if (GENERIC && (row.r0 & ROW_GENERIC) && comp == COMP_ACTION)        // or / in [..] / numeric comparisons: the clause form
+    if (generic_row && comp == COMP_ACTION)                    // or / in [..] / numeric comparisons: the clause form
         T = ww_cond_generic<NB>(s, c.cc, row.r0, ALL) & alive;
     return T;
 }
@@ -1057,7 +1083,8 @@ __device__ __forceinline__ void tt_turn(TT<NB> &s, uint32_t &done, DevRow &row, 
     const uint32_t tk = turn_key(rkey, turn);
 
     uint32_t T = 0;
-    if (comp == COMP_ACTION) {
+    const bool generic_row = GENERIC && (row.r0 & ROW_GENERIC);
+    if (comp == COMP_ACTION && !generic_row) {
         // the 5 base predicates, two per 32-bit word; terms 0..1 by byte permute (see ww_turn, ge_layout.h DevRow)
         const uint32_t W0 = s.speaker | (s.submitted << 16), W1 = s.revealed | (s.can_vote << 16), W2 = s.has_voted;
         uint32_t X = __builtin_amdgcn_perm(W1, W0, row.r4) & __builtin_amdgcn_perm(W2, W2, row.r5);
@@ -1076,7 +1103,7 @@ __device__ __forceinline__ void tt_turn(TT<NB> &s, uint32_t &done, DevRow &row, 
         }
         T = X & ALL;
     }
-    if (GENERIC && (row.r0 & ROW_GENERIC) && comp == COMP_ACTION)        // the clause form (see ww_turn)
+    if (generic_row && comp == COMP_ACTION)                    // the clause form (see ww_turn)
         T = tt_cond_generic<NB>(s, cc, row.r0, ALL);
 
     uint32_t newly = 0;

@@ -205,9 +205,12 @@ __device__ __forceinline__ void run_ww(const SegDev *__restrict__ sgp, const Ste
     };
     const uint32_t term_mask = __builtin_amdgcn_readfirstlane(sg.term_mask);
     const uint32_t turn0 = a.turn0 + (a.turn_dev ? *a.turn_dev : 0u);   // uniform (scalar load)
-    CondShape cs = {0u, 0u, 0u, 0u};
-    if (GENERIC) cs = CondShape{(uint32_t)__builtin_amdgcn_readfirstlane(tables[sg.table_idx].cond_shape), (uint32_t)__builtin_amdgcn_readfirstlane(tables[sg.table_idx].cond_slots),
-                               (uint32_t)__builtin_amdgcn_readfirstlane(tables[sg.table_idx].cond_fields[0]), (uint32_t)__builtin_amdgcn_readfirstlane(tables[sg.table_idx].cond_fields[1])};
+    CondShape cs = {0u, 0u, 0u, 0u, 0u};
+    if (GENERIC) {
+        const DevTable &tb = tables[sg.table_idx];
+        cs = CondShape{(uint32_t)__builtin_amdgcn_readfirstlane(tb.cond_shape), (uint32_t)__builtin_amdgcn_readfirstlane(tb.cond_g[0]), (uint32_t)__builtin_amdgcn_readfirstlane(tb.cond_g[1]),
+                       (uint32_t)__builtin_amdgcn_readfirstlane(tb.cond_fields[0]), (uint32_t)__builtin_amdgcn_readfirstlane(tb.cond_fields[1])};
+    }
     // Role deals are keyed by (room, game index), so they can be prepared before the turn that applies them.  Entering
     // the role-assignment phase is rare per room (once a game) but in a wavefront of 64 rooms some room does it on ~80 %
     // of the turns; instead of running the deal for that one lane, every GE_DEAL_PERIOD-th turn all lanes without a
@@ -349,9 +352,12 @@ __device__ __forceinline__ void run_tt(const SegDev *__restrict__ sgp, const Ste
     const uint32_t done0 = __builtin_amdgcn_readfirstlane(sg.done0);
     const uint32_t term_mask = __builtin_amdgcn_readfirstlane(sg.term_mask);
     const uint32_t turn0 = a.turn0 + (a.turn_dev ? *a.turn_dev : 0u);
-    CondShape cs = {0u, 0u, 0u, 0u};
-    if (GENERIC) cs = CondShape{(uint32_t)__builtin_amdgcn_readfirstlane(tables[sg.table_idx].cond_shape), (uint32_t)__builtin_amdgcn_readfirstlane(tables[sg.table_idx].cond_slots),
-                               (uint32_t)__builtin_amdgcn_readfirstlane(tables[sg.table_idx].cond_fields[0]), (uint32_t)__builtin_amdgcn_readfirstlane(tables[sg.table_idx].cond_fields[1])};
+    CondShape cs = {0u, 0u, 0u, 0u, 0u};
+    if (GENERIC) {
+        const DevTable &tb = tables[sg.table_idx];
+        cs = CondShape{(uint32_t)__builtin_amdgcn_readfirstlane(tb.cond_shape), (uint32_t)__builtin_amdgcn_readfirstlane(tb.cond_g[0]), (uint32_t)__builtin_amdgcn_readfirstlane(tb.cond_g[1]),
+                       (uint32_t)__builtin_amdgcn_readfirstlane(tb.cond_fields[0]), (uint32_t)__builtin_amdgcn_readfirstlane(tb.cond_fields[1])};
+    }
     const CondCtx cc = {reinterpret_cast<const unsigned char *>(rows) + a.cond_off, cs};
     uint32_t done = tt_done_mask<NB>(s.rounds, sg.rounds);   // who has spoken all agreed rounds (ge_device.h)
     if constexpr (SINGLE) {

@@ -338,8 +338,11 @@ struct DevCond { uint32_t lit[4][4]; uint32_t meta, pad[3]; };
 // a wavefront walks the same NCL x LEN slots whatever row it is in, and no lane tests a clause count or length.  A row
 // finds its literals through its slot number (DevRow r0 bits 22..26): image + slot * NCL * LEN * stride.
 // One literal = 4 words (Werewolf N <= 8, Two-Truths) or 8 (Werewolf N <= 12):
-//   w    bit 0: numeric range (else base set); bits 1..3: the numeric field (GE_NUM_*), bits 4..7: the same one-hot (bit 3 + field,
-//        Two-Truths); bits 16..31: 0xFFFF if negated
+//   w    bit 0: numeric range; bits 1..3: the numeric field (GE_NUM_*), bits 4..7: the same one-hot (bit 3 + field, Two-Truths);
+//        bit 8: conj; neither: a base set; bits 16..31: 0xFFFF if negated (base set / numeric range)
+//   conj        an AND of up to 4 (Werewolf N <= 8) / 2 single base predicates, each possibly negated - what most of a generated
+//               condition consists of: m[0..] = v_perm_b32 selectors over the predicate word pairs + the XOR mask of the negated
+//               terms, exactly a shipped row's own terms (DevRow r4..r7): {sA, sB, xor} / Werewolf N <= 12 {sA, sB, sC, xor}
 //   base set    m[k] = AND-mask over packed predicate word k (0xFF / 0xFFFF in the fields the set names): the literal is
 //               the OR-fold of (W[k] & m[k]) - any number of fields, three AND / OR per word (Two-Truths packs its five
 //               masks as speaker | submitted << 16, revealed | can_vote << 16, has_voted)
@@ -352,8 +355,12 @@ struct CondLit12 { uint32_t w, m[6], pad; };
 constexpr uint32_t COND_IMG_BYTES = 16384;      // 32 rows x 16 literals x 32 B at the very most
 constexpr uint32_t ROW_COND_SLOT_SHIFT = 22;    // DevRow r0 bits 22..26: the generic row's slot in the image
 
-// the generic rows' common shape, read once per launch into scalar registers (wave-uniform loop bounds and skips)
-struct CondShape { uint32_t shape, slots, f0, f1; };
+// the generic rows' common shape, read once per launch into scalar registers (wave-uniform loop bounds and skips).
+// shape: NCL [2:0], LEN [6:4].  g / f: a nibble per slot in the order the evaluator visits them (slot i = clause i / LEN,
+// literal i % LEN; the evaluator shifts them out) - g: bit 0 some row has a base set in this slot, bit 1 a numeric range,
+// bit 2 the slot ends a clause, bit 3 some row has a conj; f: which numeric fields the slot compares in some row
+// (bit = GE_NUM_* - 1, Two-Truths)
+struct CondShape { uint32_t shape, g_lo, g_hi, f_lo, f_hi; };
 
 // rows | ord8 | nth8 | spread8 | tally64 lead the structure, contiguous and in the order of a step block's LDS: one linear
 // copy of the first IMG_* bytes fills it (the lone-wavefront builds take rows (+ ord8), Two-Truths up to nth8)
@@ -365,11 +372,11 @@ struct DevTable {
     uint32_t spread8[256];   // spread8[mask] = 0xF in nibble i for every set bit i of the 8-bit mask (voters -> vote nibbles)
     uint64_t tally64[256];   // tally64[a | b << 4] = (1 << 4a) + (1 << 4b): two votes' worth of nibble counters per lookup
     int32_t n_phases, rounds, n_players;
-    uint32_t cond_shape;     // generic rows: largest clause count [2:0] and clause length [6:4], any base-set literal [8], any numeric literal [9]
-    uint32_t cond_slots;     // generic rows: bit 4k + l = some row has a base-set literal in slot l of clause k; bit 16 + 4k + l = a numeric one
-    uint32_t cond_fields[2]; // generic rows: nibble 4k + l (slots 0..7 in [0], 8..15 in [1]) = which numeric fields slot (k, l) compares, bit = GE_NUM_* - 1
+    uint32_t cond_shape;     // generic rows: largest clause count [2:0] and clause length [6:4] (CondShape::shape)
+    uint32_t cond_g[2];      // generic rows: CondShape::g
+    uint32_t cond_fields[2]; // generic rows: CondShape::f
     uint32_t cond_n16;       // generic rows: 16-byte elements of cond_img in use (what a block copies into its LDS)
-    uint32_t pad_[3];
+    uint32_t pad_[2];
     DevCond conds[32];       // clause form of the generic rows, per row (ge_inject_kernel)
     alignas(16) unsigned char cond_img[COND_IMG_BYTES];   // the same for the step kernels: padded literals, slot-major (CondLit / CondLit12)
 };

@@ -41,18 +41,42 @@ struct Segment {
     uint64_t local_first;      // index of the segment's room 0 inside the batch
 };
 
+// v_perm_b32 selectors that gather up to 4 (Werewolf N <= 8: a byte each) or 2 (every other layout: a half-word each)
+// single base predicates out of the packed predicate word pairs (W1:W0), (W3:W2) / (W2:W2), (W5:W4), 0xFF where a term lives
+// elsewhere, and the XOR mask of the negated ones - the form of a row's own terms (DevRow r4..r7) and of a `conj` literal
+void term_selectors(uint32_t kind, int n, const uint8_t *bases, const uint8_t *negs, uint32_t sel[3], uint32_t &negmask) {
+    const bool bytes4 = kind == K_WW8;
+    const int fpw = bytes4 ? 4 : 2, fbytes = bytes4 ? 1 : 2;
+    sel[0] = sel[1] = sel[2] = 0x0D0D0D0Du;                      // selector 0x0D = the constant 0xFF
+    negmask = 0;
+    for (int j = 0; j < n; j++) {
+        const uint32_t base = bases[j];
+        const uint32_t word = base / fpw, pair = bytes4 ? (word < 2 ? 0u : 1u) : word / 2;
+        const uint32_t in_pair = bytes4 ? (word < 2 ? word : 0u) : word % 2;     // N <= 8: W2 is the low word of pair 1
+        const uint32_t byte0 = in_pair * 4u + (base % fpw) * fbytes;
+        for (int k = 0; k < fbytes; k++) {
+            const int ob = j * fbytes + k;                        // output byte
+            sel[pair] = (sel[pair] & ~(0xFFu << (8 * ob))) | ((byte0 + k) << (8 * ob));
+            if (negs[j]) negmask |= 0xFFu << (8 * ob);
+        }
+    }
+}
+
 DevRow to_dev_row(const ge_game_table &tb, const ge_phase_row &r, uint32_t kind) {
     // predicate masks per 32-bit word (ge_device.h): 4 bytes (werewolf N<=8) or 2 half-words (all others)
     const bool bytes4 = kind == K_WW8;
     const int fpw = bytes4 ? 4 : 2;
     const int stride = bytes4 ? 8 : 16;
     DevRow d = {0, 0, 0, 0, 0, 0, 0, 0};
-    d.r0 = (r.completion & 3u) | ((r.act & 7u) << 2) | ((r.effect & 7u) << 5) | ((r.n_terms & 7u) << 8) |
+    // a generic row's condition is its literal image (build_cond_image): it carries no terms, so the kernels' term path has
+    // nothing to do for it (a leftover n_terms > 2 would run the slow per-term branch of ww_targets / tt_turn for nothing)
+    const int n_terms = r.generic ? 0 : r.n_terms;
+    d.r0 = (r.completion & 3u) | ((r.act & 7u) << 2) | ((r.effect & 7u) << 5) | (((uint32_t)n_terms & 7u) << 8) |
            ((r.n_branches & 7u) << 11) | (r.generic ? ROW_GENERIC : 0u);
     for (int j = 0; j < GE_MAX_TERMS; j++) {
-        if (j < r.n_terms) d.r0 |= (uint32_t)(r.term_neg[j] & 1u) << (16 + j);
+        if (j < n_terms) d.r0 |= (uint32_t)(r.term_neg[j] & 1u) << (16 + j);
         const uint32_t base = r.term_base[j];
-        const uint32_t enc = j < r.n_terms ? ((((base / fpw) & 7u) << 5) | (((base % fpw) * stride) & 31u)) : (7u << 5);
+        const uint32_t enc = j < n_terms ? ((((base / fpw) & 7u) << 5) | (((base % fpw) * stride) & 31u)) : (7u << 5);
         d.r1 |= enc << (8 * j);
     }
     for (int b = 0; b < GE_MAX_BRANCHES; b++) {
@@ -63,23 +87,10 @@ DevRow to_dev_row(const ge_game_table &tb, const ge_phase_row &r, uint32_t kind)
         if (b < r.n_branches && r.br_res[b] == GE_RES_ALL_ROUNDS_DONE) d.r0 |= 1u << 20;
     }
     {
-        // all kinds (two-truths: three words of two half-word fields, pairs (W1:W0) and (W2:W2)).
-        // v_perm_b32 selector bytes: 0..3 = bytes of the pair's low word, 4..7 = of its high word, 0x0D = 0xFF
-        uint32_t sel[3] = {0x0D0D0D0Du, 0x0D0D0D0Du, 0x0D0D0D0Du};
-        const int fbytes = bytes4 ? 1 : 2;                       // bytes per field
-        const int nfast = bytes4 ? 4 : 2;                        // terms the permute path covers
-        for (int j = 0; j < nfast && j < r.n_terms; j++) {
-            const uint32_t base = r.term_base[j];
-            const uint32_t word = base / fpw, pair = bytes4 ? (word < 2 ? 0u : 1u) : word / 2;
-            const uint32_t in_pair = bytes4 ? (word < 2 ? word : 0u) : word % 2;     // N<=8: W2 is the low word of pair 1
-            const uint32_t byte0 = in_pair * 4u + (base % fpw) * fbytes;
-            for (int k = 0; k < fbytes; k++) {
-                const int ob = j * fbytes + k;                    // output byte
-                sel[pair] = (sel[pair] & ~(0xFFu << (8 * ob))) | ((byte0 + k) << (8 * ob));
-                if (r.term_neg[j]) d.r7 |= 0xFFu << (8 * ob);
-            }
-        }
-        d.r4 = sel[0]; d.r5 = sel[1]; d.r6 = sel[2];
+        // the first 4 (Werewolf N <= 8) / 2 terms through the permute path
+        uint32_t sel[3], nm;
+        term_selectors(kind, std::min(n_terms, bytes4 ? 4 : 2), r.term_base, r.term_neg, sel, nm);
+        d.r4 = sel[0]; d.r5 = sel[1]; d.r6 = sel[2]; d.r7 = nm;
     }
     return d;
 }
@@ -104,55 +115,119 @@ DevCond to_dev_cond(const ge_phase_row &r) {                       // the clause
 // The generic rows of a table as the step kernels evaluate them: the literal image a block copies into its LDS
 // (ge_layout.h CondLit / CondLit12, ge_device.h eval_cond_image).  Every generic row gets a slot and is padded to the
 // table's common shape with neutral literals; dt.rows[] must already hold the rows (the slot number goes into r0).
+// Inside a clause the literals that test ONE base predicate each ("role == 'Doctor'", "is_alive != false": most of what a
+// generated condition consists of) are merged into `conj` literals - up to 4 (2) terms answered by one permute-and-fold,
+// like a shipped row's own terms - so a typical clause is one conj literal, or one and a numeric range.
 void build_cond_image(const ge_game_table &tb, uint32_t kind, DevTable &dt) {
-    uint32_t ncl = 0, len = 0, kinds = 0, slots = 0, fields[2] = {0, 0}, n_generic = 0;
+    struct Lit { int what; ge_literal x; int n; uint8_t bases[4], negs[4]; };          // what: 0 base set, 1 numeric range, 2 conj, 3 constant FALSE (x.neg: TRUE)
+    const bool ww8 = kind == K_WW8, ww12 = kind == K_WW12;
+    const int cap = ww8 ? 4 : 2;                                                        // terms per conj literal
+    std::vector<std::vector<std::vector<Lit>>> rows;                                    // generic row -> clause -> literal
+    std::vector<int> row_of;
+    uint32_t ncl = 0, len = 0;
     for (int r = 0; r < tb.n_phases; r++) {
         const ge_phase_row &pr = tb.rows[r];
         if (!pr.generic) continue;
-        n_generic++;
         const uint32_t rc = pr.n_clauses <= GE_MAX_CLAUSES ? pr.n_clauses : GE_MAX_CLAUSES;
-        ncl = std::max<uint32_t>(ncl, std::max<uint32_t>(rc, 1u));                      // no clause at all = everybody: one clause of TRUE literals
+        std::vector<std::vector<Lit>> clauses;
         for (uint32_t k = 0; k < rc; k++) {
             const uint32_t rl = pr.clause_len[k] <= GE_MAX_TERMS ? pr.clause_len[k] : GE_MAX_TERMS;
-            len = std::max<uint32_t>(len, rl);
+            std::vector<Lit> singles, others;
             for (uint32_t l = 0; l < rl; l++) {
-                const ge_literal &x = pr.clause[k][l];
-                const uint32_t slot = 4u * k + l;
-                const bool num = x.kind == GE_LIT_NUM && x.lo <= x.hi;                  // an empty range is the constant FALSE: no compare
-                if (x.kind == GE_LIT_NUM && !num) continue;
-                kinds |= num ? 0x200u : 0x100u;
-                slots |= 1u << ((num ? 16u : 0u) + slot);
-                if (num && x.num_field >= 1 && x.num_field <= 4) fields[slot >> 3] |= 1u << (4u * (slot & 7u) + (x.num_field - 1u));
+                Lit t;
+                memset(&t, 0, sizeof t);
+                t.x = pr.clause[k][l];
+                const bool nibbles = t.x.num_field == GE_NUM_SELECTED_TARGET || t.x.num_field == GE_NUM_ROUNDS_AS_SPEAKER;
+                if (t.x.kind == GE_LIT_NUM) {
+                    t.what = (t.x.lo > t.x.hi || (nibbles && t.x.lo > 15)) ? 3 : 1;                // an empty range: the constant FALSE (negated: TRUE)
+                    others.push_back(t);
+                } else if (__builtin_popcount(t.x.bases) == 1) {
+                    t.what = 2; t.n = 1; t.bases[0] = (uint8_t)__builtin_ctz(t.x.bases); t.negs[0] = t.x.neg ? 1 : 0;
+                    singles.push_back(t);
+                } else {
+                    t.what = t.x.bases ? 0 : 3;
+                    others.push_back(t);
+                }
             }
+            // every single-predicate literal goes into a conj, `cap` terms per literal - a lone one too: a slot that holds one
+            // kind of literal in every row evaluates one form, and a conj costs what a base set does
+            std::vector<Lit> out;
+            for (size_t i = 0; i < singles.size(); i += cap) {
+                Lit c;
+                memset(&c, 0, sizeof c);
+                c.what = 2;
+                for (size_t j = i; j < singles.size() && j < i + cap; j++) { c.bases[c.n] = singles[j].bases[0]; c.negs[c.n] = singles[j].negs[0]; c.n++; }
+                out.push_back(c);
+            }
+            for (const Lit &t : others) out.push_back(t);
+            len = std::max<uint32_t>(len, (uint32_t)out.size());
+            clauses.push_back(out);
         }
+        ncl = std::max<uint32_t>(ncl, std::max<uint32_t>((uint32_t)clauses.size(), 1u));          // no clause at all = everybody: one clause of TRUE literals
+        rows.push_back(clauses);
+        row_of.push_back(r);
     }
-    dt.cond_shape = 0; dt.cond_slots = 0; dt.cond_fields[0] = dt.cond_fields[1] = 0; dt.cond_n16 = 0;
-    if (!n_generic) return;
+    dt.cond_shape = 0; dt.cond_g[0] = dt.cond_g[1] = 0; dt.cond_fields[0] = dt.cond_fields[1] = 0; dt.cond_n16 = 0;
+    if (rows.empty()) return;
     len = std::max<uint32_t>(len, 1u);
-    dt.cond_shape = ncl | (len << 4) | kinds;
-    dt.cond_slots = slots; dt.cond_fields[0] = fields[0]; dt.cond_fields[1] = fields[1];
-    const bool ww8 = kind == K_WW8, ww12 = kind == K_WW12;
-    const uint32_t stride = ww12 ? sizeof(CondLit12) : sizeof(CondLit);                 // bytes per literal
+    dt.cond_shape = ncl | (len << 4);
+    // per slot, over all rows: which kinds (g: 1 base set, 2 numeric, 4 clause end, 8 conj) and which numeric fields (f)
+    uint32_t g_of[16] = {0}, f_of[16] = {0};
+    for (const auto &clauses : rows)
+        for (size_t k = 0; k < clauses.size(); k++)
+            for (size_t l = 0; l < clauses[k].size(); l++) {
+                const Lit &t = clauses[k][l];
+                const uint32_t i = (uint32_t)(k * len + l);
+                if (t.what == 0) g_of[i] |= 1u;
+                if (t.what == 2) g_of[i] |= 8u;
+                if (t.what == 1) { g_of[i] |= 2u; if (t.x.num_field >= 1 && t.x.num_field <= 4) f_of[i] |= 1u << (t.x.num_field - 1u); }
+            }
+    {
+        uint64_t G = 0, F = 0;                                                                     // a nibble per slot, in the evaluator's order
+        for (uint32_t i = 0; i < ncl * len; i++) {
+            G |= (uint64_t)(g_of[i] | ((i + 1u) % len == 0u ? 4u : 0u)) << (4u * i);
+            F |= (uint64_t)f_of[i] << (4u * i);
+        }
+        dt.cond_g[0] = (uint32_t)G; dt.cond_g[1] = (uint32_t)(G >> 32);
+        dt.cond_fields[0] = (uint32_t)F; dt.cond_fields[1] = (uint32_t)(F >> 32);
+    }
+    const uint32_t stride = ww12 ? sizeof(CondLit12) : sizeof(CondLit);                            // bytes per literal
     uint32_t *img = reinterpret_cast<uint32_t *>(dt.cond_img);
-    const uint32_t FALSE_W = 0u, TRUE_W = 0xFFFF0000u;                                   // base sets with no field; TRUE = negated
-    uint32_t slot_no = 0;
-    for (int r = 0; r < tb.n_phases; r++) {
-        const ge_phase_row &pr = tb.rows[r];
-        if (!pr.generic) continue;
-        dt.rows[r].r0 |= slot_no << ROW_COND_SLOT_SHIFT;
-        const uint32_t rc = pr.n_clauses <= GE_MAX_CLAUSES ? pr.n_clauses : GE_MAX_CLAUSES;
+    for (size_t slot_no = 0; slot_no < rows.size(); slot_no++) {
+        const auto &clauses = rows[slot_no];
+        dt.rows[row_of[slot_no]].r0 |= (uint32_t)slot_no << ROW_COND_SLOT_SHIFT;
         for (uint32_t k = 0; k < ncl; k++)
             for (uint32_t l = 0; l < len; l++) {
-                uint32_t *d = img + (size_t)((slot_no * ncl + k) * len + l) * (stride / 4u);
+                const uint32_t i = k * len + l;
+                uint32_t *d = img + ((size_t)slot_no * ncl * len + i) * (stride / 4u);
                 memset(d, 0, stride);
-                const bool clause_used = rc == 0 ? k == 0 : k < rc;
-                const uint32_t rl = k < rc ? std::min<uint32_t>(pr.clause_len[k], GE_MAX_TERMS) : 0u;
-                if (!clause_used) { d[0] = FALSE_W; continue; }
-                if (l >= rl) { d[0] = TRUE_W; continue; }
-                const ge_literal &x = pr.clause[k][l];
+                // a neutral literal in the cheapest kind the slot evaluates anyway: a base set with no field (FALSE; negated:
+                // TRUE), or - in a slot that holds conj literals but no base sets - a conj of no terms (TRUE; one negated
+                // constant byte: FALSE)
+                auto constant = [&](bool value) {
+                    if ((g_of[i] & 8u) && !(g_of[i] & 1u)) {
+                        d[0] = 0x100u; d[1] = d[2] = 0x0D0D0D0Du;
+                        if (ww12) { d[3] = 0x0D0D0D0Du; d[4] = value ? 0u : 0xFFFFFFFFu; } else d[3] = value ? 0u : 0xFFFFFFFFu;
+                    } else {
+                        d[0] = value ? 0xFFFF0000u : 0u;
+                    }
+                };
+                const bool clause_used = clauses.empty() ? k == 0 : k < clauses.size();
+                if (!clause_used) { constant(false); continue; }
+                if (clauses.empty() || l >= clauses[k].size()) { constant(true); continue; }
+                const Lit &t = clauses[k][l];
+                const ge_literal &x = t.x;
                 const uint32_t neg = x.neg ? 0xFFFF0000u : 0u;
-                if (x.kind == GE_LIT_NUM) {
-                    if (x.lo > x.hi) { d[0] = FALSE_W ^ neg; continue; }                 // never true (negated: always)
+                if (t.what == 3) { constant(x.neg != 0); continue; }
+                if (t.what == 2) {                                                                 // conj: selectors + XOR mask, like a row's own terms
+                    uint32_t sel[3], nm;
+                    term_selectors(kind, t.n, t.bases, t.negs, sel, nm);
+                    d[0] = 0x100u;
+                    if (ww12) { d[1] = sel[0]; d[2] = sel[1]; d[3] = sel[2]; d[4] = nm; }
+                    else { d[1] = sel[0]; d[2] = sel[1]; d[3] = nm; }
+                    continue;
+                }
+                if (t.what == 1) {
                     const uint32_t f = x.num_field & 7u;
                     d[0] = 1u | (f << 1) | (f ? 1u << (3u + f) : 0u) | neg;
                     if (f == GE_NUM_LIE_INDEX || f == GE_NUM_VOTE_CHOICE) {              // 2-bit fields: the allowed values as masks
@@ -163,7 +238,6 @@ void build_cond_image(const ge_game_table &tb, uint32_t kind, DevTable &dt) {
                         d[1] = (uint32_t)x.lo * 0x00010001u;
                         d[2] = ((uint32_t)x.hi * 0x00010001u) | 0x80008000u;
                     } else {                                                             // nibble arrays (selected_target_id, rounds_as_speaker) in byte lanes
-                        if (x.lo > 15) { d[0] = FALSE_W ^ neg; continue; }
                         d[1] = (uint32_t)x.lo * 0x01010101u;
                         d[2] = (std::min<uint32_t>(x.hi, 15u) * 0x01010101u) | 0x80808080u;
                     }
@@ -177,9 +251,8 @@ void build_cond_image(const ge_game_table &tb, uint32_t kind, DevTable &dt) {
                     else if (b < 5u) d[1 + b / 2u] |= 0xFFFFu << (16u * (b % 2u));       // speaker | submitted << 16, revealed | can_vote << 16, has_voted
                 }
             }
-        slot_no++;
     }
-    dt.cond_n16 = slot_no * ncl * len * stride / 16u;
+    dt.cond_n16 = (uint32_t)rows.size() * ncl * len * stride / 16u;
 }
 
 // the initial record in the kernels' register form (SegDev::init_regs)
