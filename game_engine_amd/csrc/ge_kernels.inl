@@ -8,7 +8,6 @@ constexpr uint32_t LDS_ROWS = sizeof(DevRow) * GE_MAX_PHASES;
 constexpr uint32_t LDS_ORD8 = 1024;
 static_assert(LDS_ROWS == IMG_ORD8 && LDS_ROWS + LDS_ORD8 == IMG_NTH8, "LDS image offsets");
 
-enum Kind { K_WW8 = 0, K_WW12, K_TT4, K_TT8, K_TT12, K_COUNT };
 
 struct SegDev {
     uint32_t *base;            // planes of this segment
@@ -637,10 +636,11 @@ template <int NB> __device__ __forceinline__ bool ww_base(const WW<NB> &s, uint3
     }
 }
 template <int NB> __device__ __forceinline__ bool tt_base(const TT<NB> &s, uint32_t base, uint32_t bit) {
-    switch (base) {
-    case 0: return s.speaker & bit; case 1: return s.submitted & bit; case 2: return s.revealed & bit;
-    case 3: return s.can_vote & bit; default: return s.has_voted & bit;
-    }
+    // selects, not a switch: the compiler turns a switch over five masks into a table in scratch memory
+    uint32_t m = s.has_voted;
+    m = sel32(base == 0u, s.speaker, m); m = sel32(base == 1u, s.submitted, m);
+    m = sel32(base == 2u, s.revealed, m); m = sel32(base == 3u, s.can_vote, m);
+    return (m & bit) != 0u;
 }
 // the row's j-th term as (base, negated): r1 encodes {word, shift} into the packed predicate words
 __device__ __forceinline__ void row_term(const DevRow &row, uint32_t j, uint32_t fpw, uint32_t &base, bool &neg) {
@@ -674,7 +674,7 @@ __device__ __forceinline__ bool clauses_hold(const DevCond &c, BASE base_true, N
     return false;
 }
 
-template <int NB> __device__ int inject_ww(WW<NB> &s, const DevRow &row, const DevCond &cond, uint32_t n, uint32_t player, uint32_t choice) {
+template <int NB> __device__ __forceinline__ int inject_ww(WW<NB> &s, const DevRow &row, const DevCond &cond, uint32_t n, uint32_t player, uint32_t choice) {
     using nib_t = typename WW<NB>::nib_t;
     if (player < 1 || player > n) return GE_ERR_ARG;
     if ((row.r0 & 3u) != COMP_ACTION) return GE_ERR_ARG;
@@ -706,7 +706,7 @@ template <int NB> __device__ int inject_ww(WW<NB> &s, const DevRow &row, const D
     return GE_OK;
 }
 
-template <int NB> __device__ int inject_tt(TT<NB> &s, const DevRow &row, const DevCond &cond, uint32_t n, uint32_t player, uint32_t choice) {
+template <int NB> __device__ __forceinline__ int inject_tt(TT<NB> &s, const DevRow &row, const DevCond &cond, uint32_t n, uint32_t player, uint32_t choice) {
     if (player < 1 || player > n) return GE_ERR_ARG;
     if ((row.r0 & 3u) != COMP_ACTION) return GE_ERR_ARG;
     const uint32_t bit = 1u << (player - 1u);
@@ -718,8 +718,8 @@ template <int NB> __device__ int inject_tt(TT<NB> &s, const DevRow &row, const D
                               if (f == 2u) return (s.vote >> (2u * i)) & 3u;
                               if (f == 4u) return (uint32_t)(s.rounds >> (4u * i)) & 15u;
                               uint32_t sc = s.score[0];                            // no dynamic index: the record stays in registers
-                              if (NB > 4 && i >= 4u) sc = s.score[NB > 4 ? 1 : 0];
-                              if (NB > 8 && i >= 8u) sc = s.score[NB > 8 ? 2 : 0];
+                              if (NB > 4) sc = sel32(i >= 4u, s.score[NB > 4 ? 1 : 0], sc);
+                              if (NB > 8) sc = sel32(i >= 8u, s.score[NB > 8 ? 2 : 0], sc);
                               return (sc >> (8u * (i % 4u))) & 255u;
                           })) return GE_ERR_ARG;
     }
@@ -741,7 +741,7 @@ template <int NB> __device__ int inject_tt(TT<NB> &s, const DevRow &row, const D
     return GE_OK;
 }
 
-template <int NB> __device__ void inject_group_ww(const SegDev &sg, const DevTable *tables, uint64_t room, const InjectArgs &a, uint32_t lo, uint32_t hi) {
+template <int NB> __device__ __forceinline__ void inject_group_ww(const SegDev &sg, const DevTable *tables, uint64_t room, const InjectArgs &a, uint32_t lo, uint32_t hi) {
     using L = WWLayout<NB>;
     uint32_t w[L::WORDS];
     load_words<L::WORDS>(sg.base, sg.rooms_padded, room, w);
@@ -753,7 +753,7 @@ template <int NB> __device__ void inject_group_ww(const SegDev &sg, const DevTab
     L::pack(s, w);
     store_words<L::WORDS>(sg.base, sg.rooms_padded, room, w);
 }
-template <int NB> __device__ void inject_group_tt(const SegDev &sg, const DevTable *tables, uint64_t room, const InjectArgs &a, uint32_t lo, uint32_t hi) {
+template <int NB> __device__ __forceinline__ void inject_group_tt(const SegDev &sg, const DevTable *tables, uint64_t room, const InjectArgs &a, uint32_t lo, uint32_t hi) {
     using L = TTLayout<NB>;
     uint32_t w[L::WORDS];
     load_words<L::WORDS>(sg.base, sg.rooms_padded, room, w);

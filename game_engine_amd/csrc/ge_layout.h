@@ -31,6 +31,8 @@ template <int NB> struct Nib;                       // nibble-array carrier: 4 b
 template <> struct Nib<8> { using type = uint32_t; };
 template <> struct Nib<12> { using type = uint64_t; };
 
+enum Kind { K_WW8 = 0, K_WW12, K_TT4, K_TT8, K_TT12, K_COUNT };   // the record layouts (one kernel instantiation each)
+
 constexpr int FLAG_PHASE0_DONE = 1;                 // flags bit 0; bits 1..3 = effect of prev phase
 constexpr uint32_t END_NONE = 0xFFFFu;              // end_turn: not finished
 
