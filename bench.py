@@ -65,14 +65,19 @@ WORKLOADS = {
     "c3": [(TT, 4, 1048576)],
     "c4": [(WW, 12, 2097152)],                                   # 16 777 216 rooms over 8 GPUs
     "c5": [(WW, 8, 524288), (TT, 4, 524288)],                    # 50/50 mix, one launch
+    # resident states larger than the 256 MiB Infinity Cache (the hbm_streaming_beyond_l3 shapes; `--workload` lets
+    # tools/profile.sh take their kernel-trace and counter passes)
+    "ww8_33554432": [(WW, 8, 1 << 25)],
+    "c4_whole": [(WW, 12, 1 << 24)],                             # the whole of C4 on one GPU
+    "tt4_33554432": [(TT, 4, 1 << 25)],
 }
 L3_BYTES = 256 << 20           # Infinity Cache (MALL) of MI355X, /opt/skills/guides/MI355X_MICROARCH.md:297
 # single-turn launches over a resident state LARGER than the Infinity Cache: what a launch reads and writes cannot have been
 # left in the cache by the launch before it - the HBM figure that is provably HBM (label, profile key, segments)
 BEYOND_L3_SHAPES = (
-    ("33554432 Werewolf x8 (1 GiB of records)", "ww8_33554432", [(WW, 8, 1 << 25)]),
-    ("16777216 Werewolf x12 (the WHOLE of C4 on one GPU, 640 MiB)", "c4_whole", [(WW, 12, 1 << 24)]),
-    ("33554432 Two-Truths x4 (768 MiB)", "tt4_33554432", [(TT, 4, 1 << 25)]),
+    ("33554432 Werewolf x8 (1 GiB of records)", "ww8_33554432"),
+    ("16777216 Werewolf x12 (the WHOLE of C4 on one GPU, 640 MiB)", "c4_whole"),
+    ("33554432 Two-Truths x4 (768 MiB)", "tt4_33554432"),
 )
 # the informational shapes of an N = 1 run: (label, profile key, per-GPU segments)
 OTHER_SHAPES = (
@@ -383,14 +388,15 @@ def main():
     # the HBM-streaming point of the contract shape (N=1 only: keeps multi-GPU runs symmetric)
     unfused = None
     if rank == 0 and world == 1 and not args.no_unfused:
-        unfused = streaming_point(spec)
+        unfused = streaming_point(spec, launches=max(16, min(256, int(1.2e10 // rooms))), preroll=PREROLL_TURNS if rooms <= (1 << 22) else 256)
 
     # the same launch over a state larger than the Infinity Cache (N = 1), and parity at that size: 64 single-turn launches
     # == 64 fused turns (the whole ge_summary, checksum of every packed record included)
     beyond_l3 = None
     if rank == 0 and world == 1 and not args.no_unfused and not args.no_other_shapes and args.workload == "c2":
         beyond_l3 = {}
-        for label, key, sp in BEYOND_L3_SHAPES:
+        for label, key in BEYOND_L3_SHAPES:
+            sp = WORKLOADS[key]
             r = sum(x[2] for x in sp)
             pt = streaming_point(sp, launches=max(8, min(64, int(3e9 // r))), preroll=256)
             with RoomBatch(segments_of(sp), seed=SEED, device=device_index, max_fuse=1, restart=True) as k1, \

@@ -6,7 +6,7 @@ usage: design_tables.py [tag] [--write]    (--write: rewrite the marked blocks o
 import io, json, os, re, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
-tag = args[0] if args else "r03"
+tag = args[0] if args else "r04"
 _blocks, _real_print, _cur = {}, print, [None]
 def begin(name): _cur[0] = name; _blocks[name] = []
 def print(*a):                                                   # rows go to the current block
@@ -37,14 +37,27 @@ if os.path.exists(os.path.join(root, "profiles", "pmc_c5.json")) and os.path.exi
     tot = i["valu"] + i["salu"] + i["lds"]; ceil5 = 1024 * 2.4e9 / 2.0
     print(f"| C5 share: 524 288 Werewolf × 8 + 524 288 Two-Truths × 4, one launch | {i['valu']:.0f} + {i['salu']:.0f} + {i['lds']:.0f} | {us:.3f} | {rooms5 / (us * 1e-6):.3g} | {tot * wt / ceil5:.2f} / {i['valu'] * wt / ceil5:.2f} | {100 * p['wait_any_frac']:.0f} % |")
 begin("k1_table")
-print("| shape (single-turn launches) | VALU + SALU + LDS per wave-turn | measured HBM bytes per launch (state read + written) | kernel-trace average (sustained) | % of 8 TB/s by kernel-trace | bench line: sustained / per-launch events | `SQ_WAIT_ANY` |\n|---|---|---|---|---|---|---|")
+print("| shape (single-turn launches; state <= 256 MiB: a memory-side rate, the Infinity Cache may serve) | VALU + SALU + LDS per wave-turn | measured memory-side bytes per launch (state read + written) | kernel-trace average (sustained) | % of 8 TB/s by kernel-trace | bench line: sustained / per-launch events | `SQ_WAIT_ANY` |\n|---|---|---|---|---|---|---|")
 for k in ("c2", "ww8_1048576", "c4", "c3"):
     p = P(k + "_k1"); i = p["instructions_per_wave_turn"]; kt = p["kernel_trace"]
     hs = bench["hbm_streaming"] if k == "c2" else other[okey[k]]["hbm_streaming"]
     st = p["state_bytes_read_plus_written"]
     print(f"| {labels[k].split(' (1 wave')[0]} | {i['valu']:.0f} + {i['salu']:.0f} + {i['lds']:.0f} | {p['hbm_bytes_per_launch'] / 1e6:.1f} MB ({st / 1e6:.1f}) | {kt['average_ns'] / 1e3:.2f} µs ({kt['calls']} launches) | **{100 * st / kt['average_ns'] / 8e3:.1f}** | {100 * hs['frac']:.1f} / {100 * hs['frac_kernel']:.1f} | {100 * p['wait_any_frac']:.0f} % |")
+begin("beyond_l3_table")
+# single-turn launches over a resident state larger than the Infinity Cache: the HBM figure that is provably HBM
+print("| shape (single-turn launches, resident state > 256 MiB) | resident state | VALU + SALU + LDS per wave-turn | measured HBM bytes per launch (state read + written) | kernel-trace average | **% of 8 TB/s by kernel-trace** (% of the 6.29 TB/s copy rate) | bench line (HIP events around a graph replay) | 64 single-turn launches == 64 fused turns |\n|---|---|---|---|---|---|---|---|")
+for label, key in (("33554432 Werewolf x8 (1 GiB of records)", "ww8_33554432"), ("16777216 Werewolf x12 (the WHOLE of C4 on one GPU, 640 MiB)", "c4_whole"), ("33554432 Two-Truths x4 (768 MiB)", "tt4_33554432")):
+    p = P(key + "_k1"); i = p["instructions_per_wave_turn"]; kt = p["kernel_trace"]; st = p["state_bytes_read_plus_written"]
+    b = bench["hbm_streaming_beyond_l3"][label]
+    pct = 100 * st / kt["average_ns"] / 8e3
+    print(f"| {label.replace(' x', ' × ')} | {b['resident_state_MiB']:.0f} MiB | {i['valu']:.0f} + {i['salu']:.0f} + {i['lds']:.0f} | {p['hbm_bytes_per_launch'] / 1e6:.1f} MB ({st / 1e6:.1f}) | {kt['average_ns'] / 1e3:.1f} µs ({kt['calls']} launches) | **{pct:.1f}** ({pct * 8 / 6.29:.0f}) | {100 * b['frac']:.1f} ({b['us_per_launch_sustained']:.1f} µs) | {'yes' if b['parity']['single_turn_equals_fused'] else 'NO'} |")
+begin("asm_table")
+# registers, spills, scratch, occupancy of every kernel, from the compiler's remarks (tools/asm_table.py = make asm)
+sys.path.insert(0, os.path.join(root, "tools"))
+import asm_table as _asm
+for line in _asm.markdown(_asm.collect(rebuild=True)).splitlines(): print(line)
 begin("result_table")
-print("| shape | fused (1 024 turns/launch): steps/s | alg. GB/s (% of 8 TB/s: a yardstick, not traffic) | single-turn launches: real HBM % of 8 TB/s (sustained) | CPU: oracle, steps/s (cores) |\n|---|---|---|---|---|")
+print("| shape | fused (1 024 turns/launch): steps/s | alg. GB/s (% of 8 TB/s: a yardstick, not traffic) | single-turn launches: memory-side % of 8 TB/s (sustained; state fits the Infinity Cache) | CPU: oracle, steps/s (cores) |\n|---|---|---|---|---|")
 print(f"| C2: 65 536 Werewolf × 8 — the `bench.py` line | **{bench['value']:.3g}** (wall) | {bench['roofline']['achieved']:.0f} ({100 * bench['roofline']['frac']:.1f}) | {100 * bench['hbm_streaming']['frac']:.1f} (launch-bound: {bench['hbm_streaming']['us_per_launch_sustained']:.1f} µs per launch) | {bench['cpu_baseline']['value']:.3g} ({bench['cpu_baseline']['cores']}); one thread {bench['cpu_baseline']['single_thread_value']:.3g} |")
 for k in ("ww8_1048576", "c4", "c3"):
     v = other[okey[k]]
@@ -82,6 +95,9 @@ _vals = {
     "k1pct": " / ".join("%.1f" % (100 * P(k + "_k1")["state_bytes_read_plus_written"] / P(k + "_k1")["kernel_trace"]["average_ns"] / 8e3)
                         for k in ("ww8_1048576", "c4", "c3")) + " %",
 }
+for _lab, _key in (("33554432 Werewolf x8 (1 GiB of records)", "bl3_ww8"), ("16777216 Werewolf x12 (the WHOLE of C4 on one GPU, 640 MiB)", "bl3_c4"), ("33554432 Two-Truths x4 (768 MiB)", "bl3_tt4")):
+    _q = P({"bl3_ww8": "ww8_33554432", "bl3_c4": "c4_whole", "bl3_tt4": "tt4_33554432"}[_key] + "_k1")
+    _vals[_key] = "%.1f" % (100 * _q["state_bytes_read_plus_written"] / _q["kernel_trace"]["average_ns"] / 8e3)
 _n2 = os.path.join(root, "profiles", f"{tag}_bench_n2_gloo_rehearsal.json")
 if os.path.exists(_n2):                                           # the 2-rank rehearsal's whole-job figures
     n2 = json.loads(open(_n2).read().strip().splitlines()[-1]); ow = n2.get("other_workloads") or {}
@@ -93,7 +109,7 @@ if "--write" in sys.argv:
     for doc in ("DESIGN.md", "BASELINE.md", "README.md", os.path.join("profiles", "README.md")):
         path = os.path.join(root, doc); s = open(path, encoding="utf-8").read(); before = s
         for name, rows in _blocks.items():
-            s = re.sub(r"(<!-- gen:%s -->\n).*?(\n<!-- /gen -->)" % name, lambda m: m.group(1) + "\n".join(rows) + m.group(2), s, flags=re.S)
+            s = re.sub(r"(<!-- gen:%s -->\n).*?(<!-- /gen -->)" % name, lambda m: m.group(1) + "\n".join(rows) + "\n" + m.group(2), s, flags=re.S)   # (also an empty block)
         for name, v in _vals.items():
             s = re.sub(r"(<!--g:%s-->).*?(<!--/g-->)" % name, lambda m: m.group(1) + v + m.group(2), s)
         if s != before:
