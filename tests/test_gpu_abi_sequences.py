@@ -10,6 +10,7 @@ staging buffer of read_rooms / write_rooms and left the pointer); these tests pi
   interleaved at random, batch sizes on both sides of the 4 KB stack / pinned threshold and action counts on both sides of
   the injection scratch's first size, every observable compared with the oracle model after every operation.
 """
+import os
 import zlib
 
 import numpy as np
@@ -166,7 +167,7 @@ SCENARIOS = [
 
 
 @pytest.mark.parametrize("name,segs,fuse,restart,trace", SCENARIOS, ids=[s[0] for s in SCENARIOS])
-@pytest.mark.parametrize("fuzz_seed", [0, 1])
+@pytest.mark.parametrize("fuzz_seed", range(int(os.environ.get("GE_SEQ_FUZZ_SEEDS", "2"))))     # (a soak run sets more)
 def test_abi_state_machine_fuzz(name, segs, fuse, restart, trace, fuzz_seed):
     rng = np.random.default_rng(zlib.crc32(name.encode()) + fuzz_seed)
     seed, first = 777 + fuzz_seed, (1 << 30) + 3
