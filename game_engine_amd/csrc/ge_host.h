@@ -251,14 +251,15 @@ template <int NB> inline void view_to_ww(const ge_room_view &v, const ge_game_ta
     for (int i = 0; i < v.n_players; i++) {
         const uint8_t *f = v.players[i];
         const uint32_t b = 1u << i;
-        if (f[0] & 1) s.rb0 |= b; if (f[0] & 2) s.rb1 |= b; if (f[0] & 4) s.rb2 |= b;
-        if (f[1] == 1) s.team_v |= b; if (f[1] == 2) s.team_w |= b;
-        if (f[2]) s.alive |= b; if (f[3]) s.revealed |= b; if (f[4]) s.can_vote |= b; if (f[5]) s.secret |= b;
-        if (f[6]) s.elig |= b; if (f[7]) s.sub |= b;
+        auto put = [b](bool on, uint32_t &mask) { mask |= on ? b : 0u; };
+        put(f[0] & 1, s.rb0); put(f[0] & 2, s.rb1); put(f[0] & 4, s.rb2);
+        put(f[1] == 1, s.team_v); put(f[1] == 2, s.team_w);
+        put(f[2], s.alive); put(f[3], s.revealed); put(f[4], s.can_vote); put(f[5], s.secret);
+        put(f[6], s.elig); put(f[7], s.sub);
         s.sel |= (typename WW<NB>::nib_t)(f[8] & 15) << (4 * i);
-        if (f[9]) s.acted |= b;
+        put(f[9], s.acted);
         s.choice |= (typename WW<NB>::nib_t)(f[10] & 15) << (4 * i);
-        if (v.det[i] == 1) s.det_v |= b; if (v.det[i] == 2) s.det_w |= b;
+        put(v.det[i] == 1, s.det_v); put(v.det[i] == 2, s.det_w);
     }
     int pi = 0, qi = 0;
     for (int k = 0; k < tb.n_phases; k++) {
@@ -299,8 +300,9 @@ template <int NB> inline void view_to_tt(const ge_room_view &v, const ge_game_ta
     for (int i = 0; i < v.n_players; i++) {
         const uint8_t *f = v.players[i];
         const uint32_t b = 1u << i;
-        if (f[0]) s.speaker |= b; if (f[1]) s.submitted |= b; if (f[3]) s.revealed |= b;
-        if (f[4]) s.can_vote |= b; if (f[6]) s.has_voted |= b; if (f[9]) s.acted |= b;
+        auto put = [b](bool on, uint32_t &mask) { mask |= on ? b : 0u; };
+        put(f[0], s.speaker); put(f[1], s.submitted); put(f[3], s.revealed);
+        put(f[4], s.can_vote); put(f[6], s.has_voted); put(f[9], s.acted);
         s.lie |= (uint32_t)(f[2] & 3) << (2 * i); s.vote |= (uint32_t)(f[5] & 3) << (2 * i);
         s.choice |= (uint32_t)(f[10] & 3) << (2 * i);
         s.score[i / 4] |= (uint32_t)f[7] << (8 * (i % 4));

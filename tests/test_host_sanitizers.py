@@ -14,7 +14,7 @@ from oracle import dsl_variants
 def test_host_code_under_address_and_ub_sanitizers(tmp_path):
     exe = tmp_path / "host_sanitize"
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
-                           "-Wall", "-Wextra", "-Wno-unused-parameter", "-Wno-misleading-indentation", "-o", str(exe),
+                           "-Wall", "-Wextra", "-Werror", "-Wno-unused-parameter", "-o", str(exe),
                            os.path.join(ROOT, "tests", "native", "host_sanitize.cpp"),
                            os.path.join(ROOT, "game_engine_amd", "csrc", "ge_table.cpp")])
     files = [os.path.join(GOLD, "dsl", f) for f in sorted(os.listdir(os.path.join(GOLD, "dsl"))) if f.endswith(".json")]
