@@ -163,6 +163,10 @@ SCENARIOS = [
     ("mixed-small", [(WW, 12, 102, 0b1), (TT, 4, 170, 0b11), (WW, 8, 128, 0b10)], 8, True, False),
     ("mixed-large", [(WW, 12, 103, 0b100000000001), (TT, 4, 171, 0b1), (WW, 8, 3000, 0)], 2, False, True),
     ("tt4-5000-trace", [(TT, 4, 5000, 0b11)], 3, True, True),
+    # single-game Werewolf x 12 in single-turn launches: the side plane of prepared deals (both kernel builds) under resets,
+    # turn changes and overwritten rooms
+    ("ww12-300-single", [(WW, 12, 300, 0b1)], 1, True, True),
+    ("ww12-70000-single", [(WW, 12, 70000, 0)], 1, True, False),
 ]
 
 
