@@ -270,6 +270,15 @@ class RoomLog {
     }
     this.phaseHistory.push({ phase_id: after.current_phase_id, phase_name: after.current_phase_name, timestamp: new Date(now).toISOString() });   // every turn, v2:1207-1215
   }
+  /** File a person's game message as process_human_action_if_needed does (agent/tools/utils.py:343-350): under Player 1,
+   * the first 200 characters, and under PHASE 0's NAME whatever the current phase is (InitialRouterNode passes state keys that
+   * do not exist, agent/game_agent_v2.py:324-331) - mirrored, not corrected (POLICY.md 3b). */
+  personMessage(text, now = Date.now()) {
+    const rec = this.playerActions['1'] || (this.playerActions['1'] = { name: this.names[0], actions: {} });
+    const id = String(Object.values(rec.actions).reduce((m, x) => Math.max(m, Number(x.id)), 0) + 1);
+    rec.name = this.names[0];
+    rec.actions[id] = { action: Array.from(String(text)).slice(0, 200).join(''), timestamp: now, phase: this.table.phaseName(0), id };
+  }
   /** AgentState of the room (v2:97-117), player_states in the reference's key order. */
   agentState(room) {
     const ps = {};

@@ -16,6 +16,10 @@ export class RoomService {
   createRoom(opts: { threadId: string; gameName: string; players: RoomPlayer[]; dsl?: object; /** global room index the RNG is keyed by (default: hash of the thread id) */ roomIndex?: number | bigint }): AgentStateView;
   /** Requests of one thread are served strictly one after the other. */
   humanAction(threadId: string, playerId: number, choice: number): Promise<AgentStateView>;
+  /** One message of the browser, as the reference's graph reads it (page.tsx:272-275, 302-305, 341-349, 2774, 2843, 2962;
+   *  POLICY.md 3b): chat plays no turn; anything else plays one, after a game message was logged under Player 1 and - where it
+   *  is a valid action of a host-driven seat - applied. */
+  handleMessage(threadId: string, text: string, items?: { id: string; type: string }[]): Promise<TurnResult & { played: boolean; kind: 'chat' | 'control' | 'action' }>;
   /** items: the frontend's canvas items (AgentState.items), for clearCanvas's exemptList */
   continueRoom(threadId: string, items?: { id: string; type: string }[]): Promise<TurnResult>;
   /** Forget a thread and free its device memory; resolves false for an unknown thread. */

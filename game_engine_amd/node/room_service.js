@@ -14,6 +14,7 @@
  */
 const http = require('http');
 const { GameTable, RoomBatch, RoomLog, loadDslByGamename, turnToolCalls, uiToolCalls } = require('./index.js');
+const M = require('./messages.js');
 
 /** stable 48-bit room index from a thread id (the RNG is keyed by it) */
 function roomIndexOf(threadId) {
@@ -42,7 +43,8 @@ class RoomService {
                                   device: this.device, maxFuse: 1, trace: true });
     if (this.rooms.has(threadId)) this.close(threadId);
     const names = players.map((p, i) => p.name || `Player ${i + 1}`);
-    const room = { batch, table, gameName, names, state: batch.readRoom(0), log: new RoomLog(table, names, gameName), queue: Promise.resolve() };
+    const humanSeats = players.map((p, i) => (p.isBot === false ? i + 1 : 0)).filter((x) => x);
+    const room = { batch, table, gameName, names, humanSeats, panel: null, state: batch.readRoom(0), log: new RoomLog(table, names, gameName), queue: Promise.resolve() };
     this.rooms.set(threadId, room);
     return this.agentState(room);
   }
@@ -79,7 +81,40 @@ class RoomService {
     if (!room) return Promise.reject(new Error(`unknown thread ${threadId}`));
     return this._serial(room, () => this._continue(room, items));
   }
+  /**
+   * The drop-in's message-level entry: what the reference's graph does with ONE message of the browser
+   * (src/app/page.tsx:183-259 -> agent/game_agent_v2.py:198-349, agent/tools/utils.py:310-358; POLICY.md 3b).
+   *   chat ("... in game chat: ..." / "... to Bot k: ...")  -> ChatBotNode: no turn, no state change;
+   *   control ("Start game.", "Continue")                    -> one turn;
+   *   anything else -> logged verbatim under Player 1 (200 characters, phase 0's name - the reference's own quirk), read as a
+   *                    seat's action where it is one (a vote on the newest panel, an input for the statements phase), then one turn.
+   * Resolves { state, toolCalls, uiCalls, played, kind }; an action message that is no valid game action is still logged and
+   * still plays the turn, as in the reference.
+   */
+  handleMessage(threadId, text, items) {
+    const room = this.rooms.get(threadId);
+    if (!room) return Promise.reject(new Error(`unknown thread ${threadId}`));
+    return this._serial(room, async () => {
+      const kind = M.classify(text);
+      if (kind === M.CHAT) return { state: this.agentState(room), toolCalls: [], uiCalls: [], played: false, kind };
+      if (kind === M.ACTION) {
+        room.log.personMessage(text);
+        const st = room.state, info = room.table.info;
+        const phase = info.phases.find((x) => x.id === st.current_phase_id);
+        const alive = st.slots.map((v) => (st.pack === 1 ? !!v[2] : true));
+        for (const [seat, choice] of M.resolve(text, room.panel, phase ? phase.act : 0, st.pack, room.names, alive, room.humanSeats)) {
+          try { room.batch.injectAction(0, seat, choice); break; } catch (e) {
+            if (e.code !== 'GE-1') throw e;            // GE_ERR_ARG: not a living pending target of this phase - logged, no game effect
+          }
+        }
+      }
+      const out = await this._continue(room, items);
+      return Object.assign(out, { played: true, kind });
+    });
+  }
   async _continue(room, items) {
+    // `before` is the state BEFORE any injected action of this message: the person's record writes then show up among the
+    // turn's update_player_state calls, where the reference's Referee issues them
     const before = room.state;
     await room.batch.step(1);
     const after = room.batch.readRoom(0);
@@ -91,7 +126,9 @@ class RoomService {
     room.state = after;
     const state = this.agentState(room);
     const deaths = toolCalls.filter((c) => c.name === 'update_player_state' && c.args.state_name === 'is_alive' && c.args.state_value === false).map((c) => c.args.player_id);
-    return { state, toolCalls, uiCalls: uiToolCalls(room.table.dsl, state, { table: room.table, turn: event.turn, deaths, items }) };
+    const uiCalls = uiToolCalls(room.table.dsl, state, { table: room.table, turn: event.turn, deaths, items });
+    room.panel = M.newestPanel(uiCalls);               // what a person's next vote message can answer
+    return { state, toolCalls, uiCalls };
   }
   serve(port = 8124) {
     const server = http.createServer((req, res) => {
@@ -103,6 +140,7 @@ class RoomService {
           let out;
           if (req.method === 'POST' && req.url === '/rooms') out = this.createRoom(msg);
           else if (req.method === 'POST' && req.url === '/continue') out = await this.continueRoom(msg.threadId, msg.items);
+          else if (req.method === 'POST' && req.url === '/message') out = await this.handleMessage(msg.threadId, msg.text, msg.items);
           else if (req.method === 'POST' && req.url === '/action') out = await this.humanAction(msg.threadId, msg.playerId, msg.choice);
           else if (req.method === 'POST' && req.url === '/close') out = { closed: await this.close(msg.threadId) };
           else { res.writeHead(404); res.end(); return; }

@@ -13,8 +13,8 @@ from __future__ import annotations
 
 from typing import Any, Dict, List, Optional
 
-from .stepper import GameTable, RoomBatch, load_dsl_by_gamename, view_to_agent_state
-from .toolcalls import RoomLog, turn_tool_calls
+from .stepper import PACK_WEREWOLF, GeError, GameTable, RoomBatch, load_dsl_by_gamename, slot_values, view_to_agent_state
+from .toolcalls import WW_IS_ALIVE, RoomLog, turn_tool_calls
 from .ui_script import ui_tool_calls
 
 
@@ -46,16 +46,20 @@ class RoomService:
         room_index: the global room index the RNG is keyed by (default: derived from the thread id)."""
         tb = self.table(game_name, dsl)
         human_mask = sum(1 << i for i, p in enumerate(players) if p.get("isBot") is False)
-        batch = RoomBatch([(tb, len(players), 1, human_mask)], seed=self.seed,
-                          first_room=room_index_of(thread_id) if room_index is None else room_index,
-                          device=self.device, max_fuse=1, trace=True)
+        batch = self._new_batch(tb, len(players), human_mask, room_index_of(thread_id) if room_index is None else room_index)
         if thread_id in self._rooms:
             self.close(thread_id)
         names = [p.get("name") or f"Player {i + 1}" for i, p in enumerate(players)]
-        room = {"batch": batch, "table": tb, "gameName": game_name, "names": names,
+        room = {"batch": batch, "table": tb, "gameName": game_name, "names": names, "panel": None,
+                "human_seats": [i + 1 for i in range(len(players)) if (human_mask >> i) & 1],
                 "view": batch.read_rooms(0, 1)[0], "log": RoomLog(tb, names, game_name)}
         self._rooms[thread_id] = room
         return self._agent_state(room)
+
+    def _new_batch(self, tb: GameTable, n_players: int, human_mask: int, first_room: int) -> RoomBatch:
+        """The room's N=1 traced batch on the device (there is no other stepper: without the HIP library this raises)."""
+        return RoomBatch([(tb, n_players, 1, human_mask)], seed=self.seed, first_room=first_room,
+                         device=self.device, max_fuse=1, trace=True)
 
     def _agent_state(self, room: Dict[str, Any]) -> Dict[str, Any]:
         return room["log"].agent_state(room["view"])
@@ -71,7 +75,44 @@ class RoomService:
         """One turn (one graph run): {"state": AgentState, "toolCalls": [...], "uiCalls": [...]}.
         items: the frontend's canvas items (AgentState.items, [{id, type, ...}]) when the caller has them:
         clearCanvas then names the ids to keep (exemptList)."""
+        return self._turn(self._rooms[thread_id], items)
+
+    def handle_message(self, thread_id: str, text: str, items: Optional[List[Dict[str, Any]]] = None) -> Dict[str, Any]:
+        """The drop-in's message-level entry: what the reference's graph does with ONE message of the browser
+        (src/app/page.tsx:183-259 -> agent/game_agent_v2.py:198-349, agent/tools/utils.py:310-358; POLICY.md 3b).
+          chat ("... in game chat: ..." / "... to Bot k: ...")  -> ChatBotNode: no turn, no state change;
+          control ("Start game.", "Continue")                    -> one turn;
+          anything else -> logged verbatim under Player 1 (first 200 characters, phase 0's name - the reference's own quirk),
+                           read as a seat's action where it is one (a vote on the newest panel, an input for the
+                           statements phase: ge_batch_inject_action), then one turn.
+        Returns {"state", "toolCalls", "uiCalls", "played", "kind"}; an action message that is no valid game action is still
+        logged and still plays the turn, as in the reference."""
+        from . import messages as M
         room = self._rooms[thread_id]
+        kind = M.classify(text)
+        if kind == M.CHAT:
+            return {"state": self._agent_state(room), "toolCalls": [], "uiCalls": [], "played": False, "kind": kind}
+        if kind == M.ACTION:
+            room["log"].person_message(text)
+            view, tb = room["view"], room["table"]
+            n = int(view["n_players"])
+            pid = int(view["phase_id"])
+            act = next((r["act"] for r in tb.rows() if r["phase_id"] == pid), 0)
+            alive = [bool(slot_values(tb, view, i)[WW_IS_ALIVE]) for i in range(n)] if tb.pack == PACK_WEREWOLF else [True] * n
+            for seat, choice in M.resolve(text, room["panel"], act, tb.pack, room["names"], alive, room["human_seats"]):
+                try:
+                    room["batch"].inject_action(0, seat, choice)
+                    break
+                except GeError as e:                     # not a living pending target of this phase: logged, no game effect
+                    if e.status != -1:                 # GE_ERR_ARG
+                        raise
+        out = self._turn(room, items)
+        out.update(played=True, kind=kind)
+        return out
+
+    def _turn(self, room: Dict[str, Any], items: Optional[List[Dict[str, Any]]] = None) -> Dict[str, Any]:
+        # `before` is the view BEFORE any injected action of this message: the person's record writes (night target, vote
+        # choice, ...) then show up among the turn's update_player_state calls, where the reference's Referee issues them
         batch, before = room["batch"], room["view"]
         batch.step(1)
         after = batch.read_rooms(0, 1)[0]
@@ -83,6 +124,8 @@ class RoomService:
         deaths = [c["args"]["player_id"] for c in calls if c["name"] == "update_player_state"
                   and c["args"]["state_name"] == "is_alive" and c["args"]["state_value"] is False]
         ui = ui_tool_calls(room["table"].dsl, state, room["table"], turn=int(event["turn"]), deaths=deaths, items=items)
+        from .messages import newest_panel
+        room["panel"] = newest_panel(ui)                  # what a person's next vote message can answer
         return {"state": state, "toolCalls": calls, "uiCalls": ui}
 
     def close(self, thread_id: Optional[str] = None):

@@ -193,6 +193,23 @@ class RoomLog:
             entry["timestamp"] = datetime.datetime.now().isoformat()
         self.phase_history.append(entry)                      # one entry per turn, transition or not (v2:1207-1215)
 
+    def person_message(self, text: str, now_ms: Optional[int] = None) -> None:
+        """File a person's game message as process_human_action_if_needed does (agent/tools/utils.py:343-350): under Player 1
+        whoever sent it, the first 200 characters, and under PHASE 0's NAME whatever the current phase is - InitialRouterNode
+        passes `state.get("currentPhaseId", 0)` and `state.get("playerStates", {})`, keys the state does not have
+        (agent/game_agent_v2.py:324-331), so the phase id is always 0 and the name comes from roomSession.  Mirrored, not
+        corrected: the string layer is the reference's (POLICY.md 3b)."""
+        from .messages import logged_text
+        self.calls_fold_person(logged_text(text), self.table.phase_name(0), now_ms)
+
+    def calls_fold_person(self, action: str, phase: str, now_ms: Optional[int]) -> None:
+        import time
+        rec = self.player_actions.setdefault("1", {"name": self.names[0], "actions": {}})
+        aid = str(max((int(x["id"]) for x in rec["actions"].values()), default=0) + 1)
+        rec["name"] = self.names[0]
+        rec["actions"][aid] = {"action": action, "timestamp": int(time.time() * 1000) if now_ms is None else now_ms,
+                               "phase": phase, "id": aid}
+
     def agent_state(self, view) -> Dict[str, Any]:
         """AgentState of the room (v2:97-117) with the reference's key order inside player_states."""
         from .stepper import view_to_agent_state

@@ -120,27 +120,34 @@ def restart_cases():
 def human_cases():
     """Player 1 is host-driven (the reference's human): the bot policy skips it and a scripted
     person (oracle/human_script.py) acts for it."""
-    from ..human_script import HUMAN_MASK, scripted_human
+    from ..human_script import HUMAN_MASK, person
     for game, n, turns in (("werewolf-(mafia)", 8, 110), ("two-truths-and-a-lie", 4, 100), ("werewolf-(mafia)", 12, 140),
                            ("draft-werewolf-(mafia)", 8, 110)):
         cases = []
         for seed in SEEDS:
             room = 31
-            sess = {v: RoomSession(game, n, seed, room, v, human_mask=HUMAN_MASK, human_script=scripted_human) for v in ("v2", "v3")}
-            traj = []
+            sess = {v: RoomSession(game, n, seed, room, v, human_mask=HUMAN_MASK, human_script=person) for v in ("v2", "v3")}
+            traj, sent = [], 0
             for t in range(turns):
                 for s_ in sess.values():
                     s_.step()
+                assert sess["v2"].last_message == sess["v3"].last_message
+                sent += sess["v2"].last_message != "Continue"
                 pa = sess["v2"].project()
                 assert pa == sess["v3"].project()
                 traj.append(pa)
             assert traj[-1][3] >= 0, (game, n, seed, "did not finish")
+            # every message of the person went through the reference's own process_human_action_if_needed
+            filed = sess["v2"].state["playerActions"].get("1", {}).get("actions", {})
+            assert len(filed) == sent and all(a["phase"] == sess["v2"].table.by_id(0).name for a in filed.values())
             cases.append({"seed": seed, "room": room, "turns": traj})
-            print("human", game, n, hex(seed), "end", traj[-1][3], file=sys.stderr)
+            print("human", game, n, hex(seed), "end", traj[-1][3], "messages", sent, file=sys.stderr)
         name = f"human_{file_tag(game)}_n{n}.json"
         with open(os.path.join(GOLD, name), "w") as f:
             json.dump({"game": game, "n_players": n, "rounds": 1, "human_mask": HUMAN_MASK,
-                       "source": "reference v2 + v3 nodes under FixedPolicy with player 1 host-driven (oracle/human_script.py)",
+                       "source": "reference v2 + v3 nodes under FixedPolicy with player 1 host-driven: the scripted person "
+                                 "(oracle/human_script.py) sends the frontend's message strings, the reference's own "
+                                 "process_human_action_if_needed logs them, the policy reads the choice off that entry",
                        "cases": cases}, f, separators=(",", ":"))
 
 
@@ -229,9 +236,68 @@ def string_cases():
                        "cases": cases}, f, ensure_ascii=False, separators=(",", ":"))
 
 
+def _turn_record(st, seen_actions, n_notes, n_hist):
+    acts = []
+    for pid in sorted(st["playerActions"], key=int):
+        rec = st["playerActions"][pid]
+        for aid in sorted(rec["actions"], key=int):
+            if (pid, aid) not in seen_actions:
+                seen_actions[(pid, aid)] = True
+                a = rec["actions"][aid]
+                acts.append({"player_id": pid, "name": rec["name"], "id": a["id"], "action": a["action"], "phase": a["phase"]})
+    return {"current_phase_id": st["current_phase_id"], "current_phase_name": st.get("current_phase_name"),
+            "actions_added": acts, "notes_added": list(st["game_notes"][n_notes:]),
+            "history_added": _strip_ts(st["phase_history"][n_hist:]),
+            "player_states": _strip_ts(st["player_states"])}
+
+
+def string_human_cases():
+    """The string layer of rooms with a PERSON in them, message by message: what the browser sent (vote / input / button /
+    chat / control strings of src/app/page.tsx, oracle/human_script.py::talkative_person), whether a turn was played, and the
+    reference's AgentState after it - the person's log entries as the reference's own process_human_action_if_needed files
+    them (Player 1, phase 0's name, 200 characters).  What RoomService.handle_message must reproduce."""
+    from ..human_script import talkative_person
+    for game, n, picks in (("werewolf-(mafia)", 8, [(0xC0FFEE, 2, (1,)), (1, 6, (1,)), (0, 9, (1, 3))]),
+                           ("two-truths-and-a-lie", 4, [(0xC0FFEE, 0, (1,)), (1, 5, (1, 3))]),
+                           ("draft-werewolf-(mafia)", 8, [(0, 4, (1,))])):
+        cases = []
+        for seed, room, seats in picks:
+            mask = sum(1 << (k - 1) for k in seats)
+            names = [("Alice" if i == 0 else "Carol" if i == 2 else f"Bot {i + 1}") for i in range(n)]
+            s_ = RoomSession(game, n, seed, room, "v2", human_mask=mask, human_script=talkative_person(seats), names=names)
+            b_ = RoomSession(game, n, seed, room, "v3", human_mask=mask, human_script=talkative_person(seats), names=names)
+            msgs, n_notes, n_hist, seen = [], 0, 0, {}
+            while s_.end_turn < 0 or s_.turn < s_.end_turn + 3:
+                played = s_.step()
+                assert b_.step() == played and b_.last_message == s_.last_message and b_.project() == s_.project()
+                rec = _turn_record(s_.state, seen, n_notes, n_hist)
+                rec.update(message=s_.last_message, played=played)
+                if not played:
+                    assert not rec["actions_added"] and not rec["notes_added"] and not rec["history_added"]
+                msgs.append(rec)
+                n_notes, n_hist = len(s_.state["game_notes"]), len(s_.state["phase_history"])
+                assert len(msgs) < 600
+            cases.append({"seed": seed, "room": room, "human_seats": list(seats), "names": names, "messages": msgs,
+                          "final": {"playerActions": _strip_ts(s_.state["playerActions"]), "game_notes": s_.state["game_notes"],
+                                    "phase_history": _strip_ts(s_.state["phase_history"])}})
+            kinds = {}
+            for m in msgs:
+                k = m["message"].split(" ")[0]
+                kinds[k] = kinds.get(k, 0) + 1
+            print("strings_human", game, n, hex(seed), room, "messages", len(msgs), kinds, file=sys.stderr)
+        name = f"strings_human_{file_tag(game)}_n{n}.json"
+        with open(os.path.join(GOLD, name), "w", encoding="utf-8") as f:
+            json.dump({"game": game, "n_players": n, "rounds": 1,
+                       "source": "reference game_agent_v2 nodes (v3 asserted equal) under FixedPolicy with host-driven seats; the "
+                                 "person's messages are the frontend's strings, logged by the reference's own "
+                                 "process_human_action_if_needed; timestamps stripped",
+                       "cases": cases}, f, ensure_ascii=False, separators=(",", ":"))
+
+
 if __name__ == "__main__":
     main()
     restart_cases()
     human_cases()
     string_cases()
+    string_human_cases()
     variant_cases()

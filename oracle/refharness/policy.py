@@ -14,7 +14,16 @@ stateless (all are plain arguments of the reference's backend tools):
     informational: v3 drops game_notes from its update, v3:863-874, so nothing parses it)
 The harness (the runtime around the graph) supplies the clock: the turn index, the
 turn in which the current phase was entered and the phase it was entered from, all
-observable from `current_phase_id` between graph runs.
+observable from `current_phase_id` between graph runs - and, for every log entry that
+`process_human_action_if_needed` (agent/tools/utils.py:310-358) filed from a person's
+message, the turn of the graph run that filed it (`human_turns`; the reference stamps
+such an entry with wall-clock milliseconds only).
+
+A person's action is NOT a tool call of this policy: the walker sends the frontend's own
+message string (src/app/page.tsx:302-305 vote, :2843 input), the reference's
+InitialRouterNode logs it verbatim under Player 1 with phase 0's name (its state keys
+`currentPhaseId` / `playerStates` do not exist, v2:324-331), and the policy reads the
+person's choice back off that entry (`RoomView.person_entries`, POLICY.md 3b).
 
 This file runs only in the build container next to /root/reference; nothing here
 travels to the GPU box except the golden vectors it produces.
@@ -28,6 +37,9 @@ from .. import dsl_table as T
 from .. import rng
 
 _TAG = re.compile(r"^\[t=(\d+)\|c=(\d+)\] ")
+# the frontend's vote message (src/app/page.tsx:302-305) with this build's votingId scheme (POLICY.md 3b)
+_VOTE = re.compile(r'^Player ([0-9]+) voted "(.*)" in voting vote-p([0-9]+)-t([0-9]+)\Z', re.S)
+_INPUT = re.compile(r"^Input: ", re.S)          # src/app/page.tsx:2843
 
 
 def _pids(player_states: dict) -> List[str]:
@@ -37,8 +49,11 @@ def _pids(player_states: dict) -> List[str]:
 class RoomView:
     """Integer view of the dict state the reference shows its LLM."""
 
-    def __init__(self, table: T.Table, state: dict, t_enter: int = -1, prev_phase: int = 0):
+    def __init__(self, table: T.Table, state: dict, t_enter: int = -1, prev_phase: int = 0,
+                 human_mask: int = 0, human_turns: Optional[Dict[str, int]] = None):
         self.table = table
+        self.human_mask = human_mask              # host-driven seats (bit i: player i+1)
+        self.human_turns = human_turns or {}      # id of a person's entry in Player 1's log -> turn of the run that filed it
         self.ps: Dict[str, dict] = state.get("player_states", {}) or {}
         self.ids = _pids(self.ps)
         self.n = len(self.ids)
@@ -102,10 +117,73 @@ class RoomView:
         return self.mask(lambda i: self.alive(i) and (not ph.clauses or any(
             all(self.literal_true(i, l) for l in clause) for clause in ph.clauses)))
 
-    def visit_actions(self, ph: T.Phase, only_turn: Optional[int] = None, ever: bool = False) -> Dict[int, Tuple[int, int]]:
-        """player index -> (turn, choice) of the latest action in this visit of `ph`
-        (referee_system_prompt_1.txt:19: latest action matching the current phase name); `ever`: in any visit."""
-        out: Dict[int, Tuple[int, int]] = {}
+    # ---- what a voting panel of `ph` offers (POLICY.md 3b; the product's ui_script builds the same list)
+    def name_of(self, i: int) -> str:
+        return str(self.ps[self.ids[i]].get("name") or f"Player {self.ids[i]}")
+
+    def panel_options(self, ph: T.Phase) -> List[str]:
+        if self.table.pack != T.PACK_WEREWOLF:
+            return ["1", "2", "3"]
+        if ph.act == T.ACT_WOLF_TARGET:
+            keep = lambda i: self.alive(i) and not self.is_wolf_team(i)
+        elif ph.act == T.ACT_DETECTIVE:
+            keep = lambda i: self.alive(i) and self.role_class(i) != T.ROLE_DETECTIVE
+        else:
+            keep = self.alive
+        return [self.name_of(i) for i in range(self.n) if keep(i)]
+
+    def option_choice(self, option: str) -> int:
+        """1-based choice an option string stands for (a player's name -> the lowest id carrying it; a statement number), 0: none."""
+        if self.table.pack != T.PACK_WEREWOLF:
+            return int(option) if option in ("1", "2", "3") else 0
+        for i in range(self.n):
+            if self.name_of(i) == option:
+                return i + 1
+        return 0
+
+    def person_entries(self, ph: T.Phase, ever: bool = False):
+        """(seat index, turn, choice) of every message of a person that counts as an action of `ph` (POLICY.md 3b), in log order.
+        The reference files every such message under Player 1 with phase 0's name (utils.py:331-349 via v2:324-331), so the
+        phase is read from the votingId, the seat from the message, the turn from the runtime's clock (`human_turns`)."""
+        rec = self.actions.get("1") or {}
+        tgt = self.targets(ph) if not ever else 0
+        done = set()
+        for aid in sorted(rec.get("actions", {}), key=int):
+            text = rec["actions"][aid].get("action", "")
+            turn = self.human_turns.get(str(aid))
+            if turn is None or _TAG.match(text):
+                continue
+            if turn <= self.t_enter and not ever:
+                continue
+            m = _VOTE.match(text)
+            if m:
+                seat, option, p_id, p_turn = int(m.group(1)) - 1, m.group(2), int(m.group(3)), int(m.group(4))
+                if ph.act in (T.ACT_NONE, T.ACT_TT_STATEMENTS) or "createVotingPanel" not in ph.tools or \
+                        p_id != ph.id or p_turn + 1 != turn:
+                    continue                                  # not a panel of this phase / not the newest panel
+                if not (0 <= seat < self.n) or not (self.human_mask >> seat) & 1:
+                    continue
+                choice = self.option_choice(option)           # what ge_batch_inject_action accepts: a living player / 1..3
+                if choice and not ever and self.table.pack == T.PACK_WEREWOLF and not self.alive(choice - 1):
+                    continue
+            elif _INPUT.match(text) and ph.act == T.ACT_TT_STATEMENTS:
+                # a text panel carries no seat: the pending host-driven target with the lowest id
+                seats = [i for i in range(self.n) if (self.human_mask >> i) & 1 and (ever or ((tgt >> i) & 1 and i not in done))]
+                if not seats:
+                    continue
+                seat, choice = seats[0], 1
+            else:
+                continue
+            if not choice:
+                continue
+            if not ever:
+                if not (tgt >> seat) & 1 or seat in done:     # only a living target's first action of the visit counts
+                    continue
+                done.add(seat)
+            yield seat, turn, choice
+
+    def entries(self, ph: T.Phase, ever: bool = False):
+        """(player index, turn, choice) of every logged action of `ph` - bots' tagged entries and persons' messages."""
         for i, pid in enumerate(self.ids):
             rec = self.actions.get(pid)
             if not rec:
@@ -115,11 +193,21 @@ class RoomView:
                 m = _TAG.match(a.get("action", ""))
                 if not m or a.get("phase") != ph.name:
                     continue
-                turn, choice = int(m.group(1)), int(m.group(2))
+                turn = int(m.group(1))
                 if turn <= self.t_enter and not ever:
                     continue
-                if only_turn is not None and turn != only_turn:
-                    continue
+                yield i, turn, int(m.group(2))
+        if self.human_mask:
+            yield from self.person_entries(ph, ever)
+
+    def visit_actions(self, ph: T.Phase, only_turn: Optional[int] = None, ever: bool = False) -> Dict[int, Tuple[int, int]]:
+        """player index -> (turn, choice) of the latest action in this visit of `ph`
+        (referee_system_prompt_1.txt:19: latest action matching the current phase name); `ever`: in any visit."""
+        out: Dict[int, Tuple[int, int]] = {}
+        for i, turn, choice in self.entries(ph, ever):
+            if only_turn is not None and turn != only_turn:
+                continue
+            if i not in out or turn >= out[i][0]:
                 out[i] = (turn, choice)
         return out
 
@@ -132,15 +220,12 @@ class RoomView:
             for ph in self.table.phases:
                 if ph.act != T.ACT_DETECTIVE:
                     continue
-                for rec in self.actions.values():
-                    for a in (rec.get("actions") or {}).values():
-                        m = _TAG.match(a.get("action", ""))
-                        if m and a.get("phase") == ph.name:
-                            c = int(m.group(2)) - 1
-                            if self.get(c, "team", "") == "werewolves":
-                                kw |= 1 << c
-                            else:
-                                kv |= 1 << c
+                for _i, _turn, choice in self.entries(ph, ever=True):
+                    c = choice - 1
+                    if self.get(c, "team", "") == "werewolves":
+                        kw |= 1 << c
+                    else:
+                        kv |= 1 << c
             return kv, kw
         for i in range(self.n):
             mem = self.get(i, "investigated_alignments", {}) or {}
@@ -171,7 +256,7 @@ class FixedPolicy:
         self.table = table
         self.rkey = rng.room_key(seed, room)
         self.human_mask = human_mask      # players the bot policy never acts for (player 1 = the human)
-        self.human = human                # callable(turn, view) -> (player_id, choice) | None: the scripted person
+        self.human_turns: Dict[str, int] = {}   # runtime clock: id of a person's entry in Player 1's log -> turn that filed it
         self.game = 0            # index of this room's game on its slot (steady-state chains; else 0)
         # clock, set by the walker before each graph run
         self.turn = 0
@@ -179,7 +264,7 @@ class FixedPolicy:
         self.prev_phase = 0
 
     def _view(self, state: dict) -> RoomView:
-        return RoomView(self.table, state, self.t_enter, self.prev_phase)
+        return RoomView(self.table, state, self.t_enter, self.prev_phase, self.human_mask, self.human_turns)
 
     # ------------------------------------------------------------------ bots
     def bot_actions(self, state: dict, p_id: int) -> List[dict]:
@@ -196,15 +281,6 @@ class FixedPolicy:
         wolfteam = v.mask(v.is_wolf_team)
         kv, kw = v.known() if tb.pack == T.PACK_WEREWOLF else (0, 0)
         calls = []
-        if self.human is not None:
-            # the person's action, logged at the start of this graph run (utils.py:310-358 does it in
-            # InitialRouterNode from the chat message; same tool, same effect)
-            act = self.human(t, v)
-            if act:
-                hp, hc = act
-                calls.append({"name": "update_player_actions",
-                              "args": {"player_id": str(hp), "actions": f"[t={t}|c={hc}] (human) chose {hc}",
-                                       "phase": ph.name}})
         for i in range(v.n):
             if not (tgt >> i) & 1 or i in acted or (self.human_mask >> i) & 1:
                 continue
@@ -454,6 +530,16 @@ class FixedPolicy:
 
     # -------------------------------------------------------------- executor
     def ui_calls(self, state: dict, q_id: int) -> List[dict]:
-        """ActionExecutor / UIUpdateNode's LLM: the phase's DSL tool list, verbatim
-        (ww:171-184 etc.).  Frontend only; no game state depends on it."""
-        return [{"name": tname, "args": {}} for tname in self.table.by_id(q_id).tools]
+        """ActionExecutor / UIUpdateNode's LLM: the phase's DSL tool list, verbatim (ww:171-184 etc.).  Frontend only; no
+        game state depends on it - but a person answers a createVotingPanel by its votingId and one of its options
+        (src/app/page.tsx:302-305), so those two arguments are scripted (POLICY.md 3b); the others stay with the product's
+        ui_script (the reference leaves them to the LLM)."""
+        ph = self.table.by_id(q_id)
+        v = self._view(state)
+        calls = []
+        for tname in ph.tools:
+            args: Dict[str, Any] = {}
+            if tname == "createVotingPanel":
+                args = {"votingId": f"vote-p{q_id}-t{self.turn}", "options": v.panel_options(ph)}
+            calls.append({"name": tname, "args": args})
+        return calls

@@ -89,7 +89,9 @@ class RoomSession:
 
     def __init__(self, game: str, n_players: int, seed: int, room: int = 0,
                  version: str = "v2", rounds: int = 1, turn0: int = 0, human_mask: int = 0, human_script=None, game_index: int = 0,
-                 dsl_variant=None):
+                 dsl_variant=None, names=None):
+        """human_mask: host-driven seats (roomSession isBot: false).  human_script(session) -> the message a person sends to
+        start the next graph run (None: the "Continue" button), see oracle/human_script.py.  names: roomSession player names."""
         from .. import dsl_table
         from .policy import FixedPolicy
         import yaml
@@ -109,11 +111,10 @@ class RoomSession:
             # that is already in the state instead of loading the game's file (v2:254-262)
             dsl = dsl_variant(dsl)
         self.table = dsl_table.compile_dsl(dsl, rounds=rounds)
-        human = None
-        if human_script is not None:
-            def human(turn, view, _s=self):          # the script sees the canonical projection, like the tests do
-                return human_script(_s.table, turn, _s.project(), n_players)
-        self.policy = FixedPolicy(self.table, seed, room, human_mask, human)
+        self.human_script, self.human_mask, self.n_players = human_script, human_mask, n_players
+        self.last_panel = None         # (votingId, options) of the newest createVotingPanel call, what a person answers
+        self.last_message = None       # what started the latest graph run
+        self.policy = FixedPolicy(self.table, seed, room, human_mask)
         self.policy.game = min(game_index, 0xFFFF)
         self.turn = turn0              # the clock may start late: a new room on a recycled slot
         self.t_enter, self.prev_phase, self.end_turn = turn0 - 1, 0, -1
@@ -124,13 +125,15 @@ class RoomSession:
             "current_phase_id": 0, "player_states": {}, "playerActions": {},
             "phase_history": [], "game_notes": [], "dsl": (dsl if dsl_variant is not None else {}),
             "roomSession": {"players": [
-                {"name": f"Bot {i + 1}", "gamePlayerId": i + 1, "isBot": True} for i in range(n_players)]},
+                {"name": (names[i] if names else f"Bot {i + 1}"), "gamePlayerId": i + 1, "isBot": not (human_mask >> i) & 1}
+                for i in range(n_players)]},
         }
         self._p_at_turn_start = 0
 
     # ---- the stub LLM's dispatch: which node is asking is told by the bound tools
     def answer(self, tool_names) -> List[dict]:
         st, pol = self.state_in_node, self.policy
+        self._stamp_person_entries()
         cur = st.get("current_phase_id", 0)
         if tool_names == {"update_player_actions"}:
             return pol.bot_actions(st, cur)
@@ -168,19 +171,52 @@ class RoomSession:
                     self.state[k] = v
             node = cmd.goto
 
-    def step(self):
-        """One turn: the browser's "Continue" message (src/app/page.tsx:2962) -> one graph run,
-        then the browser answers every frontend tool call with a ToolMessage."""
+    def _stamp_person_entries(self):
+        """The runtime's clock for what process_human_action_if_needed filed (utils.py:343-350: Player 1's log, wall-clock
+        stamp only): the turn of the graph run in which the entry appeared."""
+        rec = (self.state.get("playerActions") or {}).get("1") or {}
+        for aid, a in (rec.get("actions") or {}).items():
+            if str(aid) not in self.policy.human_turns and not str(a.get("action", "")).startswith("[t="):
+                self.policy.human_turns[str(aid)] = self.turn
+
+    @staticmethod
+    def is_chat(message: str) -> bool:
+        """InitialRouterNode's own test (v2:305-311, case-sensitive): such a message goes to ChatBotNode, no turn is played."""
+        return "in game chat:" in message or "to Bot" in message
+
+    def step(self, message=None):
+        """One message of the browser -> one graph run, then the browser answers every frontend tool call with a ToolMessage.
+        Default: what the scripted person sends (human_script), else the "Continue" button (src/app/page.tsx:2962).  A game
+        message (vote page.tsx:302-305, button :272-275, input :2843) is logged by the reference's own
+        process_human_action_if_needed (utils.py:310-358) inside InitialRouterNode; a chat message (page.tsx:341-349) is routed
+        to ChatBotNode and plays no turn (the room's clock stands still).  Returns True when a turn was played."""
         from langchain_core.messages import HumanMessage, ToolMessage, AIMessage
+        if message is None and self.human_script is not None:
+            message = self.human_script(self)
+        if message is None:
+            message = "Continue"
+        self.last_message = message
         self.policy.turn = self.turn
         self.policy.t_enter, self.policy.prev_phase = self.t_enter, self.prev_phase
         self._p_at_turn_start = p0 = self.state.get("current_phase_id", 0)
-        self.state["messages"].append(HumanMessage(content="Continue"))
+        self.state["messages"].append(HumanMessage(content=message))
         self.node_path = []
+        if self.is_chat(message):
+            try:
+                asyncio.run(self._run_graph())
+            except FileNotFoundError:
+                # v3's ChatBotNode asks for prompt/chat_system_prompt.txt (game_agent_v3.py:407), a file the reference does
+                # not ship (v2 reads chatbot_system_prompt.txt): that run fails and leaves the thread as it was
+                assert self.version == "v3"
+            assert self.node_path == ["InitialRouterNode", "ChatBotNode"], self.node_path
+            return False
         asyncio.run(self._run_graph())
+        self._stamp_person_entries()
         last = self.state["messages"][-1] if self.state["messages"] else None
         if isinstance(last, AIMessage):
             for tc in last.tool_calls:
+                if tc["name"] == "createVotingPanel":
+                    self.last_panel = (tc["args"]["votingId"], list(tc["args"]["options"]))
                 self.state["messages"].append(ToolMessage(content="ok", tool_call_id=tc["id"]))
         self.state["messages"] = self.state["messages"][-40:]
         q = self.state.get("current_phase_id", 0)
@@ -189,13 +225,31 @@ class RoomSession:
             if not self.table.by_id(q).branches and self.end_turn < 0:
                 self.end_turn = self.turn
         self.turn += 1
+        return True
+
+    def vote_message(self, player: int, choice: int) -> str:
+        """What the browser of seat `player` sends when it picks `choice` (a player id / a statement number) on the newest
+        panel: `Player <id> voted "<option>" in voting <votingId>` (page.tsx:302-305); the statements phase has a text panel
+        instead: `Input: <text>` (page.tsx:2843)."""
+        from .. import dsl_table as T
+        ph = self.table.by_id(self.state.get("current_phase_id", 0))
+        if ph.act == T.ACT_TT_STATEMENTS:
+            return "Input: " + "; ".join(f"Statement {s} of Player {player}" for s in (1, 2, 3))
+        voting_id = self.last_panel[0] if self.last_panel else "vote-none"
+        if self.table.pack == T.PACK_WEREWOLF:
+            ps = self.state["player_states"]
+            option = str(ps[str(choice)].get("name") or f"Player {choice}")
+        else:
+            option = str(choice)
+        return f'Player {player} voted "{option}" in voting {voting_id}'
 
     # ---- canonical projection (ints only; no strings, timestamps, versions)
     def project(self) -> List[int]:
-        return project_state(self.table, self.state, self.t_enter, self.prev_phase, self.end_turn)
+        return project_state(self.table, self.state, self.t_enter, self.prev_phase, self.end_turn,
+                             self.human_mask, self.policy.human_turns)
 
 
-def project_state(table, state: dict, t_enter: int, prev_phase: int, end_turn: int) -> List[int]:
+def project_state(table, state: dict, t_enter: int, prev_phase: int, end_turn: int, human_mask: int = 0, human_turns=None) -> List[int]:
     """[phase, prev_phase, phase0_done, end_turn] + per player 11 ints (+ detective memory, ww).
 
     Layout (also produced by oracle.py and the product's read_rooms):
@@ -205,7 +259,7 @@ def project_state(table, state: dict, t_enter: int, prev_phase: int, end_turn: i
     """
     from .. import dsl_table as T
     from .policy import RoomView
-    v = RoomView(table, state, t_enter, prev_phase)
+    v = RoomView(table, state, t_enter, prev_phase, human_mask, human_turns)
     cur = int(state.get("current_phase_id", 0))
     ph = table.by_id(cur)
     hist = state.get("phase_history", []) or []
