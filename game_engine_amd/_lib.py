@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GE_LIB_PATH") or os.path.join(_HERE, "libge_step.so")
 
 GE_MAX_PHASES, GE_MAX_SEGMENTS, GE_NAME_LEN, GE_MAX_SLOTS = 32, 4, 64, 12
-GE_ABI_VERSION = 4
+GE_ABI_VERSION = 5
 
 
 class Literal(C.Structure):
@@ -58,7 +58,7 @@ SUMMARY_WORDS = C.sizeof(Summary) // 8
 SYMBOLS = ["ge_table_compile_json", "ge_batch_create", "ge_batch_step", "ge_batch_reset", "ge_batch_set_turn", "ge_batch_inject_actions", "ge_batch_sync", "ge_batch_turn",
            "ge_batch_n_rooms", "ge_batch_read_rooms", "ge_batch_write_rooms", "ge_batch_read_events", "ge_batch_inject_action", "ge_batch_summary",
            "ge_batch_state", "ge_batch_set_timing", "ge_batch_kernel_time", "ge_batch_destroy",
-           "ge_group_create", "ge_group_size", "ge_group_shard", "ge_group_step", "ge_group_sync", "ge_group_summary", "ge_group_destroy",
+           "ge_group_partition", "ge_batch_create_shard", "ge_group_create", "ge_group_size", "ge_group_shard", "ge_group_step", "ge_group_sync", "ge_group_summary", "ge_group_destroy",
            "ge_strerror", "ge_last_hip_error", "ge_last_comm_error", "ge_abi_version", "ge_device_count"]
 
 _lib = None
@@ -128,5 +128,8 @@ def load() -> C.CDLL:
         lib.ge_group_summary.argtypes = [vp, C.POINTER(Summary)]
         lib.ge_group_destroy.argtypes = [vp]
         lib.ge_group_destroy.restype = None
+    if hasattr(lib, "ge_group_partition") or not any_abi:
+        lib.ge_group_partition.argtypes = [C.POINTER(BatchDesc), C.c_int, C.c_int, C.POINTER(BatchDesc), C.POINTER(u64)]
+        lib.ge_batch_create_shard.argtypes = [C.POINTER(BatchDesc), C.POINTER(u64), C.POINTER(vp)]
     _lib = lib
     return lib

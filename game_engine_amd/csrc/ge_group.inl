@@ -139,19 +139,14 @@ static int group_create_impl(const ge_batch_desc *desc, const int *devices, int 
     g->send.assign((size_t)n, nullptr);
     g->recv.assign((size_t)n, nullptr);
     int st = GE_OK;
-    // segment k's rooms in global order: [first_room + sum of earlier segments ...); device i takes the i-th of n
-    // contiguous parts of each, so every room keeps the global index (hence the RNG stream) it has in one batch of `desc`
-    uint64_t seg_global[GE_MAX_SEGMENTS], acc = desc->first_room;
-    for (uint32_t k = 0; k < desc->n_segments; k++) { seg_global[k] = acc; acc += desc->seg[k].n_rooms; }
+    // device i takes the i-th of n contiguous parts of each segment; every room keeps the global index (hence the RNG stream)
+    // it has in one batch of `desc` (ge_host.h group_partition: the same arithmetic a host gets from ge_group_partition)
     for (int i = 0; i < n && st == GE_OK; i++) {
-        ge_batch_desc d = *desc;
-        d.device = devices[i];
+        ge_batch_desc d;
         uint64_t first[GE_MAX_SEGMENTS];
-        for (uint32_t k = 0; k < desc->n_segments; k++) {
-            const uint64_t R = desc->seg[k].n_rooms, lo = R * (uint64_t)i / (uint64_t)n, hi = R * (uint64_t)(i + 1) / (uint64_t)n;
-            d.seg[k].n_rooms = hi - lo;
-            first[k] = seg_global[k] + lo;
-        }
+        st = group_partition(*desc, n, i, &d, first);
+        if (st != GE_OK) break;
+        d.device = devices[i];
         st = create_impl(&d, &g->shards[(size_t)i], first);
         if (st != GE_OK) break;
         DeviceGuard dg(devices[i]);
@@ -206,6 +201,16 @@ extern "C" {
 
 int ge_group_create(const ge_batch_desc *desc, const int *devices, int n_devices, ge_group **out) {
     return guarded([&] { return group_create_impl(desc, devices, n_devices, out); });
+}
+
+int ge_group_partition(const ge_batch_desc *desc, int n_parts, int part, ge_batch_desc *shard, uint64_t *seg_first) {
+    if (!desc) return GE_ERR_ARG;
+    return group_partition(*desc, n_parts, part, shard, seg_first);
+}
+
+int ge_batch_create_shard(const ge_batch_desc *shard, const uint64_t *seg_first, ge_batch **out) {
+    if (!seg_first) return GE_ERR_ARG;
+    return guarded([&] { return create_impl(shard, out, seg_first); });
 }
 
 int ge_group_size(const ge_group *g) { return g ? (int)g->shards.size() : GE_ERR_ARG; }

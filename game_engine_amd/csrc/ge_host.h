@@ -373,4 +373,30 @@ inline bool view_fits(const ge_room_view &v, const ge_game_table &tb, uint32_t n
     return ok;
 }
 
+
+// The sharding of a device group (ge_group_create) and of any host that splits a job by hand: part i of n takes the i-th of n
+// contiguous parts of EVERY segment of `desc` (the whole job), and seg_first[k] is the GLOBAL index of that part's first room of
+// segment k - the index the room has in one batch of `desc`, which is what the RNG is keyed by (POLICY.md 2), so results do not
+// depend on n.  Rooms never interact in the reference (one LangGraph thread each, src/app/api/copilotkit/route.ts:24-37), so
+// this arithmetic is all there is to multi-GPU stepping.  HIP-free: also built with g++ under ASan + UBSan (tests/native).
+inline int group_partition(const ge_batch_desc &desc, int n, int i, ge_batch_desc *shard, uint64_t *seg_first) {
+    if (n < 1 || i < 0 || i >= n || !shard || !seg_first || desc.n_segments == 0 || desc.n_segments > GE_MAX_SEGMENTS) return GE_ERR_ARG;
+    uint64_t acc = desc.first_room;
+    ge_batch_desc d = desc;
+    for (uint32_t k = 0; k < desc.n_segments; k++) {
+        const uint64_t R = desc.seg[k].n_rooms;
+        if (R < (uint64_t)n) return GE_ERR_ARG;                       // every part holds rooms of every segment
+        // R * i can pass 2^64 for absurd R only (R < 2^57 at n <= 64 is safe); split the product to stay exact anyway
+        const uint64_t q = R / (uint64_t)n, r = R % (uint64_t)n;
+        const uint64_t lo = q * (uint64_t)i + r * (uint64_t)i / (uint64_t)n;
+        const uint64_t hi = q * (uint64_t)(i + 1) + r * (uint64_t)(i + 1) / (uint64_t)n;
+        d.seg[k].n_rooms = hi - lo;
+        seg_first[k] = acc + lo;
+        acc += R;
+    }
+    for (uint32_t k = desc.n_segments; k < GE_MAX_SEGMENTS; k++) seg_first[k] = 0;
+    *shard = d;
+    return GE_OK;
+}
+
 }  // namespace ge

@@ -93,7 +93,7 @@ export class DeviceGroup {
   summary(): Summary;
   /** room = index in segment-major order, as in one RoomBatch of the same segments */
   readRoom(room: number): RoomState;
-  locate(room: number): [number, number, GameTable];
+  locate(room: number): [number, number, GameTable];   // via locateInShards
   close(): void;
 }
 export function turnToolCalls(table: GameTable, before: RoomState, after: RoomState, event: TurnEvent): ToolCall[];
@@ -120,3 +120,5 @@ export interface FrontendToolCall { name: string; args: { audience_type?: boolea
 export function uiToolCalls(dsl: object, room: RoomState, opts?: { table?: GameTable; act?: number; turn?: number; deaths?: string[];
   items?: { id: string; type: string }[] }): FrontendToolCall[];
 export function validateCall(call: FrontendToolCall): string[];
+/** [part, index inside the part's batch, segment] of a room of the whole job after the group's sharding (ge_group_partition). */
+export function locateInShards(segmentRooms: number[], nParts: number, room: number): [number, number, number];

@@ -428,6 +428,30 @@ function decodeSummary(buffer) {
  * run time; there is none in the host).  ShardedBatch above is the host-side form of the same thing (its summary is a
  * host sum): it also runs with several shards on ONE device, which RCCL refuses, and serves as the cross-check.
  */
+/**
+ * Where a room of the WHOLE job lives after the device group's sharding (ge_group_partition, csrc/ge_host.h group_partition:
+ * part i of n holds rooms [floor(R i / n), floor(R (i + 1) / n)) of every segment of R rooms, segment by segment):
+ * [part, index inside that part's batch, segment] for `room` counted segment-major as in one RoomBatch.
+ */
+function locateInShards(segmentRooms, n, room) {
+  let base = 0;
+  for (let k = 0; k < segmentRooms.length; k++) {
+    const R = segmentRooms[k];
+    if (room < base + R) {
+      const r = room - base;
+      const part = (j, Rj) => Number(BigInt(Rj) * BigInt(j) / BigInt(n));     // exact floor, whatever the room count
+      let i = Math.min(n - 1, Math.floor((r + 1) * n / R));
+      while (i > 0 && part(i, R) > r) i--;
+      while (part(i + 1, R) <= r) i++;
+      let local = r - part(i, R);                          // rooms of the earlier segments on this part come first
+      for (let j = 0; j < k; j++) local += part(i + 1, segmentRooms[j]) - part(i, segmentRooms[j]);
+      return [i, local, k];
+    }
+    base += R;
+  }
+  throw new RangeError(`room ${room}`);
+}
+
 class DeviceGroup {
   constructor({ segments, devices, seed = 0n, firstRoom = 0n, maxFuse = 0, restart = false, trace = false }) {
     if (!devices || !devices.length) throw new RangeError('devices');
@@ -455,24 +479,8 @@ class DeviceGroup {
   summary() { return decodeSummary(addon.groupSummary(this.handle)); }
   /** [shard, local index, table] of a room given by its index in segment-major order (the order of one RoomBatch) */
   locate(room) {
-    const n = this.devices.length;
-    let base = 0;
-    for (let k = 0; k < this.segments.length; k++) {
-      const R = this.segments[k].nRooms;
-      if (room < base + R) {
-        const r = room - base;
-        for (let i = 0; i < n; i++) {
-          const lo = Math.floor(R * i / n), hi = Math.floor(R * (i + 1) / n);
-          if (r >= lo && r < hi) {
-            let local = r - lo;                          // rooms of the earlier segments on this device come first
-            for (let j = 0; j < k; j++) { const Rj = this.segments[j].nRooms; local += Math.floor(Rj * (i + 1) / n) - Math.floor(Rj * i / n); }
-            return [i, local, this.segments[k].table];
-          }
-        }
-      }
-      base += R;
-    }
-    throw new RangeError(`room ${room}`);
+    const [i, local, k] = locateInShards(this.segments.map((s) => s.nRooms), this.devices.length, room);
+    return [i, local, this.segments[k].table];
   }
   readRoom(room) {
     const [shard, local, table] = this.locate(room);
@@ -483,5 +491,5 @@ class DeviceGroup {
 
 const { compileCriteria, audienceGroups, uiToolCalls } = require('./ui_script.js');
 
-module.exports = { GameTable, RoomBatch, ShardedBatch, DeviceGroup, RoomLog, formatNote, loadDslByGamename, findGameFile, initializePlayers, turnToolCalls, compileCriteria, audienceGroups, uiToolCalls,
+module.exports = { GameTable, RoomBatch, ShardedBatch, DeviceGroup, locateInShards, RoomLog, formatNote, loadDslByGamename, findGameFile, initializePlayers, turnToolCalls, compileCriteria, audienceGroups, uiToolCalls,
                    deviceCount: addon.deviceCount, addon };

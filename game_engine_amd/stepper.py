@@ -336,14 +336,7 @@ class RoomGroup:
         if not 1 <= len(segments) <= _lib.GE_MAX_SEGMENTS:
             raise GeError(-1, "segments")
         self.segments = list(segments)
-        d = _lib.BatchDesc()
-        d.seed, d.first_room, d.n_segments, d.device, d.max_fuse = seed, first_room, len(segments), 0, max_fuse
-        d.flags = (1 if restart else 0) | (2 if trace else 0)
-        for k, seg in enumerate(segments):
-            tb, n_players, n_rooms = seg[:3]
-            d.seg[k].table = C.pointer(tb.c)
-            d.seg[k].n_players, d.seg[k].n_rooms = n_players, n_rooms
-            d.seg[k].human_mask = seg[3] if len(seg) > 3 else 0
+        d = self._desc = _job_desc(segments, seed, first_room, max_fuse, restart, trace)
         devs = (C.c_int * len(devices))(*devices)
         h = C.c_void_p()
         _check(lib.ge_group_create(C.byref(d), devs, len(devices), C.byref(h)), "ge_group_create")
@@ -387,19 +380,123 @@ class RoomGroup:
 
     def read_rooms(self) -> np.ndarray:
         """All rooms in the order of one RoomBatch with the same segments (segment-major)."""
-        per_seg: List[List[np.ndarray]] = [[] for _ in self.segments]
+        shards = []
         for i in range(self.n_devices):
             b = C.c_void_p()
             _check(self._lib.ge_group_shard(self._h, i, C.byref(b)), "ge_group_shard")
-            first = 0
-            for k, seg in enumerate(self.segments):
-                R = seg[2]
-                cnt = R * (i + 1) // self.n_devices - R * i // self.n_devices
-                out = np.empty(cnt, dtype=ROOM_VIEW_DTYPE)          # the library writes every byte of every view
-                _check(self._lib.ge_batch_read_rooms(b, first, cnt, out.ctypes.data, out.nbytes), "ge_batch_read_rooms")
-                per_seg[k].append(out)
-                first += cnt
-        return np.concatenate([x for seg in per_seg for x in seg])
+            shards.append(b)
+        return reassemble_rooms(self._lib, shards, self._desc)
+
+
+def _job_desc(segments: Sequence[Segment], seed: int, first_room: int, max_fuse: int, restart: bool, trace: bool) -> "_lib.BatchDesc":
+    d = _lib.BatchDesc()
+    d.seed, d.first_room, d.n_segments, d.device, d.max_fuse = seed, first_room, len(segments), 0, max_fuse
+    d.flags = (1 if restart else 0) | (2 if trace else 0)
+    for k, seg in enumerate(segments):
+        tb, n_players, n_rooms = seg[:3]
+        d.seg[k].table = C.pointer(tb.c)
+        d.seg[k].n_players, d.seg[k].n_rooms = n_players, n_rooms
+        d.seg[k].human_mask = seg[3] if len(seg) > 3 else 0
+    return d
+
+
+def partition(desc: "_lib.BatchDesc", n_parts: int, part: int):
+    """(shard desc, [global index of the part's first room of each segment]) - ge_group_partition, the arithmetic
+    ge_group_create shards a job with: the part-th of n_parts contiguous parts of every segment.  No device is touched."""
+    lib = _lib.load()
+    shard = _lib.BatchDesc()
+    first = (C.c_uint64 * _lib.GE_MAX_SEGMENTS)()
+    _check(lib.ge_group_partition(C.byref(desc), n_parts, part, C.byref(shard), first), "ge_group_partition")
+    return shard, [int(first[k]) for k in range(desc.n_segments)]
+
+
+def reassemble_rooms(lib, shard_handles, desc: "_lib.BatchDesc") -> np.ndarray:
+    """Every room of a sharded job in the order of ONE batch of `desc` (segment-major): shard i holds, segment by segment,
+    the i-th part of each; read each part and put segment k's parts side by side.  Used by RoomGroup (devices of a node)
+    and RoomShards (shards placed by the host)."""
+    n = len(shard_handles)
+    per_seg: List[List[np.ndarray]] = [[] for _ in range(desc.n_segments)]
+    for i, b in enumerate(shard_handles):
+        sd, _ = partition(desc, n, i)
+        first = 0
+        for k in range(desc.n_segments):
+            cnt = int(sd.seg[k].n_rooms)
+            out = np.empty(cnt, dtype=ROOM_VIEW_DTYPE)          # the library writes every byte of every view
+            _check(lib.ge_batch_read_rooms(b, first, cnt, out.ctypes.data, out.nbytes), "ge_batch_read_rooms")
+            per_seg[k].append(out)
+            first += cnt
+    return np.concatenate([x for seg in per_seg for x in seg])
+
+
+class RoomShards:
+    """The same sharding as RoomGroup, with the shards placed by the host: `devices[i]` is where part i of len(devices) lives -
+    devices may repeat (several shards on one GPU) and no collective library is involved; summary() adds the shards' own
+    summaries on the host (every field is a sum over rooms).  For hosts that schedule shards themselves, and the way the n > 1
+    partition is exercised on a one-GPU box (tests/test_gpu_group.py)."""
+
+    def __init__(self, segments: Sequence[Segment], devices: Sequence[int], seed: int = 0, first_room: int = 0,
+                 max_fuse: int = 0, restart: bool = False, trace: bool = False):
+        lib = _lib.load()
+        if not 1 <= len(segments) <= _lib.GE_MAX_SEGMENTS:
+            raise GeError(-1, "segments")
+        self.segments, self._lib = list(segments), lib
+        self._desc = _job_desc(segments, seed, first_room, max_fuse, restart, trace)
+        self._h: List[C.c_void_p] = []
+        self.firsts: List[List[int]] = []
+        for i, dev in enumerate(devices):
+            sd, first = partition(self._desc, len(devices), i)
+            sd.device = dev
+            h = C.c_void_p()
+            arr = (C.c_uint64 * _lib.GE_MAX_SEGMENTS)(*(first + [0] * (_lib.GE_MAX_SEGMENTS - len(first))))
+            st = lib.ge_batch_create_shard(C.byref(sd), arr, C.byref(h))
+            if st != 0:
+                self.close()
+                _check(st, "ge_batch_create_shard")
+            self._h.append(h)
+            self.firsts.append(first)
+        self.n_rooms = sum(s[2] for s in segments)
+
+    def close(self):
+        for h in getattr(self, "_h", []):
+            self._lib.ge_batch_destroy(h)
+        self._h = []
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def step(self, n_turns: int = 1):
+        for h in self._h:                                  # asynchronous: shards on different devices step concurrently
+            _check(self._lib.ge_batch_step(h, n_turns, None), "ge_batch_step")
+
+    def shard_summaries(self) -> List[Dict[str, Any]]:
+        out = []
+        for h in self._h:
+            s = _lib.Summary()
+            _check(self._lib.ge_batch_summary(h, C.byref(s)), "ge_batch_summary")
+            out.append(summary_to_dict(np.frombuffer(bytes(s), dtype="<u8")))
+        return out
+
+    def summary(self) -> Dict[str, Any]:
+        return sum_summaries(self.shard_summaries())
+
+    def read_rooms(self) -> np.ndarray:
+        return reassemble_rooms(self._lib, self._h, self._desc)
+
+
+def sum_summaries(parts: List[Dict[str, Any]]) -> Dict[str, Any]:
+    """Whole-job summary from the shards' (what the all-gather + sum of ge_group_summary computes): sums mod 2^64; `turn` is common."""
+    out: Dict[str, Any] = {}
+    for k, v in parts[0].items():
+        if isinstance(v, list):
+            out[k] = [sum(p[k][j] for p in parts) & 0xFFFFFFFFFFFFFFFF for j in range(len(v))]
+        else:
+            out[k] = v if k == "turn" else sum(p[k] for p in parts) & 0xFFFFFFFFFFFFFFFF
+    return out
 
 
 def summary_to_dict(w: np.ndarray) -> Dict[str, Any]:

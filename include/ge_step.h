@@ -31,7 +31,14 @@
 extern "C" {
 #endif
 
-#define GE_ABI_VERSION 4
+/* ABI history (a host checks ge_abi_version() == GE_ABI_VERSION; a ge_game_table carries the version it was compiled by):
+ *   2  stream ordering, device-side reset, batched injection     3  ge_game_table.field_names (schema binding)
+ *   4  device group (ge_group_*, GE_ERR_COMM); ge_batch_write_rooms became all-or-nothing and REFUSES (GE_ERR_ARG) a view whose
+ *      `pack` / player count is not the segment's or whose phase ids name no row of its table (until then unknown ids were
+ *      silently stored as row 0) - a caller that zero-initialises views must set `pack`
+ *   5  ge_group_partition + ge_batch_create_shard (the group's sharding arithmetic for hosts that place shards themselves);
+ *      mixed and generic batches get single-turn kernel builds; the Werewolf x 12 deal side plane is allocated on first use */
+#define GE_ABI_VERSION 5
 #define GE_MAX_PHASES 32
 #define GE_MAX_PLAYERS 12
 #define GE_MAX_SEGMENTS 4
@@ -318,6 +325,15 @@ void ge_batch_destroy(ge_batch *b);
  * is created - GE_ERR_UNSUPPORTED if there is none; hosts that never create a group never load it.
  * Not thread-safe, like a ge_batch.  The multi-PROCESS form (one rank per GPU, torch.distributed) is game_engine_amd/dist.py. */
 typedef struct ge_group ge_group;
+/* The group's sharding, for a host that places the shards itself (several per device, or devices of its own choosing without RCCL)
+ * - and what ge_group_create does internally: part `part` of `n_parts` takes the part-th of n_parts contiguous parts of every
+ * segment of `desc` (the whole job; every segment needs >= n_parts rooms).  *shard = desc with those room counts;
+ * seg_first[0 .. GE_MAX_SEGMENTS) = the global index of the part's first room of each segment (what the RNG is keyed by).
+ * Pure host arithmetic: no device is touched.  ge_batch_create_shard(shard, seg_first, &b) then creates that part as an ordinary
+ * batch (shard->device says where); n such batches hold, room for room, what ONE batch of `desc` holds, and their summaries add up
+ * to its summary (checksums and histograms are sums over rooms). */
+int ge_group_partition(const ge_batch_desc *desc, int n_parts, int part, ge_batch_desc *shard, uint64_t *seg_first);
+int ge_batch_create_shard(const ge_batch_desc *shard, const uint64_t *seg_first, ge_batch **out);
 int ge_group_create(const ge_batch_desc *desc, const int *devices, int n_devices, ge_group **out);
 int ge_group_size(const ge_group *g);                           /* number of devices, or GE_ERR_ARG */
 int ge_group_shard(ge_group *g, int i, ge_batch **out);         /* borrow device i's batch (read_rooms, inject, events ...); owned by the group */

@@ -47,8 +47,67 @@ static ge_room_view random_view(const ge_game_table &tb, uint32_t n, bool valid)
     return v;
 }
 
+// group_partition (what ge_group_create and ge_group_partition shard a job with): for every n the parts tile every segment
+// exactly, in order, and each part's seg_first is the global index those rooms have in ONE batch of the job.
+static int check_partition(const ge_game_table *tb_ww, const ge_game_table *tb_tt) {
+    struct Job { uint32_t n_seg; uint64_t rooms[GE_MAX_SEGMENTS]; uint64_t first_room; };
+    const Job jobs[] = {
+        {1, {16777216ull, 0, 0, 0}, 0},                                   // C4: 16 777 216 Werewolf x 12
+        {2, {8388608ull, 8388608ull, 0, 0}, 1ull << 40},                   // C5: half Werewolf x 8, half Two-Truths x 4
+        {4, {1000003ull, 64ull, 777ull, 4099ull}, 0xFFFFFFFF00ull},        // four ragged segments, one as small as n
+        {3, {65ull, 66ull, 67ull, 0}, 5},
+    };
+    for (const Job &j : jobs) {
+        ge_batch_desc d;
+        memset(&d, 0, sizeof d);
+        d.seed = 7; d.first_room = j.first_room; d.n_segments = j.n_seg; d.flags = GE_FLAG_RESTART; d.max_fuse = 3;
+        for (uint32_t k = 0; k < j.n_seg; k++) { d.seg[k].table = (k & 1) ? tb_tt : tb_ww; d.seg[k].n_players = (k & 1) ? 4 : 8; d.seg[k].n_rooms = j.rooms[k]; d.seg[k].human_mask = k; }
+        for (int n : {1, 2, 3, 5, 8, 64}) {
+            uint64_t next[GE_MAX_SEGMENTS], base[GE_MAX_SEGMENTS], acc = j.first_room;
+            for (uint32_t k = 0; k < j.n_seg; k++) { base[k] = next[k] = acc; acc += j.rooms[k]; }
+            for (int i = 0; i < n; i++) {
+                ge_batch_desc sh;
+                uint64_t first[GE_MAX_SEGMENTS];
+                if (group_partition(d, n, i, &sh, first) != GE_OK) return 1;
+                if (sh.seed != d.seed || sh.first_room != d.first_room || sh.n_segments != d.n_segments || sh.flags != d.flags || sh.max_fuse != d.max_fuse) return 2;
+                for (uint32_t k = 0; k < j.n_seg; k++) {
+                    if (first[k] != next[k]) return 3;                            // parts follow each other without gap or overlap
+                    if (sh.seg[k].table != d.seg[k].table || sh.seg[k].n_players != d.seg[k].n_players || sh.seg[k].human_mask != d.seg[k].human_mask) return 4;
+                    const uint64_t want = j.rooms[k] * (uint64_t)(i + 1) / (uint64_t)n - j.rooms[k] * (uint64_t)i / (uint64_t)n;   // floor(R (i+1) / n) - floor(R i / n)
+                    if (sh.seg[k].n_rooms != want || want == 0) return 5;
+                    next[k] += sh.seg[k].n_rooms;
+                }
+            }
+            for (uint32_t k = 0; k < j.n_seg; k++)
+                if (next[k] != base[k] + j.rooms[k]) return 6;                    // ... and end where the segment ends
+        }
+        // refused, nothing written: more parts than the smallest segment has rooms, bad part index, null outputs
+        ge_batch_desc sh; uint64_t first[GE_MAX_SEGMENTS];
+        if (j.n_seg == 4 && group_partition(d, 65, 0, &sh, first) != GE_ERR_ARG) return 7;
+        if (group_partition(d, 2, 2, &sh, first) != GE_ERR_ARG || group_partition(d, 0, 0, &sh, first) != GE_ERR_ARG ||
+            group_partition(d, 2, -1, &sh, first) != GE_ERR_ARG || group_partition(d, 2, 0, nullptr, first) != GE_ERR_ARG ||
+            group_partition(d, 2, 0, &sh, nullptr) != GE_ERR_ARG) return 8;
+    }
+    // rooms near 2^64 / n: the split product stays exact
+    ge_batch_desc d; memset(&d, 0, sizeof d);
+    d.n_segments = 1; d.seg[0].table = tb_ww; d.seg[0].n_players = 8; d.seg[0].n_rooms = 0xFFFFFFFFFFFFFFF0ull;
+    uint64_t total = 0;
+    for (int i = 0; i < 7; i++) {
+        ge_batch_desc sh; uint64_t first[GE_MAX_SEGMENTS];
+        if (group_partition(d, 7, i, &sh, first) != GE_OK || first[0] != total) return 9;
+        total += sh.seg[0].n_rooms;
+    }
+    return total == d.seg[0].n_rooms ? 0 : 10;
+}
+
 int main(int argc, char **argv) {
     int compiled = 0;
+    {
+        ge_game_table a, b;                                  // group_partition only carries the table pointers along
+        memset(&a, 0, sizeof a); memset(&b, 0, sizeof b);
+        const int pc = check_partition(&a, &b);
+        if (pc) { fprintf(stderr, "FAILED: group_partition check %d\n", pc); return 1; }
+    }
     for (int a = 1; a < argc; a++) {
         FILE *f = fopen(argv[a], "rb");
         if (!f) return fail("open", argv[a]);

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     assert set(names) == set(_lib.SYMBOLS)
     for n in names:
         assert getattr(lib, n) is not None
-    assert lib.ge_abi_version() == _lib.GE_ABI_VERSION == 4
+    assert lib.ge_abi_version() == _lib.GE_ABI_VERSION == 5
 
 
 def test_struct_sizes_match_header():
@@ -123,3 +123,37 @@ int main(void) {
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
     assert out.returncode == 0, (out.returncode, out.stderr)
     assert "needs top-level" in out.stdout
+
+
+def test_group_partition_through_the_c_abi_needs_no_device():
+    """ge_group_partition (the device group's sharding arithmetic, ABI 5) is host-only: parts tile every segment and carry the
+    global index of their first room; the Python hosts' reassembly and RoomGroup read-back walk the same parts."""
+    import ctypes as C
+    from game_engine_amd import _lib
+    from game_engine_amd.stepper import partition
+    lib = _lib.load()
+    for rooms, first_room in (([16777216], 0), ([8388608, 8388608], 1 << 40), ([1000003, 64, 777, 4099], 0xFFFFFFFF00)):
+        d = _lib.BatchDesc()
+        d.first_room, d.n_segments, d.seed = first_room, len(rooms), 5
+        for k, r in enumerate(rooms):
+            d.seg[k].n_rooms, d.seg[k].n_players = r, 8
+        for n in (1, 2, 3, 8, 64):
+            nxt, acc = [], first_room
+            for r in rooms:
+                nxt.append(acc)
+                acc += r
+            for i in range(n):
+                sd, first = partition(d, n, i)
+                assert first == nxt and sd.seed == 5 and sd.n_segments == len(rooms)
+                for k, r in enumerate(rooms):
+                    assert sd.seg[k].n_rooms == r * (i + 1) // n - r * i // n > 0
+                    nxt[k] += sd.seg[k].n_rooms
+            acc = first_room
+            for k, r in enumerate(rooms):
+                acc += r
+                assert nxt[k] == acc
+    sh, first = _lib.BatchDesc(), (C.c_uint64 * 4)()
+    assert lib.ge_group_partition(C.byref(d), 65, 0, C.byref(sh), first) == -1          # a segment has only 64 rooms
+    assert lib.ge_group_partition(C.byref(d), 2, 2, C.byref(sh), first) == -1
+    assert lib.ge_group_partition(None, 2, 0, C.byref(sh), first) == -1
+    assert lib.ge_batch_create_shard(C.byref(sh), None, None) == -1

@@ -1,6 +1,6 @@
 """Host-only code of libge_step.so under AddressSanitizer + UBSan (CPU; GPU sanitizers are not available on this pool):
 ge_table.cpp (the DSL compiler) and csrc/ge_host.h (table rows, the generic rows' literal image, restart template, room
-view <-> packed record conversion, the checks of ge_batch_write_rooms) built with g++ -fsanitize=address,undefined and driven
+view <-> packed record conversion, the checks of ge_batch_write_rooms, the device group's sharding arithmetic group_partition) built with g++ -fsanitize=address,undefined and driven
 by tests/native/host_sanitize.cpp over the shipped DSLs, the reference's draft and every grammar variant of the goldens, for
 every player count and record layout.  (ge_table.cpp alone against garbage input: tests/test_table_fuzz.py.)"""
 import json

@@ -122,3 +122,37 @@ def test_single_room_service_over_http():
     bt = r["burst"]
     assert bt["hist"] == 9 and bt["idsOk"] and not bt["busy"]
     assert bt["closed"] is True and "unknown thread" in bt["afterClose"] and bt["rooms"] == 1
+
+
+@needs_node
+def test_js_group_room_lookup_follows_the_native_partition():
+    """DeviceGroup.readRoom finds a room's shard and local index with locateInShards: the same parts ge_group_partition makes."""
+    import random
+    from game_engine_amd import _lib
+    from game_engine_amd.stepper import partition
+    rnd = random.Random(3)
+    cases = []
+    for rooms in ([16777216], [8388608, 8388608], [1000003, 64, 777, 4099], [65, 66, 67]):
+        d = _lib.BatchDesc()
+        d.n_segments = len(rooms)
+        for k, r in enumerate(rooms):
+            d.seg[k].n_rooms, d.seg[k].n_players = r, 8
+        for n in (1, 2, 3, 8, 64):
+            parts = [partition(d, n, i) for i in range(n)]                     # first[] relative to first_room 0
+            seg_base = [sum(rooms[:k]) for k in range(len(rooms))]
+            probes = {0, sum(rooms) - 1} | {rnd.randrange(sum(rooms)) for _ in range(40)}
+            for i, (sd, first) in enumerate(parts):                            # every part's edges too
+                for k in range(len(rooms)):
+                    probes |= {first[k], first[k] + int(sd.seg[k].n_rooms) - 1}
+            for room in sorted(probes):
+                k = max(j for j in range(len(rooms)) if seg_base[j] <= room)
+                i = next(i for i, (sd, first) in enumerate(parts) if first[k] <= room < first[k] + int(sd.seg[k].n_rooms))
+                local = room - parts[i][1][k] + sum(int(parts[i][0].seg[j].n_rooms) for j in range(k))
+                cases.append({"rooms": rooms, "n": n, "room": room, "want": [i, local, k]})
+    js = ("const {locateInShards}=require(process.argv[1]);const cs=JSON.parse(require('fs').readFileSync(0,'utf8'));"
+          "const bad=cs.filter((c)=>JSON.stringify(locateInShards(c.rooms,c.n,c.room))!==JSON.stringify(c.want));"
+          "console.log(JSON.stringify({n:cs.length,bad:bad.slice(0,3)}));")
+    out = subprocess.run(["node", "-e", js, os.path.join(NODE_DIR, "index.js")], input=json.dumps(cases), capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = json.loads(out.stdout)
+    assert r["n"] == len(cases) > 1000 and r["bad"] == [], r["bad"]
