@@ -84,6 +84,7 @@ OTHER_SHAPES = (
     ("1048576 Werewolf x8", "ww8_1048576", [(WW, 8, 1 << 20)]),
     ("2097152 Werewolf x12 (one GPU's share of C4)", "c4", WORKLOADS["c4"]),
     ("1048576 Two-Truths x4 (C3)", "c3", WORKLOADS["c3"]),
+    ("524288 Werewolf x8 + 524288 Two-Truths x4 (one GPU's share of C5)", "c5", WORKLOADS["c5"]),
 )
 
 
@@ -116,25 +117,28 @@ def usable_cores():
 
 def cpu_baseline(spec, budget_s=12.0, sample_rooms=None, single_thread=True):
     """The oracle (a scalar C port of the reference loop + policy) on this host's cores, on a bounded sample of the
-    same steady-state workload: the first segment's game, `sample_rooms` rooms (default: the segment's own count,
-    capped at 1 048 576), as many turns as fit the time budget."""
+    same steady-state workload: every segment's game in the workload's own proportions, `sample_rooms` rooms in all
+    (default: the workload's own count, capped at 1 048 576), as many turns as fit the time budget."""
     from oracle.oracle import Oracle
-    game, n_players, rooms = spec[0]
-    rooms = min(sample_rooms or rooms, 1 << 20)
+    total = sum(r for _, _, r in spec)
+    want = min(sample_rooms or total, 1 << 20)
     cores = usable_cores()
-    orc = Oracle(load_dsl(game), n_players)
-    state = orc.init_rooms(rooms)
+    parts = [(Oracle(load_dsl(g), n), g, n, max(1, want * r // total)) for g, n, r in spec]
     t0 = time.perf_counter()
-    orc.run(state, SEED, 0, 0, 8, threads=cores, restart=True)        # calibrate
+    for orc, _, _, rooms in parts:                                   # calibrate
+        orc.run(orc.init_rooms(rooms), SEED, 0, 0, 8, threads=cores, restart=True)
     dt = max(time.perf_counter() - t0, 1e-4)
     turns = int(min(max(8 * budget_s / dt, 16), 4096))
-    state = orc.init_rooms(rooms)
+    states = [orc.init_rooms(rooms) for orc, _, _, rooms in parts]
     t0 = time.perf_counter()
-    orc.run(state, SEED, 0, 0, turns, threads=cores, restart=True)
+    for (orc, _, _, _), state in zip(parts, states):
+        orc.run(state, SEED, 0, 0, turns, threads=cores, restart=True)
     dt_all = time.perf_counter() - t0
-    out = {"value": rooms * turns / dt_all, "unit": "room-phase steps/s", "cores": cores, "kind": "port",
-           "sample": f"{rooms} {game} x{n_players} rooms x {turns} turns, steady state, OpenMP over rooms"}
+    rooms_all = sum(p[3] for p in parts)
+    out = {"value": rooms_all * turns / dt_all, "unit": "room-phase steps/s", "cores": cores, "kind": "port",
+           "sample": " + ".join(f"{rooms} {g} x{n}" for _, g, n, rooms in parts) + f" rooms x {turns} turns, steady state, OpenMP over rooms"}
     if single_thread:
+        orc = parts[0][0]
         one = orc.init_rooms(4096)
         t1 = max(turns // 8, 16)
         t0 = time.perf_counter()
@@ -300,7 +304,7 @@ def main():
 
     stream = torch.cuda.current_stream().cuda_stream
 
-    def streaming_point(spec, launches=256, first_room=0, preroll=PREROLL_TURNS):
+    def streaming_point(spec, launches=256, first_room=0, preroll=PREROLL_TURNS, parity=True):
         """The HBM-streaming point of a shape: max_fuse = 1, one launch per turn - every turn reads and writes every record
         through HBM.  Device time per launch by HIP events on the launch stream, and the wall clock of hipGraph replays."""
         segs = segments_of(spec)
@@ -330,24 +334,27 @@ def main():
         gbs_wall = 2 * bpr * rooms * launches / w1 / 1e9
         gbs_kernel = 2 * bpr * rooms / (us * 1e-6) / 1e9
         gbs_graph = 2 * bpr * rooms * launches / g1 / 1e9
-        return {"value": rooms * launches / w1, "unit": "room-phase steps/s (wall)", "ms_per_turn": w1 * 1e3 / launches,
-                "bound": "hbm", "bytes_per_launch": 2 * bpr * rooms, "rooms": rooms,
-                "resident_state_MiB": state_bytes / (1 << 20), "fits_infinity_cache": not beyond,
-                "what_frac_is": ("HBM: the resident state is larger than the 256 MiB Infinity Cache, so a launch's reads cannot be served from what the "
-                                 "previous launch left there" if beyond else
-                                 "memory-side rate (Infinity Cache may serve): the resident state fits the 256 MiB Infinity Cache and the launches replay "
-                                 "back to back over the same records - see hbm_streaming_beyond_l3 for the figure that is provably HBM"),
-                # sustained: device time of a replayed graph of back-to-back launches / launches
-                "us_per_launch_sustained": g1 * 1e6 / launches, "achieved_GBs": gbs_graph, "frac": gbs_graph / HBM_PEAK_GBS,
-                "frac_of_measured_copy_peak": gbs_graph / HBM_COPY_GBS,
-                # one launch at a time between two HIP events (includes ~2 us of event / dispatch gap per launch)
-                "kernel_us_per_launch": us, "achieved_GBs_kernel": gbs_kernel, "frac_kernel": gbs_kernel / HBM_PEAK_GBS,
-                "achieved_GBs_wall": gbs_wall, "frac_wall": gbs_wall / HBM_PEAK_GBS,
-                "note": "max_fuse=1: one launch per turn, every turn reads and writes every record (bytes_per_launch = the "
-                        "state, read + written; the committed FETCH/WRITE passes profiles/pmc_<shape>_k1.json measure the same memory-side bytes). "
-                        f"frac: HIP events around a hipGraph replay of {launches} launches on the launch stream; frac_kernel: HIP events around "
-                        "single launches; frac_wall: host clock over 4 replays; the rocprofv3 kernel-trace average of the same launches is in "
-                        "profiles/r04_<shape>_k1_kernel_stats.csv"}
+        pt = {"value": rooms * launches / w1, "unit": "room-phase steps/s (wall)", "ms_per_turn": w1 * 1e3 / launches,
+              "bound": "hbm", "bytes_per_launch": 2 * bpr * rooms, "rooms": rooms, "launches_per_replay": launches,
+              "resident_state_MiB": state_bytes / (1 << 20), "fits_infinity_cache": not beyond,
+              # what `frac` is: state > 256 MiB Infinity Cache -> at least hbm_floor_frac of it is DRAM traffic (a launch cannot
+              # read more than 256 MiB of what the previous one left in the cache); else a memory-side rate the cache may serve
+              "what_frac_is": "hbm (state > Infinity Cache)" if beyond else "memory-side (state fits the Infinity Cache)",
+              # sustained: device time of a replayed graph of back-to-back launches / launches
+              "us_per_launch_sustained": g1 * 1e6 / launches, "achieved_GBs": gbs_graph, "frac": gbs_graph / HBM_PEAK_GBS,
+              "hbm_floor_frac": (gbs_graph / HBM_PEAK_GBS) * max(0.0, 1.0 - L3_BYTES / state_bytes),
+              "frac_of_measured_copy_peak": gbs_graph / HBM_COPY_GBS,
+              # one launch at a time between two HIP events (includes ~2 us of event / dispatch gap per launch)
+              "kernel_us_per_launch": us, "frac_kernel": gbs_kernel / HBM_PEAK_GBS, "frac_wall": gbs_wall / HBM_PEAK_GBS,
+              "launch_chains": os.environ.get("GE_CHAINS", "default")}
+        if parity:
+            with RoomBatch(segs, seed=SEED, first_room=first_room, device=device_index, max_fuse=1, restart=True) as k1b, \
+                 RoomBatch(segs, seed=SEED, first_room=first_room, device=device_index, max_fuse=64, restart=True) as fz:
+                k1b.step(64, stream); fz.step(64, stream)
+                s1, sf = k1b.summary(), fz.summary()
+            pt["parity"] = {"turns": 64, "checksum_single_turn": s1["checksum"], "checksum_fused": sf["checksum"],
+                            "single_turn_equals_fused": s1 == sf}
+        return pt
 
     spec = [list(x) for x in WORKLOADS[args.workload]]
     if args.rooms:
@@ -389,6 +396,7 @@ def main():
     unfused = None
     if rank == 0 and world == 1 and not args.no_unfused:
         unfused = streaming_point(spec, launches=max(16, min(256, int(1.2e10 // rooms))), preroll=PREROLL_TURNS if rooms <= (1 << 22) else 256)
+        unfused["shape"] = args.workload
 
     # the same launch over a state larger than the Infinity Cache (N = 1), and parity at that size: 64 single-turn launches
     # == 64 fused turns (the whole ge_summary, checksum of every packed record included)
@@ -399,13 +407,7 @@ def main():
             sp = WORKLOADS[key]
             r = sum(x[2] for x in sp)
             pt = streaming_point(sp, launches=max(8, min(64, int(3e9 // r))), preroll=256)
-            with RoomBatch(segments_of(sp), seed=SEED, device=device_index, max_fuse=1, restart=True) as k1, \
-                 RoomBatch(segments_of(sp), seed=SEED, device=device_index, max_fuse=64, restart=True) as fz:
-                k1.step(64, stream); fz.step(64, stream)
-                s1, sf = k1.summary(), fz.summary()
-            pt["parity"] = {"turns": 64, "checksum_single_turn": s1["checksum"], "checksum_fused": sf["checksum"],
-                            "single_turn_equals_fused": s1 == sf}
-            pt["profile"] = f"profiles/r04_{key}_k1_kernel_stats.csv, profiles/pmc_{key}_k1.json"
+            pt["profile"] = f"profiles/r05_{key}_k1_kernel_stats.csv, profiles/pmc_{key}_k1.json"
             beyond_l3[label] = pt
 
     # BASELINE.md §3 variant: S = 64 turns from the initial state (no recycling), 3 warm-ups, median of 10
@@ -449,8 +451,6 @@ def main():
             other[label] = {"value": r * turns / (ms * 1e-3), "unit": "room-phase steps/s (device time)",
                             "us_per_turn": ms * 1e3 / turns, "turns_timed": turns, "bytes_per_room_record": bpr,
                             "algorithmic_GBs": alg, "algorithmic_frac": alg / HBM_PEAK_GBS,
-                            "algorithmic_note": "SURVEY 8(d) yardstick (2 x record x rooms x turns / time): fused turns keep the state in "
-                                                "registers, so this is not traffic and may exceed 1; the physical HBM fraction is hbm_streaming",
                             "bound_actual": "valu-issue",
                             "issue": issue_block(committed_profile(key, args.fuse), r, turns, ms * 1e-3),
                             "hbm_streaming": None if args.no_unfused else streaming_point(sp, launches=128)}
@@ -489,7 +489,7 @@ def main():
             stream_pt = None
             if key == "c4" and not args.no_unfused:
                 barrier()
-                stream_pt = streaming_point(sp, launches=64, first_room=shard_first_room(r, rank), preroll=256)
+                stream_pt = streaming_point(sp, launches=64, first_room=shard_first_room(r, rank), preroll=256, parity=False)
                 stream_pt["us_per_launch_sustained_max_over_ranks"] = max_over_ranks(stream_pt["us_per_launch_sustained"])
                 stream_pt["frac_min_over_ranks"] = 2 * bpr * r / (stream_pt["us_per_launch_sustained_max_over_ranks"] * 1e-6) / 1e9 / HBM_PEAK_GBS
                 barrier()
@@ -501,9 +501,7 @@ def main():
                 "bytes_per_room_record": bpr, "algorithmic_GBs": alg, "algorithmic_frac": alg / (HBM_PEAK_GBS * world),
                 "roofline": {"bound": "hbm", "achieved": alg, "peak": HBM_PEAK_GBS * world, "unit": "GB/s", "frac": alg / (HBM_PEAK_GBS * world),
                              "algorithmic": True, "bound_actual": "valu-issue", "traffic": None,
-                             "issue": issue_block(committed_profile(key, args.fuse), r, args.fuse * k_timed, dt),
-                             "note": "whole job over all ranks, wall clock (max over ranks); ALGORITHMIC bytes as in the top-level roofline block - "
-                                     "fused turns keep the state in registers; per-GPU issue fraction from the committed SQ pass of this shape"},
+                             "issue": issue_block(committed_profile(key, args.fuse), r, args.fuse * k_timed, dt)},
                 "hbm_streaming": stream_pt,
                 "summary_allgather_ms": ag_ms,
                 "checksum": sm["checksum"], "summary": {k: sm[k] for k in ("rooms", "finished", "village_wins", "wolf_wins", "games_recycled")}}
@@ -520,6 +518,26 @@ def main():
         traffic = prof.get("hbm_bytes_per_launch") if abs(prof.get("state_bytes_read_plus_written", -1) - state_rw) < 1 else None
         issue = issue_block(prof, rooms, turns_timed, kernel_ms * 1e-3)
         fused = args.fuse > 1
+        def phys(label, pt):
+            """one row of roofline.physical: a single-turn launch that really moves the state, from this run's HIP events"""
+            return {"shape": label, "rooms": pt["rooms"], "state_MiB": round(pt["resident_state_MiB"], 1),
+                    "us_per_launch": round(pt["us_per_launch_sustained"], 2), "frac": round(pt["frac"], 4),
+                    "hbm": not pt["fits_infinity_cache"], "hbm_floor_frac": round(pt["hbm_floor_frac"], 4),
+                    "parity": (pt.get("parity") or {}).get("single_turn_equals_fused")}
+
+        physical = []
+        for label, pt in (beyond_l3 or {}).items():
+            physical.append(phys(label, pt))
+        if unfused:
+            physical.append(phys(f"{rooms} {GAME} x{N_PLAYERS} ({args.workload})", unfused))
+        for label, o in (other or {}).items():
+            if o.get("hbm_streaming"):
+                physical.append(phys(label, o["hbm_streaming"]))
+        fused_rows = [{"shape": f"{rooms} {GAME} x{N_PLAYERS} ({args.workload})", "us_per_turn": round(kernel_ms * 1e3 / turns_timed, 3),
+                       "steps_per_s": total_steps / elapsed, "valu_frac": issue.get("valu_frac"), "issue_frac": issue.get("frac")}]
+        for label, o in (other or {}).items():
+            fused_rows.append({"shape": label, "us_per_turn": round(o["us_per_turn"], 3), "steps_per_s": o["value"],
+                               "valu_frac": o["issue"].get("valu_frac"), "issue_frac": o["issue"].get("frac")})
         out = {
             "metric": "room-phase steps/sec", "value": total_steps / elapsed, "unit": "room-phase steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -531,21 +549,7 @@ def main():
                        "rooms_per_gpu": rooms, "n_players": [n for _, n, _ in spec], "turns_fused_per_launch": args.fuse,
                        "room_phase_steps_per_bench_step": rooms * world * args.fuse, "preroll_turns": preroll,
                        "bytes_per_room_record": bytes_per_room, "sharding": f"rooms x{world}, no data-path collective"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_copy_peak": achieved / HBM_COPY_GBS,
-                         "traffic": traffic,
-                         "traffic_source": (prof.get("_path", None) and f"{prof['_path']} (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; not measured in this run)"),
-                         "kernel": "ge_step_kernel", "avg_launch_us": avg_launch_s * 1e6, "launches": launches,
-                         "algorithmic": True, "algorithmic_bytes_per_launch": alg_bytes,
-                         # what really bounds this launch, and the physical HBM figure of the same launch
-                         "bound_actual": "valu-issue" if fused else "hbm",
-                         "frac_of_actual_bound": issue.get("frac") if fused else achieved / HBM_PEAK_GBS,
-                         "hbm_frac_of_measured_traffic": (traffic / avg_launch_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                         "note": "`achieved` / `frac` are SURVEY 8(d)'s yardstick: ALGORITHMIC bytes = 2 x record x rooms x turns in the launch. "
-                                 "With fused turns the state stays in registers, those bytes never reach HBM (real traffic: `traffic`, ~1/fuse of "
-                                 "it) and the figure is not a physical fraction - the launch is bound by instruction issue (`bound_actual`, "
-                                 "block `issue`).  The physical HBM fraction of the path is `hbm_streaming` (max_fuse = 1), per shape in "
-                                 "`other_shapes[*].hbm_streaming`"},
+            # the bulky per-shape blocks first, the contract's blocks last: a tail of the line still shows them
             "issue": issue,
             "hbm_streaming": unfused,
             "hbm_streaming_beyond_l3": beyond_l3,
@@ -554,6 +558,24 @@ def main():
             "other_workloads": other_workloads,
             "summary": {k: summary[k] for k in ("rooms", "finished", "village_wins", "wolf_wins", "games_recycled", "checksum")},
             "summary_allgather_ms": summary_ms,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_copy_peak": achieved / HBM_COPY_GBS,
+                         "traffic": traffic,
+                         "traffic_source": (prof.get("_path", None) and f"{prof['_path']} (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"),
+                         "kernel": "ge_step_kernel", "avg_launch_us": avg_launch_s * 1e6, "launches": launches,
+                         # `achieved` / `frac` are SURVEY 8(d)'s yardstick: ALGORITHMIC bytes = 2 x record x rooms x turns in the launch.
+                         # Fused turns keep the state in registers: those bytes never reach HBM (`traffic`), the launch is bound by
+                         # the vector pipe (`bound_actual`; `frac_of_actual_bound` = VALU busy fraction of the issue ceiling)
+                         "algorithmic": True, "algorithmic_bytes_per_launch": alg_bytes,
+                         "bound_actual": "valu-issue" if fused else "hbm",
+                         "frac_of_actual_bound": issue.get("valu_frac") if fused else achieved / HBM_PEAK_GBS,
+                         "hbm_frac_of_measured_traffic": (traffic / avg_launch_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                         # the PHYSICAL figures of this run: single-turn launches (max_fuse = 1), every launch reads and writes every
+                         # record; frac = state read + written / device time per launch (HIP events around a replayed hipGraph on the
+                         # launch stream) / 8 TB/s; hbm: the resident state is larger than the 256 MiB Infinity Cache (>= hbm_floor_frac
+                         # of 8 TB/s is then DRAM traffic); parity: 64 such launches == 64 fused turns (whole summary + checksum)
+                         "physical": physical,
+                         "fused": fused_rows},
         }
         if not args.no_cpu_baseline and args.workload == "c2":
             # rank 0 only.  N = 1: the contract's ~12 s sample; N > 1: a shorter one (the other ranks wait at the barrier below),

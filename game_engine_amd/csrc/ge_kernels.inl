@@ -31,6 +31,7 @@ struct StepArgs {
     unsigned long long *stamps; // GE_STAMPS diagnostic build: 4 segment sums + wave-turn count (else null)
     uint32_t n_seg, turn0, n_turns, seed_key, block_threads, restart, trace, lowocc;
     uint32_t cond_off;         // GENERIC builds: byte offset of the literal image (DevTable::cond_img) in a block's LDS, behind everything else
+    uint32_t block_off;        // the launch covers blocks [block_off, block_off + gridDim.x) of the batch (launch chains, ge_step.hip graph_for)
     uint32_t block_begin[GE_MAX_SEGMENTS];
 };
 
@@ -448,36 +449,38 @@ extern __shared__ __align__(16) unsigned char ge_lds[];
 #ifndef GE_GENERIC_WAVES
 #define GE_GENERIC_WAVES 1
 #endif
-// SINGLE: the launch is one turn (a.n_turns == 1) of a single-game batch with shipped-grammar conditions (run_ww / run_tt)
+// SINGLE: the launch is one turn (a.n_turns == 1) (run_ww / run_tt)
 template <int KIND, bool LOWOCC, bool GENERIC = false, bool SINGLE = false>
 __global__ void __launch_bounds__(SINGLE ? 1024 : 256, SINGLE ? 8 : (!LOWOCC && GENERIC) ? GE_GENERIC_WAVES : (KIND == K_WW12 && !LOWOCC) ? GE_WW12_WAVES : (KIND == K_WW8 && !LOWOCC) ? GE_WW8_WAVES : 1) ge_step_kernel(const SegDev *__restrict__ segs, const DevTable *__restrict__ tables, const StepArgs a) {
     constexpr bool WWK = KIND == K_WW8 || KIND == K_WW12 || tt_uses_queue(KIND == K_TT4 ? 4 : KIND == K_TT8 ? 8 : 12, LOWOCC);   // uses the action queue
     DevRow *rows = reinterpret_cast<DevRow *>(ge_lds);
     uint8_t *nth8 = ge_lds + LDS_ROWS + LDS_ORD8;
     auto *wl = reinterpret_cast<typename WaveLdsOf<LOWOCC>::type *>(ge_lds + LDS_ROWS + LDS_ORD8 + (LOWOCC ? 0u : LDS_NTH8 + LDS_S0));
-    const uint64_t room = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t room = (uint64_t)(blockIdx.x + a.block_off) * blockDim.x + threadIdx.x;
     run_kind<KIND, LOWOCC, GENERIC, SINGLE>(segs, a, rows, WWK ? &wl[threadIdx.x >> 6] : nullptr, nth8, tables, room);
 }
 
-// mixed batch: several segments (games / player counts) in one launch
-template <bool LOWOCC, bool GENERIC = false>
-__global__ void __launch_bounds__(256, !LOWOCC ? (GENERIC ? GE_GENERIC_WAVES : GE_WW12_WAVES) : 1) ge_step_kernel_mixed(const SegDev *__restrict__ segs, const DevTable *__restrict__ tables, const StepArgs a) {
+// mixed batch: several segments (games / player counts) in one launch.  SINGLE: the launch is one turn - each kind's single-turn
+// form (no turn loop, the restart template through the scalar cache, Werewolf x 12 deals from the side plane), 8 wavefronts per SIMD
+template <bool LOWOCC, bool GENERIC = false, bool SINGLE = false>
+__global__ void __launch_bounds__(256, SINGLE ? 8 : !LOWOCC ? (GENERIC ? GE_GENERIC_WAVES : GE_WW12_WAVES) : 1) ge_step_kernel_mixed(const SegDev *__restrict__ segs, const DevTable *__restrict__ tables, const StepArgs a) {
     DevRow *rows = reinterpret_cast<DevRow *>(ge_lds);
     uint8_t *nth8 = ge_lds + LDS_ROWS + LDS_ORD8;
     auto *wl = reinterpret_cast<typename WaveLdsOf<LOWOCC>::type *>(ge_lds + LDS_ROWS + LDS_ORD8 + (LOWOCC ? 0u : LDS_NTH8 + LDS_S0));
+    const uint32_t bid = blockIdx.x + a.block_off;
     uint32_t si = 0;
     for (uint32_t k = 1; k < a.n_seg; k++)
-        if (blockIdx.x >= a.block_begin[k]) si = k;
+        if (bid >= a.block_begin[k]) si = k;
     si = __builtin_amdgcn_readfirstlane(si);
     const SegDev *sg = segs + si;
-    const uint64_t room = (uint64_t)(blockIdx.x - a.block_begin[si]) * blockDim.x + threadIdx.x;
+    const uint64_t room = (uint64_t)(bid - a.block_begin[si]) * blockDim.x + threadIdx.x;
     void *lw = &wl[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)];    // wave-uniform: kept in a scalar register across the kind switch
     switch (sg->kind) {
-    case K_WW8: run_kind<K_WW8, LOWOCC, GENERIC>(sg, a, rows, lw, nth8, tables, room); break;
-    case K_WW12: run_kind<K_WW12, LOWOCC, GENERIC>(sg, a, rows, lw, nth8, tables, room); break;
-    case K_TT4: run_kind<K_TT4, LOWOCC, GENERIC>(sg, a, rows, lw, nth8, tables, room); break;
-    case K_TT8: run_kind<K_TT8, LOWOCC, GENERIC>(sg, a, rows, lw, nth8, tables, room); break;
-    default: run_kind<K_TT12, LOWOCC, GENERIC>(sg, a, rows, lw, nth8, tables, room); break;
+    case K_WW8: run_kind<K_WW8, LOWOCC, GENERIC, SINGLE>(sg, a, rows, lw, nth8, tables, room); break;
+    case K_WW12: run_kind<K_WW12, LOWOCC, GENERIC, SINGLE>(sg, a, rows, lw, nth8, tables, room); break;
+    case K_TT4: run_kind<K_TT4, LOWOCC, GENERIC, SINGLE>(sg, a, rows, lw, nth8, tables, room); break;
+    case K_TT8: run_kind<K_TT8, LOWOCC, GENERIC, SINGLE>(sg, a, rows, lw, nth8, tables, room); break;
+    default: run_kind<K_TT12, LOWOCC, GENERIC, SINGLE>(sg, a, rows, lw, nth8, tables, room); break;
     }
 }
 

@@ -51,7 +51,8 @@ struct ge_batch {
     std::vector<Segment> segs;
     void *state = nullptr;            // one allocation, segments back to back
     void *trace = nullptr;            // GE_FLAG_TRACE: per segment [max_fuse][rooms_padded] x 16 B
-    void *deal_side = nullptr;        // Werewolf x 12 segments: prepared role deals of the single-turn launches, [rooms_padded] x 8 B each (ge_kernels.inl run_ww)
+    void *deal_side = nullptr;        // Werewolf x 12 segments: prepared role deals of the single-turn launches, [rooms_padded] x 8 B each (ge_kernels.inl run_ww); allocated by the first single-turn launch (ensure_deal_side)
+    bool deal_side_failed = false;    // ... or never (no Werewolf x 12 segment / no memory for a cache)
     uint32_t last_step_turns = 0;     // turns of the most recent ge_batch_step (what the trace holds)
     size_t state_bytes = 0;
     DevTable *tables = nullptr;
@@ -71,6 +72,8 @@ struct ge_batch {
     uint32_t *turn_dev = nullptr;     // turn base the captured launches read
     uint64_t turn_dev_value = ~0ull;  // what *turn_dev holds (host mirror)
     hipStream_t cap_stream = nullptr; // capture needs a non-default stream
+    hipStream_t chain_stream[8] = {}; // launch chains (graph_for): the forked streams of the capture, [0] unused (= cap_stream)
+    hipEvent_t chain_ev[8] = {};      // [0] the fork, [c] chain c's join
     std::vector<std::pair<uint32_t, hipGraphExec_t>> graphs;   // per n_turns
     bool graphs_ok = true;
     bool timing = false;
@@ -241,18 +244,6 @@ static int create_impl(const ge_batch_desc *desc, ge_batch **out, const uint64_t
                     off += (size_t)b->max_fuse * s.dev.rooms_padded * 16u;
                 }
             }
-            {
-                // a cache, not state: ge_batch_state does not show it, a checkpoint does not carry it, the fill zeroes it
-                size_t sb = 0;
-                for (Segment &s : b->segs) if (s.dev.kind == K_WW12) sb += (size_t)s.dev.rooms_padded * 8u;
-                if (sb && hipMalloc(&b->deal_side, sb) != hipSuccess) { st = GE_ERR_NOMEM; break; }
-                size_t off = 0;
-                for (Segment &s : b->segs)
-                    if (s.dev.kind == K_WW12) {
-                        s.dev.deal_side = reinterpret_cast<uint32_t *>(static_cast<char *>(b->deal_side) + off);
-                        off += (size_t)s.dev.rooms_padded * 8u;
-                    }
-            }
             std::vector<DevTable> host_tables(b->segs.size());
             for (size_t k = 0; k < b->segs.size(); k++) {
                 Segment &s = b->segs[k];
@@ -327,93 +318,203 @@ static int reset_impl(ge_batch *b) {
     return sync_impl(b);
 }
 
-static hipError_t launch_step(const ge_batch *b, const StepArgs &a, hipStream_t st) {
-    dim3 grid(b->n_blocks), block(b->block_threads);
-    uint32_t bt = b->block_threads;                           // rooms per block
-#define GE_LAUNCH(KERNEL, QUEUE, LOW) hipLaunchKernelGGL(KERNEL, grid, block, step_lds_bytes(QUEUE, LOW, bt), st, b->segs_dev, b->tables, a)
-    const bool low = a.lowocc != 0u && !(b->generic && b->segs.size() > 1);   // mixed batches with generic tables: the large-batch build serves every size
-    if (b->generic) {
-        // generic target conditions: single-game batches get both forms too; mixed batches the large-batch one.  A block keeps
-        // the generic rows' literal image behind everything else in its LDS (StepArgs::cond_off)
-        StepArgs ag = a;
-#undef GE_LAUNCH
-#define GE_LAUNCH(KERNEL, QUEUE, LOW) do { ag.cond_off = step_lds_bytes(QUEUE, LOW, bt); hipLaunchKernelGGL(KERNEL, grid, block, ag.cond_off + b->cond_bytes, st, b->segs_dev, b->tables, ag); } while (0)
-        if (b->segs.size() > 1) GE_LAUNCH((ge_step_kernel_mixed<false, true>), true, false);
-        else switch (b->segs[0].dev.kind) {
-        case K_WW8: if (low) GE_LAUNCH((ge_step_kernel<K_WW8, true, true>), true, true); else GE_LAUNCH((ge_step_kernel<K_WW8, false, true>), true, false); break;
-        case K_WW12: if (low) GE_LAUNCH((ge_step_kernel<K_WW12, true, true>), true, true); else GE_LAUNCH((ge_step_kernel<K_WW12, false, true>), true, false); break;
-        case K_TT4: if (low) GE_LAUNCH((ge_step_kernel<K_TT4, true, true>), tt_uses_queue(4, true), true); else GE_LAUNCH((ge_step_kernel<K_TT4, false, true>), true, false); break;
-        case K_TT8: if (low) GE_LAUNCH((ge_step_kernel<K_TT8, true, true>), tt_uses_queue(8, true), true); else GE_LAUNCH((ge_step_kernel<K_TT8, false, true>), true, false); break;
-        default: if (low) GE_LAUNCH((ge_step_kernel<K_TT12, true, true>), tt_uses_queue(12, true), true); else GE_LAUNCH((ge_step_kernel<K_TT12, false, true>), true, false); break;
-        }
-#undef GE_LAUNCH
-#define GE_LAUNCH(KERNEL, QUEUE, LOW) hipLaunchKernelGGL(KERNEL, grid, block, step_lds_bytes(QUEUE, LOW, bt), st, b->segs_dev, b->tables, a)
-    } else if (b->segs.size() > 1) {
-        if (low) GE_LAUNCH(ge_step_kernel_mixed<true>, true, true); else GE_LAUNCH(ge_step_kernel_mixed<false>, true, false);
-    } else if (a.n_turns == 1u) {
-        // one turn per launch (max_fuse = 1, or the tail of a step): the single-turn builds.  A block's first act is to fill its 7 KB
-        // of LDS tables behind a barrier - the fewer blocks, the less of that per launch - so a large Werewolf x 8 batch runs them in
-        // blocks of 512 rooms (GE_SINGLE_BLOCK = 256 / 512 / 1024 overrides, for A/B runs); a single game's rooms start at block 0,
-        // so the grid is just the rooms over the block size
-        // (profiles/r04_ab_single_block.txt, sustained us per launch at 256 / 512 / 1 024 rooms per block: Werewolf x 8 14.23 / 14.01 /
-        // 14.22 at 1 M rooms and 386 / 373 / 377 at 33 M; Werewolf x 12 34.4 / 34.6 / 37.9 at 2 M; Two-Truths x 4 10.2 / 10.2 / 10.4)
-        static const uint32_t single_block_env = [] {
-            const char *e = getenv("GE_SINGLE_BLOCK");
-            const unsigned long v = e ? strtoul(e, nullptr, 10) : 0ul;
-            return (v == 256 || v == 512 || v == 1024) ? (uint32_t)v : 0u;
-        }();
-        if (!low && b->block_threads == 256u) {
-            bt = single_block_env ? single_block_env : (b->segs[0].dev.kind == K_WW8 ? 512u : 256u);
-            grid = dim3((uint32_t)((b->segs[0].dev.rooms + bt - 1u) / bt));
-            block = dim3(bt);
-        }
-        switch (b->segs[0].dev.kind) {
-        case K_WW8: if (low) GE_LAUNCH((ge_step_kernel<K_WW8, true, false, true>), true, true); else GE_LAUNCH((ge_step_kernel<K_WW8, false, false, true>), true, false); break;
-        case K_WW12: if (low) GE_LAUNCH((ge_step_kernel<K_WW12, true, false, true>), true, true); else GE_LAUNCH((ge_step_kernel<K_WW12, false, false, true>), true, false); break;
-        case K_TT4: if (low) GE_LAUNCH((ge_step_kernel<K_TT4, true, false, true>), tt_uses_queue(4, true), true); else GE_LAUNCH((ge_step_kernel<K_TT4, false, false, true>), true, false); break;
-        case K_TT8: if (low) GE_LAUNCH((ge_step_kernel<K_TT8, true, false, true>), tt_uses_queue(8, true), true); else GE_LAUNCH((ge_step_kernel<K_TT8, false, false, true>), true, false); break;
-        default: if (low) GE_LAUNCH((ge_step_kernel<K_TT12, true, false, true>), tt_uses_queue(12, true), true); else GE_LAUNCH((ge_step_kernel<K_TT12, false, false, true>), true, false); break;
-        }
-    } else {
-        switch (b->segs[0].dev.kind) {
-        case K_WW8: if (low) GE_LAUNCH((ge_step_kernel<K_WW8, true>), true, true); else GE_LAUNCH((ge_step_kernel<K_WW8, false>), true, false); break;
-        case K_WW12: if (low) GE_LAUNCH((ge_step_kernel<K_WW12, true>), true, true); else GE_LAUNCH((ge_step_kernel<K_WW12, false>), true, false); break;
-        case K_TT4: if (low) GE_LAUNCH((ge_step_kernel<K_TT4, true>), tt_uses_queue(4, true), true); else GE_LAUNCH((ge_step_kernel<K_TT4, false>), true, false); break;
-        case K_TT8: if (low) GE_LAUNCH((ge_step_kernel<K_TT8, true>), tt_uses_queue(8, true), true); else GE_LAUNCH((ge_step_kernel<K_TT8, false>), true, false); break;
-        default: if (low) GE_LAUNCH((ge_step_kernel<K_TT12, true>), tt_uses_queue(12, true), true); else GE_LAUNCH((ge_step_kernel<K_TT12, false>), true, false); break;
-        }
+// ---- one launch of the step kernel.  What is launched is chosen from four facts, each a template argument of the kernels so that
+// every build gets its own register allocation (ge_kernels.inl): the record layout (or "mixed": several segments), LOWOCC (up to
+// one wavefront per SIMD), GENERIC (some table has a generic target condition) and SINGLE (the launch is exactly one turn).
+// [block_lo, block_hi) restricts the launch to a range of its blocks: rooms never interact, so ranges of one batch can run as
+// independent launch chains (graph_for).
+namespace {
+struct LaunchShape { dim3 grid, block; uint32_t lds; hipStream_t st; const ge_batch *b; StepArgs a; };
+
+template <class K> inline void launch_one(K kernel, const LaunchShape &L, bool queue, bool lds_low) {
+    StepArgs a = L.a;
+    const uint32_t base = step_lds_bytes(queue, lds_low, L.block.x);
+    a.cond_off = base;                                        // GENERIC builds: the literal image follows everything else in LDS
+    hipLaunchKernelGGL(kernel, L.grid, L.block, base + (L.b->generic ? L.b->cond_bytes : 0u), L.st, L.b->segs_dev, L.b->tables, a);
+}
+
+template <bool LOW, bool GEN, bool SINGLE> inline void launch_kind(uint32_t kind, const LaunchShape &L) {
+    switch (kind) {
+    case K_WW8: launch_one(ge_step_kernel<K_WW8, LOW, GEN, SINGLE>, L, true, LOW); break;
+    case K_WW12: launch_one(ge_step_kernel<K_WW12, LOW, GEN, SINGLE>, L, true, LOW); break;
+    case K_TT4: launch_one(ge_step_kernel<K_TT4, LOW, GEN, SINGLE>, L, tt_uses_queue(4, LOW), LOW); break;
+    case K_TT8: launch_one(ge_step_kernel<K_TT8, LOW, GEN, SINGLE>, L, tt_uses_queue(8, LOW), LOW); break;
+    default: launch_one(ge_step_kernel<K_TT12, LOW, GEN, SINGLE>, L, tt_uses_queue(12, LOW), LOW); break;
     }
-#undef GE_LAUNCH
+}
+template <bool LOW, bool GEN> inline void launch_kind(uint32_t kind, bool single, const LaunchShape &L) {
+    if (single) launch_kind<LOW, GEN, true>(kind, L); else launch_kind<LOW, GEN, false>(kind, L);
+}
+template <bool LOW, bool GEN> inline void launch_mixed(bool single, const LaunchShape &L) {
+    if (single) launch_one(ge_step_kernel_mixed<LOW, GEN, true>, L, true, LOW); else launch_one(ge_step_kernel_mixed<LOW, GEN, false>, L, true, LOW);
+}
+}  // namespace
+
+// rooms per block and number of blocks of a launch of n_turns turns
+static void launch_geometry(const ge_batch *b, bool low, bool single, uint32_t &bt, uint32_t &blocks) {
+    bt = b->block_threads; blocks = b->n_blocks;
+    // One turn per launch (max_fuse = 1, or the tail of a step): a block's first act is to fill its 7 KB of LDS tables behind a
+    // barrier - the fewer blocks, the less of that per launch - so a large single-game Werewolf x 8 batch runs these launches in
+    // blocks of 512 rooms (GE_SINGLE_BLOCK = 256 / 512 / 1024 overrides, for A/B runs); a single game's rooms start at block 0,
+    // so the grid is just the rooms over the block size
+    // (profiles/r04_ab_single_block.txt, sustained us per launch at 256 / 512 / 1 024 rooms per block: Werewolf x 8 14.23 / 14.01 /
+    // 14.22 at 1 M rooms and 386 / 373 / 377 at 33 M; Werewolf x 12 34.4 / 34.6 / 37.9 at 2 M; Two-Truths x 4 10.2 / 10.2 / 10.4)
+    static const uint32_t single_block_env = [] {
+        const char *e = getenv("GE_SINGLE_BLOCK");
+        const unsigned long v = e ? strtoul(e, nullptr, 10) : 0ul;
+        return (v == 256 || v == 512 || v == 1024) ? (uint32_t)v : 0u;
+    }();
+    if (single && b->segs.size() == 1 && !b->generic && !low && bt == 256u) {
+        bt = single_block_env ? single_block_env : (b->segs[0].dev.kind == K_WW8 ? 512u : 256u);
+        blocks = (uint32_t)((b->segs[0].dev.rooms + bt - 1u) / bt);
+    }
+}
+
+static bool launch_low(const ge_batch *b, const StepArgs &a) {
+    return a.lowocc != 0u && !(b->generic && b->segs.size() > 1);   // mixed batches with generic tables: the large-batch build serves every size
+}
+
+static hipError_t launch_step(const ge_batch *b, const StepArgs &a_in, hipStream_t st, uint32_t block_lo = 0u, uint32_t block_hi = ~0u) {
+    const bool single = a_in.n_turns == 1u, mixed = b->segs.size() > 1, low = launch_low(b, a_in);
+    uint32_t bt, blocks;
+    launch_geometry(b, low, single, bt, blocks);
+    if (block_hi > blocks) block_hi = blocks;
+    if (block_lo >= block_hi) return hipSuccess;
+    LaunchShape L{dim3(block_hi - block_lo), dim3(bt), 0u, st, b, a_in};
+    L.a.block_threads = bt;
+    L.a.block_off = block_lo;
+    const uint32_t kind = b->segs[0].dev.kind;
+    if (mixed) {
+        if (b->generic) launch_mixed<false, true>(single, L);
+        else if (low) launch_mixed<true, false>(single, L);
+        else launch_mixed<false, false>(single, L);
+    } else if (b->generic) {
+        if (low) launch_kind<true, true>(kind, single, L); else launch_kind<false, true>(kind, single, L);
+    } else {
+        if (low) launch_kind<true, false>(kind, single, L); else launch_kind<false, false>(kind, single, L);
+    }
     return hipGetLastError();
+}
+
+// The Werewolf x 12 side plane of prepared role deals (ge_kernels.inl run_ww): read by single-turn launches only, so it is
+// allocated when the first such launch is due - a batch that only ever runs fused launches (max_fuse > 1 and turn counts that are
+// multiples of it) never pays its 8 B per room (+20 % on a 40-byte record; 128 MiB for the whole of C4 on one GPU).
+static int ensure_deal_side(ge_batch *b) {
+    if (b->deal_side || b->deal_side_failed) return GE_OK;
+    size_t sb = 0;
+    for (Segment &s : b->segs) if (s.dev.kind == K_WW12) sb += (size_t)s.dev.rooms_padded * 8u;
+    if (!sb) { b->deal_side_failed = true; return GE_OK; }       // nothing to allocate, ever
+    int st = sync_impl(b);                                       // segs_dev is rewritten: nothing of this batch may be in flight
+    if (st != GE_OK) return st;
+    if (hipMalloc(&b->deal_side, sb) != hipSuccess) {            // a cache: without it every launch deals on the spot, as before round 4
+        (void)hipGetLastError();
+        b->deal_side = nullptr; b->deal_side_failed = true;
+        return GE_OK;
+    }
+    HIP_TRY(hipMemset(b->deal_side, 0, sb));                     // tag 0 = no deal
+    size_t off = 0;
+    SegDev host[GE_MAX_SEGMENTS];
+    memset(host, 0, sizeof host);
+    for (size_t k = 0; k < b->segs.size(); k++) {
+        Segment &s = b->segs[k];
+        if (s.dev.kind == K_WW12) {
+            s.dev.deal_side = reinterpret_cast<uint32_t *>(static_cast<char *>(b->deal_side) + off);
+            off += (size_t)s.dev.rooms_padded * 8u;
+        }
+        host[k] = s.dev;
+    }
+    HIP_TRY(hipMemcpy(b->segs_dev, host, sizeof host, hipMemcpyHostToDevice));
+    return GE_OK;
 }
 
 // A ge_batch_step call that needs many launches (small max_fuse: interactive or traced stepping) is
 // launch-bound for small batches; the sequence is captured once per n_turns into a hipGraph whose
 // launches take their first turn relative to a device word, and replayed.
 constexpr uint32_t GRAPH_MIN_LAUNCHES = 4;
+// default number of launch chains for a single-turn launch of `waves` wavefronts (A/B: profiles/r05_ab_launch_chains.txt)
+#ifndef GE_CHAINS_DEFAULT
+#define GE_CHAINS_DEFAULT(waves) 1u
+#endif
 
+
+
+// Launch chains.  A single-turn launch of a BASELINE-sized batch is two rounds of wavefronts: its load -> turn -> store pipeline
+// never reaches a steady state, and about 2.3 us of ramp and drain are exposed per launch.  Rooms never interact
+// (the reference runs one LangGraph thread per room, src/app/api/copilotkit/route.ts:24-37), so turn t + 1 of a room depends on
+// turn t of THAT room only: the batch's blocks are cut into S contiguous ranges and each range gets its own chain of launches, a
+// parallel branch of the captured graph - range A's launch drains while range B's is in its steady state.  S from the launch's
+// block count (GE_CHAINS = 1 / 2 / 4 / 8 overrides, for A/B runs; profiles/r05_ab_launch_chains.txt).
+static uint32_t chain_count(const ge_batch *b) {
+    static const uint32_t env = [] {
+        const char *e = getenv("GE_CHAINS");
+        const unsigned long v = e ? strtoul(e, nullptr, 10) : 0ul;
+        return (v == 1 || v == 2 || v == 4 || v == 8) ? (uint32_t)v : 0u;
+    }();
+    if (b->max_fuse != 1u || (b->flags & GE_FLAG_TRACE)) return 1u;
+    StepArgs a;
+    fill_args(b, a, 0u, 1u);
+    uint32_t bt, blocks;
+    launch_geometry(b, launch_low(b, a), true, bt, blocks);
+    const uint64_t waves = (uint64_t)blocks * (bt / 64u);
+    (void)waves;
+    uint32_t S = env ? env : GE_CHAINS_DEFAULT(waves);
+    while (S > 1u && blocks / S < 256u) S >>= 1;               // every chain still fills the chip: >= 256 blocks per launch
+    return S;
+}
 
 static hipGraphExec_t graph_for(ge_batch *b, uint32_t n_turns) {
     for (auto &g : b->graphs)
         if (g.first == n_turns) return g.second;
     if (!b->turn_dev && hipMalloc(reinterpret_cast<void **>(&b->turn_dev), sizeof(uint32_t)) != hipSuccess) return nullptr;
     if (!b->cap_stream && hipStreamCreateWithFlags(&b->cap_stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    const uint32_t S = chain_count(b);
+    for (uint32_t c = 1; c < S; c++) {
+        if (!b->chain_stream[c] && hipStreamCreateWithFlags(&b->chain_stream[c], hipStreamNonBlocking) != hipSuccess) return nullptr;
+        if (!b->chain_ev[c] && hipEventCreateWithFlags(&b->chain_ev[c], hipEventDisableTiming) != hipSuccess) return nullptr;
+    }
+    if (S > 1u && !b->chain_ev[0] && hipEventCreateWithFlags(&b->chain_ev[0], hipEventDisableTiming) != hipSuccess) return nullptr;
     if (hipStreamBeginCapture(b->cap_stream, hipStreamCaptureModeThreadLocal) != hipSuccess) return nullptr;
     bool ok = true;
-    for (uint32_t done = 0; done < n_turns && ok; ) {
-        const uint32_t k = (n_turns - done) < b->max_fuse ? (n_turns - done) : b->max_fuse;
-        StepArgs a;
-        fill_args(b, a, done, k);
-        a.turn_dev = b->turn_dev;
-        ok = launch_step(b, a, b->cap_stream) == hipSuccess;
-        done += k;
+    if (S > 1u) {
+        // fork: every chain's stream joins the capture behind the origin; each chain is n_turns single-turn launches over its own
+        // block range; join: the origin waits for every chain before the turn word moves on
+        StepArgs a0;
+        fill_args(b, a0, 0u, 1u);
+        uint32_t bt, blocks;
+        launch_geometry(b, launch_low(b, a0), true, bt, blocks);
+        ok = hipEventRecord(b->chain_ev[0], b->cap_stream) == hipSuccess;
+        for (uint32_t c = 1; c < S && ok; c++) ok = hipStreamWaitEvent(b->chain_stream[c], b->chain_ev[0], 0) == hipSuccess;
+        for (uint32_t c = 0; c < S && ok; c++) {
+            hipStream_t cs = c ? b->chain_stream[c] : b->cap_stream;
+            const uint32_t lo = (uint32_t)((uint64_t)blocks * c / S), hi = (uint32_t)((uint64_t)blocks * (c + 1u) / S);
+            for (uint32_t t = 0; t < n_turns && ok; t++) {
+                StepArgs a;
+                fill_args(b, a, t, 1u);
+                a.turn_dev = b->turn_dev;
+                ok = launch_step(b, a, cs, lo, hi) == hipSuccess;
+            }
+        }
+        for (uint32_t c = 1; c < S; c++) {                     // always joined, or the capture cannot end
+            const bool j = hipEventRecord(b->chain_ev[c], b->chain_stream[c]) == hipSuccess &&
+                           hipStreamWaitEvent(b->cap_stream, b->chain_ev[c], 0) == hipSuccess;
+            ok = ok && j;
+        }
+    } else {
+        for (uint32_t done = 0; done < n_turns && ok; ) {
+            const uint32_t k = (n_turns - done) < b->max_fuse ? (n_turns - done) : b->max_fuse;
+            StepArgs a;
+            fill_args(b, a, done, k);
+            a.turn_dev = b->turn_dev;
+            ok = launch_step(b, a, b->cap_stream) == hipSuccess;
+            done += k;
+        }
     }
     if (ok) {
         hipLaunchKernelGGL(ge_turn_bump, dim3(1), dim3(1), 0, b->cap_stream, b->turn_dev, n_turns);
         ok = hipGetLastError() == hipSuccess;
     }
     hipGraph_t graph = nullptr;
-    if (hipStreamEndCapture(b->cap_stream, &graph) != hipSuccess || !graph) return nullptr;   // always ends the capture
+    if (hipStreamEndCapture(b->cap_stream, &graph) != hipSuccess || !graph) { (void)hipGetLastError(); return nullptr; }   // always ends the capture
     hipGraphExec_t exec = nullptr;
     if (ok && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) exec = nullptr;
     (void)hipGraphDestroy(graph);
@@ -432,6 +533,10 @@ static int step_impl(ge_batch *b, uint32_t n_turns, void *hip_stream) {
     if (b->turn + n_turns > 0xFFFFFFFFull) return GE_ERR_RANGE;
     if ((b->flags & GE_FLAG_TRACE) && n_turns > b->max_fuse) return GE_ERR_RANGE;   // the trace holds one launch
     GE_ON_DEVICE(b);
+    if (n_turns % b->max_fuse == 1u || b->max_fuse == 1u) {   // a single-turn launch is due: its Werewolf x 12 segments take deals from the side plane
+        int ds = ensure_deal_side(b);
+        if (ds != GE_OK) return ds;
+    }
     b->last_step_turns = n_turns;
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     const uint32_t n_launch = (n_turns + b->max_fuse - 1) / b->max_fuse;
@@ -846,6 +951,8 @@ void ge_batch_destroy(ge_batch *b) {
         if (b->order_ev) (void)hipEventDestroy(b->order_ev);
         for (auto &g : b->graphs) (void)hipGraphExecDestroy(g.second);
         if (b->cap_stream) (void)hipStreamDestroy(b->cap_stream);
+        for (hipStream_t cs : b->chain_stream) if (cs) (void)hipStreamDestroy(cs);
+        for (hipEvent_t ce : b->chain_ev) if (ce) (void)hipEventDestroy(ce);
         if (b->turn_dev) (void)hipFree(b->turn_dev);
         if (b->inj_buf) (void)hipFree(b->inj_buf);
         if (b->io_buf) (void)hipHostFree(b->io_buf);

@@ -320,3 +320,45 @@ def test_werewolf_numeric_ranges_over_whole_value_ranges(dsl_ww, n):
                 b.step(chunk)
                 orc.run(rooms, seed, first, b.turn - chunk, chunk, threads=0)
                 assert_views_equal(b.read_rooms(), oracle_rooms_as_views(orc, rooms), f"ww x{n} R={R} after turn {b.turn}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,n,rooms", [("ww_generic", 8, 3000), ("ww_generic", 8, 140001), ("ww_generic", 12, 140001),
+                                          ("tt_generic", 4, 3000), ("tt_generic", 4, 140001), ("tt_generic", 9, 70001)])
+def test_generic_tables_in_single_turn_launches(name, n, rooms):
+    """max_fuse = 1 on a table with generic conditions: the GENERIC single-turn builds (round 5; until then such a batch ran the
+    fused-loop kernel for one turn), lone-wavefront and large-batch - 75 launches == the oracle, room by room."""
+    from game_engine_amd import RoomBatch
+    from oracle.oracle import Oracle
+    from parity_util import assert_views_equal, oracle_rooms_as_views
+    game, builder, rounds = dsl_variants.VARIANTS[name]
+    dsl = builder(load_dsl(game))
+    orc = Oracle(dsl, n, rounds=rounds)
+    seed, first, turns = 3, 1 << 31, 75
+    want = orc.init_rooms(rooms)
+    orc.run(want, seed, first, 0, turns, threads=0, restart=True)
+    with RoomBatch([(GameTable(dsl, rounds), n, rooms)], seed=seed, first_room=first, max_fuse=1, restart=True) as b:
+        b.step(turns)
+        assert_views_equal(b.read_rooms(), oracle_rooms_as_views(orc, want), f"{name} n={n} rooms={rooms}, single-turn launches")
+
+
+@pytest.mark.gpu
+def test_mixed_batch_with_a_generic_table_in_single_turn_launches(dsl_ww):
+    """A mixed batch one of whose tables is generic, stepped one turn per launch (the mixed GENERIC single-turn build)."""
+    from game_engine_amd import RoomBatch
+    from oracle.oracle import Oracle
+    from parity_util import assert_views_equal, oracle_rooms_as_views
+    game, builder, rounds = dsl_variants.VARIANTS["tt_generic"]
+    dsl_g = builder(load_dsl(game))
+    segs = [(GameTable(dsl_ww), 12, 50001), (GameTable(dsl_g, rounds), 4, 60000)]
+    seed, first, turns = 11, 12345, 70
+    with RoomBatch(segs, seed=seed, first_room=first, max_fuse=1, restart=True) as b:
+        b.step(turns)
+        got = b.read_rooms()
+    lo = 0
+    for (tb, n, r), (d, rd) in zip(segs, ((dsl_ww, 1), (dsl_g, rounds))):
+        orc = Oracle(d, n, rounds=rd)
+        want = orc.init_rooms(r)
+        orc.run(want, seed, first + lo, 0, turns, threads=0, restart=True)
+        assert_views_equal(got[lo:lo + r], oracle_rooms_as_views(orc, want), f"segment x{n}")
+        lo += r

@@ -472,3 +472,48 @@ def test_single_turn_launches_beyond_the_infinity_cache_equal_fused_and_oracle(g
         fz.step(turns)
         sf = fz.summary()
     assert s1 == sf and s1["rooms"] == n_rooms and s1["turn"] == turns and s1["games_recycled"] > 0
+
+
+def test_mixed_batch_single_turn_launches_full_c5_share(dsl_ww, dsl_tt):
+    """One GPU's share of C5 (524 288 Werewolf x 8 + 524 288 Two-Truths x 4) through SINGLE-TURN launches of the mixed
+    kernel's own single-turn build (one graph run = one state read + write, agent/game_agent_v2.py:1571-1587): 70 launches ==
+    70 fused turns (whole summary, checksum over every record) and windows of both segments equal the oracle."""
+    half, seed, first, turns, win = 1 << 19, 0xC0FFEE, 9 << 20, 70, 8192
+    segs = [(GameTable(dsl_ww), 8, half), (GameTable(dsl_tt), 4, half)]
+    with RoomBatch(segs, seed=seed, first_room=first, max_fuse=1, restart=True) as k1:
+        k1.step(turns)
+        s1 = k1.summary()
+        for dsl, n, base in ((dsl_ww, 8, 0), (dsl_tt, 4, half)):
+            orc = _oracle(dsl, n)
+            for lo in (base, base + half // 2 - 33, base + half - win):
+                assert_views_equal(k1.read_rooms(lo, win), oracle_batch(orc, win, seed, first + lo, turns, restart=True),
+                                   f"C5 share, x{n}: rooms {lo}.., single-turn launches")
+    with RoomBatch(segs, seed=seed, first_room=first, max_fuse=64, restart=True) as fz:
+        fz.step(turns)
+        sf = fz.summary()
+    assert s1 == sf and s1["rooms"] == 2 * half and s1["games_recycled"] > 0
+
+
+@pytest.mark.parametrize("n_rooms", [700, 140001])               # lone-wavefront and large-batch builds
+def test_mixed_batch_with_werewolf_12_single_turn_launches(dsl_ww, dsl_tt, n_rooms):
+    """A mixed batch whose single-turn launches take a Werewolf x 12 segment's role deals from the side plane (allocated by the
+    first single-turn launch): every room of every segment vs the oracle, across the plane's refill turn and restarts; a fused
+    step in between (the plane is not read) and ge_batch_set_turn (the plane is cleared) change nothing."""
+    seed, first = 5, 1 << 30
+    segs = [(GameTable(dsl_ww), 12, n_rooms), (GameTable(dsl_tt), 4, n_rooms // 2), (GameTable(dsl_ww), 8, n_rooms)]
+    plan = [(1, 40), (64, 64), (1, 35)]
+    with RoomBatch(segs, seed=seed, first_room=first, max_fuse=64, restart=True) as b:
+        t = 0
+        for fuse, turns in plan:
+            if fuse == 1:
+                for _ in range(turns):
+                    b.step(1)
+            else:
+                b.step(turns)
+            t += turns
+        got = b.read_rooms()
+    lo = 0
+    for (tb, n, r), dsl in zip(segs, (dsl_ww, dsl_tt, dsl_ww)):
+        want = oracle_batch(_oracle(dsl, n), r, seed, first + lo, t, restart=True)
+        assert_views_equal(got[lo:lo + r], want, f"mixed batch segment x{n}, {n_rooms} rooms")
+        lo += r

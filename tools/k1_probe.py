@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Single-turn launches (max_fuse = 1) in their sustained regime: device time of a replayed hipGraph of back-to-back launches
 (HIP events around the replay on the launch stream), per launch - the figure bench.py's hbm_streaming block reports.
-    python tools/k1_probe.py [game:n:rooms ...]         (launch knobs such as GE_SINGLE_BLOCK are read once per process)"""
+    python tools/k1_probe.py [game:n:rooms[+game:n:rooms] ...]     (launch knobs such as GE_SINGLE_BLOCK / GE_CHAINS are read once per
+    process; `+` joins the segments of a mixed batch)"""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -18,11 +19,14 @@ def dsl(game):
 
 stream = torch.cuda.current_stream().cuda_stream
 for spec in sys.argv[1:] or ["ww:8:1048576", "ww:12:2097152", "tt:4:1048576"]:
-    g, n, r = spec.split(":")
-    n, r = int(n), int(r)
-    launches = max(16, min(256, int(2e10 // (r * 64))))            # ~a few hundred ms of replays at most
-    b = RoomBatch([(GameTable(dsl(SHORT[g])), n, r)], seed=0xC0FFEE, max_fuse=1, restart=True)
-    bpr = b.bytes_per_room(0)
+    segs = []
+    for part in spec.split("+"):
+        g, n, r = part.split(":")
+        segs.append((GameTable(dsl(SHORT[g])), int(n), int(r)))
+    rooms = sum(x[2] for x in segs)
+    launches = max(16, min(256, int(2e10 // (rooms * 64))))        # ~a few hundred ms of replays at most
+    b = RoomBatch(segs, seed=0xC0FFEE, max_fuse=1, restart=True)
+    state = sum(b.bytes_per_room(k) * x[2] for k, x in enumerate(segs))
     b.step(256, stream); b.step(launches, stream); b.sync()
     best = None
     for _ in range(5):
@@ -31,6 +35,6 @@ for spec in sys.argv[1:] or ["ww:8:1048576", "ww:12:2097152", "tt:4:1048576"]:
         t = e0.elapsed_time(e1) * 1e3 / launches
         best = t if best is None else min(best, t)
     b.close()
-    gbs = 2 * bpr * r / best / 1e3
-    print(f"{spec:>16} block={os.environ.get('GE_SINGLE_BLOCK', 'default'):>7} {best:9.3f} us/launch sustained ({launches} per replay)  "
-          f"{gbs:7.1f} GB/s = {gbs / 80:5.1f}% of 8 TB/s", flush=True)
+    gbs = 2 * state / best / 1e3
+    print(f"{spec:>30} block={os.environ.get('GE_SINGLE_BLOCK', 'default'):>7} chains={os.environ.get('GE_CHAINS', 'default'):>7} "
+          f"{best:9.3f} us/launch sustained ({launches} per replay)  {gbs:7.1f} GB/s = {gbs / 80:5.1f}% of 8 TB/s", flush=True)
