@@ -28,9 +28,19 @@ constexpr uint32_t GOLDEN = 0x9E3779B9u;
 // the non-default value of each and runs the parity subset on it.  (What used to be A/B switches for measured-and-rejected
 // variants is gone from the source: the numbers live in profiles/r02_ab_*.txt and in git history.)
 // GE_STAMPS=1: diagnostic build (tools/stamps.py) - s_memtime stamps at points of the werewolf turn where no LDS operation
-//   is outstanding anyway, accumulated per wavefront; never in the product build
+//   is outstanding anyway, accumulated per wavefront; never in the product build.  GE_STAMPS=2: only the two clocks at a
+//   wavefront's start and end - s_memtime (shader cycles) against s_memrealtime (constant 100 MHz): the shader clock the
+//   turn loop really ran at, un-profiled (tools/clock_probe.py)
 #ifndef GE_STAMPS
 #define GE_STAMPS 0
+#endif
+// LDS bank layout A/B (round 5, profiles/r05_ab_lds_banks.txt): GE_RES_PACKED - the queue's result words of a Werewolf x 8 room 8
+//   bytes apart instead of 16; GE_ROWS_SPLIT - the block's phase rows as two arrays of 16-byte halves (lds_row)
+#ifndef GE_RES_PACKED
+#define GE_RES_PACKED 1
+#endif
+#ifndef GE_ROWS_SPLIT
+#define GE_ROWS_SPLIT 1
 #endif
 // GE_DEAL_PERIOD: role deals are prepared ahead every GE_DEAL_PERIOD-th turn (a power of two; a game is longer, and a room
 //   whose deal is not ready when it needs one deals on the spot).  8 / 16 / 32 measured: profiles/r02_ab_deal_shadow.txt
@@ -266,6 +276,20 @@ struct WaveLdsLow {
 template <bool LOWOCC> struct WaveLdsOf { using type = WaveLds; };
 template <> struct WaveLdsOf<true> { using type = WaveLdsLow; };
 
+// A phase row from the block's LDS table image.  The image keeps the rows' two 16-byte halves in two arrays (half h of row r at
+// element h * 32 + r; load_rows permutes while it copies): a wavefront's lanes read 18 or so different rows at once, and 32 bytes
+// apart rows r, r + 8, r + 16 share their banks (ds_read_b128: bank = dword address mod 64) - every row had one or two partners in
+// the shipped tables; 16 bytes apart only r and r + 16 do.
+// SPLIT = the large-batch builds (A/B, profiles/r05_ab_lds_banks.txt: with the packed results -2.2 % at 1 M Werewolf x 8 rooms,
+// -3 % on the C5 mix; a lone wavefront has no bank conflicts with itself to lose and pays 1 % for the second address).
+template <bool SPLIT>
+__device__ __forceinline__ DevRow lds_row(const DevRow *rows, uint32_t idx) {
+    if (!(SPLIT && GE_ROWS_SPLIT)) return rows[idx];
+    const uint4 *h = reinterpret_cast<const uint4 *>(rows);
+    const uint4 a = h[idx], b = h[GE_MAX_PHASES + idx];
+    return DevRow{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+}
+
 __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -291,6 +315,8 @@ struct Stamps {
     unsigned long long last, acc[4];
     __device__ __forceinline__ void start() { last = __builtin_amdgcn_s_memtime(); acc[0] = acc[1] = acc[2] = acc[3] = 0; }
     __device__ __forceinline__ void mark(int k) { const unsigned long long now = __builtin_amdgcn_s_memtime(); acc[k] += now - last; last = now; }
+    unsigned long long m0, r0;      // GE_STAMPS = 2
+    __device__ __forceinline__ void clocks_start() { m0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
 };
 
 // candidate choice of one bot action (POLICY.md §3); shared by the per-lane loop and the queue.
@@ -596,6 +622,35 @@ __device__ __forceinline__ uint32_t eval_cond_image(const CondCtx &cc, uint32_t 
     return T & all;
 }
 
+// The same for a table whose shape is known when the kernel is built (the GENERIC template argument of the Two-Truths kernels: 2 =
+// 1 clause x 1 literal, 3 = 1 x 2 - what a generated DSL's conditions mostly are; ge_step.hip picks the build from
+// DevTable::cond_shape, the rolled loop above serves every other shape): no loop, no scalar counter, every slot's LDS read in
+// flight before the first literal is evaluated, clause ends known statically.  A Two-Truths turn is ~270 instructions, of which
+// the rolled walk of two slots was ~60: x 1.27 -> x 1.24 of the shipped game's time (profiles/r05_generic_probe.txt).  A 2 x 2
+// form was built and measured too: 20 - 43 scalar spills and no gain (x 1.61 either way) - such tables take the rolled walk.
+template <int STRIDE, int NCL, int LEN, typename LIT>
+__device__ __forceinline__ uint32_t eval_cond_image_fixed(const CondCtx &cc, uint32_t row_r0, uint32_t all, LIT lit) {
+    constexpr uint32_t n = NCL * LEN;
+    static_assert(n <= 8, "slot flags of a fixed shape come from the low words");
+    const unsigned char *p = cc.img + ((row_r0 >> ROW_COND_SLOT_SHIFT) & 31u) * (n * (uint32_t)STRIDE);
+    uint4 d[n];
+#pragma unroll
+    for (uint32_t i = 0; i < n; i++) d[i] = *reinterpret_cast<const uint4 *>(p + i * STRIDE);
+    uint32_t T = 0;
+#pragma unroll
+    for (uint32_t c = 0; c < (uint32_t)NCL; c++) {
+        uint32_t m = all;
+#pragma unroll
+        for (uint32_t l = 0; l < (uint32_t)LEN; l++) {
+            const uint32_t i = c * LEN + l;
+            const uint32_t x = lit(d[i], make_uint4(0u, 0u, 0u, 0u), (cc.cs.g_lo >> (4u * i)) & 15u, (cc.cs.f_lo >> (4u * i)) & 15u);
+            m &= x ^ (d[i].x >> 16);
+        }
+        T |= m;
+    }
+    return T & all;
+}
+
 // (an input made opaque INSIDE the block that uses it: the compare's loop-invariant half - a third of its instructions - is
 // otherwise hoisted in front of the loop and runs every turn, whether or not any slot of the table compares that field)
 __device__ __forceinline__ uint32_t pin(uint32_t v) { asm volatile("" : "+v"(v)); return v; }
@@ -637,9 +692,10 @@ template <int NB> __device__ __forceinline__ uint32_t ww_cond_generic(const WWR<
     });
 }
 
-template <int NB> __device__ __forceinline__ uint32_t tt_cond_generic(const TT<NB> &s, const CondCtx &cc, uint32_t row_r0, uint32_t all) {
+// GSHAPE: the GENERIC template argument - 1 = any shape (rolled walk), 2 / 3 = the table is 1 x 1 / 1 x 2
+template <int NB, int GSHAPE = 1> __device__ __forceinline__ uint32_t tt_cond_generic(const TT<NB> &s, const CondCtx &cc, uint32_t row_r0, uint32_t all) {
     const uint32_t W0 = s.speaker | (s.submitted << 16), W1 = s.revealed | (s.can_vote << 16), W2 = s.has_voted;
-    return eval_cond_image<(int)sizeof(CondLit)>(cc, row_r0, all, [&](const uint4 &d, const uint4 &, uint32_t g, uint32_t flds) -> uint32_t {
+    auto literal = [&](const uint4 &d, const uint4 &, uint32_t g, uint32_t flds) -> uint32_t {
         // wave-uniform: what the slot holds in some row of the table - a base set, and / or a range over which fields
         const bool any_base = g & 1u, any_conj = g & 8u;
         uint32_t x = 0;
@@ -667,7 +723,10 @@ template <int NB> __device__ __forceinline__ uint32_t tt_cond_generic(const TT<N
                 x = bfi(bit_mask(d.x, 7u), range_nibbles<NB>(NB <= 8 ? (uint64_t)pin((uint32_t)s.rounds) : ((uint64_t)pin((uint32_t)(s.rounds >> 32)) << 32) | pin((uint32_t)s.rounds), d.y, d.z), x);
         }
         return x;
-    });
+    };
+    if (GSHAPE == 2) return eval_cond_image_fixed<(int)sizeof(CondLit), 1, 1>(cc, row_r0, all, literal);
+    if (GSHAPE == 3) return eval_cond_image_fixed<(int)sizeof(CondLit), 1, 2>(cc, row_r0, all, literal);
+    return eval_cond_image<(int)sizeof(CondLit)>(cc, row_r0, all, literal);
 }
 
 // ------------------------------------------------------------------ werewolf
@@ -696,7 +755,7 @@ struct WwCtx {
 // The 12 base predicates live packed in s.W; the row carries byte-permute selectors that pull each term's mask out of
 // the word pairs (0xFF where the term is elsewhere / absent), so the condition is 2-3 v_perm + AND, XOR with the
 // negation mask, and a fold of the term bytes (ge_layout.h DevRow).
-template <int NB, bool LOWOCC, bool GENERIC>
+template <int NB, bool LOWOCC, int GENERIC>
 __device__ __forceinline__ uint32_t ww_targets(const WWR<NB> &s, const DevRow &row, const WwCtx &c, uint32_t alive, uint32_t ALL) {
     using R = WWR<NB>;
     const uint32_t comp = row.r0 & 3u, nterms = (row.r0 >> 8) & 7u;
@@ -805,7 +864,11 @@ __device__ __forceinline__ void ww_queue_actions(WWR<NB> &s, const WwCtx &c, uin
     const uint32_t kind = B::ONEHOT ? ((1u << act) >> 1) : act;          // one-hot: ACT_WOLF_TARGET = 1 -> bit 0 ...
     const uint4 ctx = B::ORD ? make_uint4(alive | (team_w << 16) | (kind << 28), ky | (lo_kw << 8) | (off << 16) | (lane << 26), ord, tk)
                              : make_uint4(alive | (team_w << 16) | (act << 28), ky | (lo_kw << 16), todo | (off << 16) | (lane << 26), tk);
-    if (NB <= 8) *reinterpret_cast<uint2 *>(&lw->res[lane]) = make_uint2(0u, 0u);     // only x, y come back
+    // N <= 8: only x, y come back - the results sit 8 bytes apart (GE_RES_PACKED; 16 bytes apart, a 64-bit access of 16 consecutive
+    // lanes hits every bank twice: /opt/skills/guides/MI355X_MICROARCH.md "LDS", ds_write_b64 / ds_read_b64 banking)
+    constexpr uint32_t RW = (NB <= 8 && GE_RES_PACKED) ? 2u : 4u;      // words per room in `res`
+    uint32_t *const res_w = reinterpret_cast<uint32_t *>(lw->res);
+    if (NB <= 8) *reinterpret_cast<uint2 *>(res_w + RW * lane) = make_uint2(0u, 0u);
     else lw->res[lane] = make_uint4(0u, 0u, 0u, 0u);
     // Queue slot -> owning room.  A room with cnt due bots owns slots [off, off + cnt); it writes
     // NB slots from `off` on, highest first (immediate offsets, no per-slot address or
@@ -848,7 +911,7 @@ __device__ __forceinline__ void ww_queue_actions(WWR<NB> &s, const WwCtx &c, uin
     // round's read is issued, so nothing of the queue is in flight behind it
     for (uint32_t base = 0;; base += 64u) {
         const uint32_t k = base + lane;
-        if (GE_STAMPS && stamps && base == 0u) { asm volatile("" :: "v"(c4.x)); stamps->mark(1); }   // [.. first slot in registers]
+        if (GE_STAMPS == 1 && stamps && base == 0u) { asm volatile("" :: "v"(c4.x)); stamps->mark(1); }   // [.. first slot in registers]
         uint32_t L, i, know, lokw;
         if (B::ORD) {
             L = c4.y >> 26;
@@ -870,13 +933,13 @@ __device__ __forceinline__ void ww_queue_actions(WWR<NB> &s, const WwCtx &c, uin
                                     : ww_choose<NB, false>(c4.x >> 28, i, d, c4.x & 0xFFFFu, (c4.x >> 16) & 0xFFFu, know, lokw, know, c.nth8);
             if (B::PIN_CHOICE) asm volatile("" : "+v"(ch));   // stays outside the exec-masked block below
             if (go) {
-                uint32_t *r = reinterpret_cast<uint32_t *>(&lw->res[L]);
+                uint32_t *r = res_w + RW * L;
                 if (!B::ONE_ATOMIC) atomicOr(r, 1u << i);
                 atomicOr(r + 1 + (i >> 3), ch << (4u * (i & 7u)));
             }
         } else if (go) {
             const uint32_t ch = ww_choose<NB, true>(c4.x >> 28, i, d, c4.x & 0xFFFFu, (c4.x >> 16) & 0xFFFu, know, lokw, know, c.nth8);
-            uint32_t *r = reinterpret_cast<uint32_t *>(&lw->res[L]);
+            uint32_t *r = res_w + RW * L;
             atomicOr(r, 1u << i);
             atomicOr(r + 1 + (i >> 3), ch << (4u * (i & 7u)));
         }
@@ -884,7 +947,7 @@ __device__ __forceinline__ void ww_queue_actions(WWR<NB> &s, const WwCtx &c, uin
         c4 = fetch(k + 64u);
     }
     wave_sync();
-    const uint4 r = NB <= 8 ? make_uint4(reinterpret_cast<const uint2 *>(&lw->res[lane])->x, reinterpret_cast<const uint2 *>(&lw->res[lane])->y, 0u, 0u)
+    const uint4 r = NB <= 8 ? make_uint4(reinterpret_cast<const uint2 *>(res_w + RW * lane)->x, reinterpret_cast<const uint2 *>(res_w + RW * lane)->y, 0u, 0u)
                             : lw->res[lane];
     if (B::SHADOW) {                                       // shadow of the result read
         shadow2();
@@ -893,7 +956,7 @@ __device__ __forceinline__ void ww_queue_actions(WWR<NB> &s, const WwCtx &c, uin
         asm volatile("" :: "v"(c4.x), "v"(c4.y), "v"(c4.z), "v"(c4.w));
     }
     uint32_t newly = r.x;
-    if (GE_STAMPS && stamps) { asm volatile("" :: "v"(newly)); stamps->mark(2); }                 // [.. results in registers]
+    if (GE_STAMPS == 1 && stamps) { asm volatile("" :: "v"(newly)); stamps->mark(2); }                 // [.. results in registers]
     const nib_t got = NB > 8 ? (nib_t)(((uint64_t)r.z << 32) | r.y) : (nib_t)r.y;
     nib_t m15;                                       // nibble mask of the players who acted now
     if (B::TABLE && !B::ONE_ATOMIC) {                // large-batch builds: the go mask through the spread8 table (see plurality)
@@ -997,7 +1060,7 @@ __device__ __forceinline__ void ww_apply_effect(WWR<NB> &s, const DevRow &row, c
 // build leaves it as it is: nobody reads it after the turn).
 // tk_io: in = turn_key(rkey, turn), out = the next turn's key (computed in an LDS wait shadow; not in a single-turn build).
 // ev_*: this turn's logged actions (who acted, what they chose) for the optional event trace.
-template <int NB, bool LOWOCC, bool GENERIC = false, bool SINGLE = false>
+template <int NB, bool LOWOCC, int GENERIC = false, bool SINGLE = false>
 __device__ __forceinline__ void ww_turn(WWR<NB> &s, DevRow &row, const WwCtx &c, uint32_t turn, uint32_t &tk_io, bool trace, Deal &deal, bool deal_now,
                                         uint32_t &ev_newly, uint64_t &ev_choice, Stamps *stamps = nullptr) {
     using R = WWR<NB>;
@@ -1008,7 +1071,7 @@ __device__ __forceinline__ void ww_turn(WWR<NB> &s, DevRow &row, const WwCtx &c,
     const bool night = act >= ACT_WOLF_TARGET && act <= ACT_DETECTIVE;
 
     const uint32_t T = ww_targets<NB, LOWOCC, GENERIC>(s, row, c, alive, ALL);
-    if (GE_STAMPS && stamps) { asm volatile("" :: "v"(T)); stamps->mark(0); }        // [end of previous turn .. row in registers]
+    if (GE_STAMPS == 1 && stamps) { asm volatile("" :: "v"(T)); stamps->mark(0); }        // [end of previous turn .. row in registers]
 
     WwBranch br;
     R dealt;
@@ -1052,7 +1115,7 @@ __device__ __forceinline__ void ww_turn(WWR<NB> &s, DevRow &row, const WwCtx &c,
     if (SINGLE) {
         if ((qe & 31u) != s.phase) ww_apply_effect<NB, LOWOCC, true>(s, row, row, c, qe, alive, ALL, turn, deal, dealt);
     } else if ((qe & 31u) != s.phase) {
-        const DevRow qrow = c.rows[qe & 31u];                  // LDS read in flight during the effect: first used at its end
+        const DevRow qrow = lds_row<!LOWOCC>(c.rows, qe & 31u);         // LDS read in flight during the effect: first used at its end
         ww_apply_effect<NB, LOWOCC, false>(s, row, qrow, c, qe, alive, ALL, turn, deal, dealt);
         row = qrow;
     }
@@ -1071,7 +1134,7 @@ template <int NB> __device__ __forceinline__ uint32_t tt_done_mask(uint64_t roun
 // QUEUE: bot actions through the wavefront work queue (see ww_turn) - pays from 8 players on, where the
 // first turn of a vote has 7-11 due bots in some room of every wavefront; TABLE: n-th-set-bit from LDS
 // SINGLE: a one-turn launch - the row the room moves to is not fetched (only whether it is terminal: term_mask)
-template <int NB, bool QUEUE, bool TABLE, bool GENERIC = false, bool SINGLE = false>
+template <int NB, bool QUEUE, bool TABLE, int GENERIC = false, bool SINGLE = false>
 __device__ __forceinline__ void tt_turn(TT<NB> &s, uint32_t &done, DevRow &row, const DevRow *rows, const CondCtx &cc, void *wave_lds, const uint8_t *nth8,
                                         bool valid, uint32_t n, uint32_t rounds,
                                         uint32_t phase0_idx, uint32_t rkey, uint32_t turn,
@@ -1104,7 +1167,7 @@ __device__ __forceinline__ void tt_turn(TT<NB> &s, uint32_t &done, DevRow &row, 
         T = X & ALL;
     }
     if (generic_row && comp == COMP_ACTION)                    // the clause form (see ww_turn)
-        T = tt_cond_generic<NB>(s, cc, row.r0, ALL);
+        T = tt_cond_generic<NB, GENERIC>(s, cc, row.r0, ALL);
 
     uint32_t newly = 0;
     {
@@ -1197,7 +1260,7 @@ __device__ __forceinline__ void tt_turn(TT<NB> &s, uint32_t &done, DevRow &row, 
     if (q == s.phase) return;
 
     DevRow qrow = row;
-    if (!SINGLE) qrow = rows[q];                               // in flight during the effect (see ww_turn)
+    if (!SINGLE) qrow = lds_row<TABLE>(rows, q);                      // in flight during the effect (see ww_turn)
     const uint32_t eff = qe >> 5;
     if (eff == EFF_TT_ROUND_START) {
         const uint32_t cand = ALL & ~done;                     // lowest id that has not spoken R rounds yet

@@ -31,7 +31,6 @@ struct StepArgs {
     unsigned long long *stamps; // GE_STAMPS diagnostic build: 4 segment sums + wave-turn count (else null)
     uint32_t n_seg, turn0, n_turns, seed_key, block_threads, restart, trace, lowocc;
     uint32_t cond_off;         // GENERIC builds: byte offset of the literal image (DevTable::cond_img) in a block's LDS, behind everything else
-    uint32_t block_off;        // the launch covers blocks [block_off, block_off + gridDim.x) of the batch (launch chains, ge_step.hip graph_for)
     uint32_t block_begin[GE_MAX_SEGMENTS];
 };
 
@@ -101,7 +100,7 @@ constexpr uint32_t LDS_S0 = 128;       // 20 words of init_regs, padded
 // element per thread and pass.  All passes' loads are issued before the first LDS write (a load -> wait -> write loop
 // serialises one L2 round trip per pass in front of every wavefront of a single-turn launch); the large-batch builds also
 // copy the restart template behind the image.
-template <uint32_t N16, bool WITH_S0, bool GENERIC = false>
+template <uint32_t N16, bool WITH_S0, int GENERIC = false, bool SPLIT = false>
 __device__ __forceinline__ void load_rows(DevRow *rows, const DevTable *tables, uint32_t table_idx, const SegDev *sg, uint32_t cond_off = 0u) {
     const u32x4 *src = reinterpret_cast<const u32x4 *>(tables + table_idx);
     if (GENERIC) {
@@ -113,22 +112,24 @@ __device__ __forceinline__ void load_rows(DevRow *rows, const DevTable *tables, 
     }
     u32x4 *dst = reinterpret_cast<u32x4 *>(rows);
     const uint32_t bd = blockDim.x, tid = threadIdx.x;
+    // element i of the image -> where it goes in LDS: the phase rows' halves into two arrays (ge_device.h lds_row), the rest as is
+    auto at = [](uint32_t i) -> uint32_t { return (SPLIT && GE_ROWS_SPLIT && i < 2u * GE_MAX_PHASES) ? ((i & 1u) * GE_MAX_PHASES + (i >> 1)) : i; };
     // the restart template behind the image (large-batch turn loops; a single-turn build reads it through the scalar cache)
     const u32x4 t0 = WITH_S0 ? reinterpret_cast<const u32x4 *>(sg->init_regs)[tid < 5u ? tid : 4u] : u32x4{0u, 0u, 0u, 0u};
     if (bd >= 512u) {                                          // wave-uniform: a single-turn launch's larger block - one pass (N16 <= 448)
         const u32x4 t = src[tid < N16 ? tid : N16 - 1u];
-        if (tid < N16) dst[tid] = t;
+        if (tid < N16) dst[at(tid)] = t;
     } else if (bd == 256u) {                                   // the block size of every large batch
         constexpr uint32_t P = (N16 + 255u) / 256u;
         u32x4 t[P];
 #pragma unroll
         for (uint32_t p = 0; p < P; p++) { const uint32_t i = p * 256u + tid; t[p] = src[i < N16 ? i : N16 - 1u]; }   // loads are not predicated (clamped index)
 #pragma unroll
-        for (uint32_t p = 0; p < P; p++) { const uint32_t i = p * 256u + tid; if (i < N16) dst[i] = t[p]; }
+        for (uint32_t p = 0; p < P; p++) { const uint32_t i = p * 256u + tid; if (i < N16) dst[at(i)] = t[p]; }
     } else {
         for (uint32_t base = 0; base < N16; base += bd) {
             const uint32_t i = base + tid;
-            if (i < N16) dst[i] = src[i];
+            if (i < N16) dst[at(i)] = src[i];
         }
     }
     if (WITH_S0 && tid < 5u) dst[IMG_END / 16u + tid] = t0;
@@ -161,7 +162,7 @@ __device__ __forceinline__ void load_init_regs(const SegDev &sg, uint32_t *ir) {
 // (profiles/r03_ab_deal_period_12.txt: every 16th / 32nd / 64th turn = 18.37 / 18.21 / 19.53 us per turn at 2 M x 12)
 template <int NB> constexpr uint32_t deal_period() { return NB <= 8 ? GE_DEAL_PERIOD : 2u * GE_DEAL_PERIOD; }
 
-template <int NB, bool LOWOCC, bool GENERIC, bool SINGLE>
+template <int NB, bool LOWOCC, int GENERIC, bool SINGLE>
 __device__ __forceinline__ void run_ww(const SegDev *__restrict__ sgp, const StepArgs &a, DevRow *rows, void *lw,
                                        uint8_t *nth8, const DevTable *__restrict__ tables, uint64_t room_in) {
     const SegDev &sg = *sgp;
@@ -175,7 +176,7 @@ __device__ __forceinline__ void run_ww(const SegDev *__restrict__ sgp, const Ste
     load_words<L::WORDS, (NB > 8)>(sg.base, sg.rooms_padded, room, w);   // in flight while the block fills its LDS tables; streaming: see load_words
     // the slot -> player table of the action queue sits right behind the phase rows (step_lds_bytes)
     uint32_t *ord8 = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(rows) + LDS_ROWS);
-    load_rows<B::TABLE ? IMG_END / 16u : B::ORD ? 128u : 64u, !LOWOCC && !SINGLE, GENERIC>(rows, tables, sg.table_idx, sgp, a.cond_off);
+    load_rows<B::TABLE ? IMG_END / 16u : B::ORD ? 128u : 64u, !LOWOCC && !SINGLE, GENERIC, !LOWOCC>(rows, tables, sg.table_idx, sgp, a.cond_off);
     WWR<NB> s;
     uint32_t cache;
     if (NB <= 8 && !SINGLE) {
@@ -224,7 +225,7 @@ __device__ __forceinline__ void run_ww(const SegDev *__restrict__ sgp, const Ste
     const uint32_t deal_phase = NB <= 8 ? turn0 : 0u;
     uint32_t tk = turn_key(rk, turn0);                        // this turn's key; ww_turn leaves the next turn's (computed in an LDS wait shadow)
     Stamps stamps;
-    if (GE_STAMPS) stamps.start();
+    if (GE_STAMPS) { stamps.start(); stamps.clocks_start(); }
     const WwCtx ctx = {rows, CondCtx{reinterpret_cast<const unsigned char *>(rows) + a.cond_off, cs}, lw, nth8, ord8, valid, sg.n_players, sg.nw, sg.phase0_idx, rk, sg.human_mask, term_mask};
     if constexpr (SINGLE) {
         // one turn, no loop: the row is fetched after the restart decision (terminal rows are a bit mask), nothing is
@@ -236,7 +237,7 @@ __device__ __forceinline__ void run_ww(const SegDev *__restrict__ sgp, const Ste
             s.games = g < 0xFFFFu ? g + 1u : g;
             restarted = 1;
         }
-        DevRow row = rows[s.phase];
+        DevRow row = lds_row<!LOWOCC>(rows, s.phase);
         const uint32_t p = s.phase;
         uint32_t ev_newly = 0;
         uint64_t ev_choice = 0;
@@ -271,10 +272,10 @@ __device__ __forceinline__ void run_ww(const SegDev *__restrict__ sgp, const Ste
         }
         if (trace && valid) store_event(sg.trace, sg.rooms_padded, 0u, room, turn0, p, s.phase, restarted, ev_newly, ev_choice);
     } else {
-        DevRow row = rows[s.phase];
+        DevRow row = lds_row<!LOWOCC>(rows, s.phase);
         WWR<NB> s0;
         DevRow row0 = row;
-        if (LOWOCC) { s0 = fresh_room(); row0 = rows[sg.phase0_idx]; }
+        if (LOWOCC) { s0 = fresh_room(); row0 = lds_row<!LOWOCC>(rows, sg.phase0_idx); }
         // the turn loop; the lone-wavefront build compiles it once per trace setting: the event-trace branches (two per turn,
         // both wave-uniform and almost always taken) cost a lone wavefront an instruction-fetch bubble each
         auto turns = [&](auto trace_c) {
@@ -286,7 +287,7 @@ __device__ __forceinline__ void run_ww(const SegDev *__restrict__ sgp, const Ste
                     const uint32_t g = s.games;
                     s = LOWOCC ? s0 : fresh_room();
                     s.games = g < 0xFFFFu ? g + 1u : g;
-                    row = LOWOCC ? row0 : rows[ctx.phase0_idx];
+                    row = LOWOCC ? row0 : lds_row<!LOWOCC>(rows, ctx.phase0_idx);
                     restarted = 1;
                 }
                 const uint32_t p = s.phase;
@@ -307,6 +308,16 @@ __device__ __forceinline__ void run_ww(const SegDev *__restrict__ sgp, const Ste
         stamps.mark(3);
         for (int k = 0; k < 4; k++) atomicAdd(a.stamps + k, stamps.acc[k]);
         atomicAdd(a.stamps + 4, (unsigned long long)a.n_turns);
+        atomicAdd(a.stamps + 5, (unsigned long long)(__builtin_amdgcn_s_memtime() - stamps.m0));       // a wavefront's life in shader cycles ...
+        const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+        atomicAdd(a.stamps + 6, (unsigned long long)(r1 - stamps.r0));                                 // ... and in 100 MHz ticks
+        if (GE_STAMPS == 2 && a.n_turns >= 256u) {
+            // the launch's timeline: per wavefront {start, end} on the chip-wide 100 MHz clock and where it ran (HW_ID, XCC_ID)
+            unsigned long long *log = a.stamps + 8 + 4ull * (((unsigned long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+            log[0] = stamps.r0; log[1] = r1;
+            log[2] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+            log[3] = __builtin_amdgcn_s_memtime() - stamps.m0;
+        }
     }
     if (!valid) return;
     ww_store_regs<NB>(s, deal_to_cache<NB, B::DEAL_FORM>(deal, s), w);
@@ -321,7 +332,7 @@ __device__ __forceinline__ void run_ww(const SegDev *__restrict__ sgp, const Ste
 #endif
 constexpr bool tt_uses_queue(int nb, bool lowocc) { return !lowocc || nb >= GE_TT_LOW_QUEUE_MIN; }
 
-template <int NB, bool LOWOCC, bool GENERIC, bool SINGLE>
+template <int NB, bool LOWOCC, int GENERIC, bool SINGLE>
 __device__ __forceinline__ void run_tt(const SegDev *__restrict__ sgp, const StepArgs &a, DevRow *rows, void *lw, uint8_t *nth8,
                                        const DevTable *__restrict__ tables, uint64_t room_in) {
     constexpr bool QUEUE = tt_uses_queue(NB, LOWOCC);
@@ -331,7 +342,7 @@ __device__ __forceinline__ void run_tt(const SegDev *__restrict__ sgp, const Ste
     const uint64_t room = valid ? room_in : 0;
     uint32_t w[L::WORDS];
     load_words<L::WORDS, true>(sg.base, sg.rooms_padded, room, w);
-    load_rows<(QUEUE && !LOWOCC) ? 256u : 64u, QUEUE && !LOWOCC && !SINGLE, GENERIC>(rows, tables, sg.table_idx, sgp, a.cond_off);
+    load_rows<(QUEUE && !LOWOCC) ? 256u : 64u, QUEUE && !LOWOCC && !SINGLE, GENERIC, !LOWOCC>(rows, tables, sg.table_idx, sgp, a.cond_off);
     TT<NB> s;
     L::unpack(w, s);
     const uint32_t rk = room_key_from(a.seed_key, sg.first_global + room);
@@ -369,24 +380,24 @@ __device__ __forceinline__ void run_tt(const SegDev *__restrict__ sgp, const Ste
             done = done0;
             restarted = 1;
         }
-        DevRow row = rows[s.phase];
+        DevRow row = lds_row<!LOWOCC>(rows, s.phase);
         const uint32_t p = s.phase;
         uint32_t ev_newly = 0;
         uint64_t ev_choice = 0;
         tt_turn<NB, QUEUE, !LOWOCC, GENERIC, true>(s, done, row, rows, cc, lw, nth8, valid, sg.n_players, sg.rounds, sg.phase0_idx, rk, turn0, a.trace != 0u, sg.human_mask, term_mask, ev_newly, ev_choice);
         if (a.trace && valid) store_event(sg.trace, sg.rooms_padded, 0u, room, turn0, p, s.phase, restarted, ev_newly, ev_choice);
     } else {
-        DevRow row = rows[s.phase];
+        DevRow row = lds_row<!LOWOCC>(rows, s.phase);
         TT<NB> s0;
         DevRow row0 = row;
-        if (LOWOCC) { s0 = fresh_room(); row0 = rows[sg.phase0_idx]; }
+        if (LOWOCC) { s0 = fresh_room(); row0 = lds_row<!LOWOCC>(rows, sg.phase0_idx); }
         for (uint32_t t = 0; t < a.n_turns; t++) {
             uint32_t restarted = 0;
             if (a.restart && ((row.r0 >> 11) & 7u) == 0u) {
                 const uint32_t g = s.games;
                 s = LOWOCC ? s0 : fresh_room();
                 s.games = g < 0xFFFFu ? g + 1u : g;
-                row = LOWOCC ? row0 : rows[sg.phase0_idx];
+                row = LOWOCC ? row0 : lds_row<!LOWOCC>(rows, sg.phase0_idx);
                 done = done0;
                 restarted = 1;
             }
@@ -407,7 +418,7 @@ __device__ __forceinline__ void run_tt(const SegDev *__restrict__ sgp, const Ste
 // Two-Truths batch diverges per block, never inside a wavefront.  Segment descriptors live in
 // device memory and are read with a block-uniform index (scalar loads): indexing the kernel
 // arguments dynamically would push them through scratch.
-template <int KIND, bool LOWOCC, bool GENERIC, bool SINGLE = false>
+template <int KIND, bool LOWOCC, int GENERIC, bool SINGLE = false>
 __device__ __forceinline__ void run_kind(const SegDev *__restrict__ sg, const StepArgs &a, DevRow *rows, void *lw,
                                          uint8_t *nth8, const DevTable *__restrict__ tables, uint64_t room) {
     if (KIND == K_WW8) run_ww<8, LOWOCC, GENERIC, SINGLE>(sg, a, rows, lw, nth8, tables, room);
@@ -434,7 +445,7 @@ extern __shared__ __align__(16) unsigned char ge_lds[];
 
 // single-kind batch (the benchmark configurations): one instantiation per record layout, so each
 // gets its own register allocation
-// GENERIC: some row of the table has a generic target condition (DevCond); single-game batches get both forms of those
+// GENERIC (0 / 1; Two-Truths fused builds also 2 / 3 = the table's shape is 1 x 1 / 1 x 2, ge_device.h tt_cond_generic): some row of the table has a generic target condition (DevCond); single-game batches get both forms of those
 // builds as well, a mixed batch with a generic table runs the large-batch form at every size
 // Minimum wavefronts per SIMD asked of the register allocator for the large-batch Werewolf builds (tuning constants;
 // tools/ab_switches.sh builds other values).  Werewolf x 12: 7 = 72 VGPRs, no scratch (round 2 held it to 6 = 80 VGPRs with a
@@ -450,24 +461,28 @@ extern __shared__ __align__(16) unsigned char ge_lds[];
 #define GE_GENERIC_WAVES 1
 #endif
 // SINGLE: the launch is one turn (a.n_turns == 1) (run_ww / run_tt)
-template <int KIND, bool LOWOCC, bool GENERIC = false, bool SINGLE = false>
-__global__ void __launch_bounds__(SINGLE ? 1024 : 256, SINGLE ? 8 : (!LOWOCC && GENERIC) ? GE_GENERIC_WAVES : (KIND == K_WW12 && !LOWOCC) ? GE_WW12_WAVES : (KIND == K_WW8 && !LOWOCC) ? GE_WW8_WAVES : 1) ge_step_kernel(const SegDev *__restrict__ segs, const DevTable *__restrict__ tables, const StepArgs a) {
+template <int KIND, bool LOWOCC, int GENERIC, bool SINGLE>
+__device__ __forceinline__ void step_body(const SegDev *__restrict__ segs, const DevTable *__restrict__ tables, const StepArgs &a) {
     constexpr bool WWK = KIND == K_WW8 || KIND == K_WW12 || tt_uses_queue(KIND == K_TT4 ? 4 : KIND == K_TT8 ? 8 : 12, LOWOCC);   // uses the action queue
     DevRow *rows = reinterpret_cast<DevRow *>(ge_lds);
     uint8_t *nth8 = ge_lds + LDS_ROWS + LDS_ORD8;
     auto *wl = reinterpret_cast<typename WaveLdsOf<LOWOCC>::type *>(ge_lds + LDS_ROWS + LDS_ORD8 + (LOWOCC ? 0u : LDS_NTH8 + LDS_S0));
-    const uint64_t room = (uint64_t)(blockIdx.x + a.block_off) * blockDim.x + threadIdx.x;
+    const uint64_t room = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     run_kind<KIND, LOWOCC, GENERIC, SINGLE>(segs, a, rows, WWK ? &wl[threadIdx.x >> 6] : nullptr, nth8, tables, room);
+}
+template <int KIND, bool LOWOCC, int GENERIC = false, bool SINGLE = false>
+__global__ void __launch_bounds__(SINGLE ? 1024 : 256, SINGLE ? 8 : (!LOWOCC && GENERIC) ? GE_GENERIC_WAVES : (KIND == K_WW12 && !LOWOCC) ? GE_WW12_WAVES : (KIND == K_WW8 && !LOWOCC) ? GE_WW8_WAVES : 1) ge_step_kernel(const SegDev *__restrict__ segs, const DevTable *__restrict__ tables, const StepArgs a) {
+    step_body<KIND, LOWOCC, GENERIC, SINGLE>(segs, tables, a);
 }
 
 // mixed batch: several segments (games / player counts) in one launch.  SINGLE: the launch is one turn - each kind's single-turn
 // form (no turn loop, the restart template through the scalar cache, Werewolf x 12 deals from the side plane), 8 wavefronts per SIMD
-template <bool LOWOCC, bool GENERIC = false, bool SINGLE = false>
+template <bool LOWOCC, int GENERIC = false, bool SINGLE = false>
 __global__ void __launch_bounds__(256, SINGLE ? 8 : !LOWOCC ? (GENERIC ? GE_GENERIC_WAVES : GE_WW12_WAVES) : 1) ge_step_kernel_mixed(const SegDev *__restrict__ segs, const DevTable *__restrict__ tables, const StepArgs a) {
     DevRow *rows = reinterpret_cast<DevRow *>(ge_lds);
     uint8_t *nth8 = ge_lds + LDS_ROWS + LDS_ORD8;
     auto *wl = reinterpret_cast<typename WaveLdsOf<LOWOCC>::type *>(ge_lds + LDS_ROWS + LDS_ORD8 + (LOWOCC ? 0u : LDS_NTH8 + LDS_S0));
-    const uint32_t bid = blockIdx.x + a.block_off;
+    const uint32_t bid = blockIdx.x;
     uint32_t si = 0;
     for (uint32_t k = 1; k < a.n_seg; k++)
         if (bid >= a.block_begin[k]) si = k;

@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <atomic>
 #include <new>
+#include <string>
 #include <thread>
 #include <type_traits>
 #include <vector>
@@ -60,6 +61,7 @@ struct ge_batch {
     unsigned long long *sum_dev = nullptr;
     hipStream_t last_stream = nullptr;
     bool generic = false;             // some phase has a generic target condition: the GENERIC kernel builds are launched
+    uint32_t gshape = 0;              // ... a single Two-Truths table whose conditions all fit 1 x 1 / 1 x 2 literal slots: 2 / 3 = the shape-specialised fused builds
     uint32_t cond_bytes = 0;          // ... and their blocks keep this much of literal image in LDS (the largest table's)
     bool pending = false;             // work was queued on last_stream since the last synchronisation
     hipEvent_t order_ev = nullptr;    // orders a step on a new stream behind the previous stream's work
@@ -72,8 +74,6 @@ struct ge_batch {
     uint32_t *turn_dev = nullptr;     // turn base the captured launches read
     uint64_t turn_dev_value = ~0ull;  // what *turn_dev holds (host mirror)
     hipStream_t cap_stream = nullptr; // capture needs a non-default stream
-    hipStream_t chain_stream[8] = {}; // launch chains (graph_for): the forked streams of the capture, [0] unused (= cap_stream)
-    hipEvent_t chain_ev[8] = {};      // [0] the fork, [c] chain c's join
     std::vector<std::pair<uint32_t, hipGraphExec_t>> graphs;   // per n_turns
     bool graphs_ok = true;
     bool timing = false;
@@ -257,6 +257,11 @@ static int create_impl(const ge_batch_desc *desc, ge_batch **out, const uint64_t
                 }
                 build_cond_image(s.table, s.dev.kind, dt);
                 b->cond_bytes = std::max<uint32_t>(b->cond_bytes, dt.cond_n16 * 16u);
+                if (b->segs.size() == 1 && s.table.pack == GE_PACK_TWO_TRUTHS && dt.cond_n16) {
+                    static const bool no_shapes = getenv("GE_NO_GENERIC_SHAPES") != nullptr;       // A/B runs: the rolled walk for every table
+                    const uint32_t ncl = dt.cond_shape & 7u, len = (dt.cond_shape >> 4) & 7u;
+                    b->gshape = no_shapes ? 0u : (ncl == 1u && len == 1u) ? 2u : (ncl == 1u && len == 2u) ? 3u : 0u;
+                }
                 dt.n_phases = s.table.n_phases; dt.rounds = s.table.rounds; dt.n_players = (int32_t)s.dev.n_players;
                 fill_nth8_host(dt.nth8);
                 fill_ord8_host(dt.ord8);
@@ -289,7 +294,8 @@ static int create_impl(const ge_batch_desc *desc, ge_batch **out, const uint64_t
 #if GE_STAMPS
     if (getenv("GE_STAMPS_OUT")) {
         DeviceGuard dg(b->device);
-        if (hipMalloc(reinterpret_cast<void **>(&b->stamps_dev), 64) == hipSuccess) (void)hipMemset(b->stamps_dev, 0, 64);
+        const size_t sb = 64 + (GE_STAMPS == 2 ? 32 * (size_t)((b->n_rooms + 63) / 64 + 64) : 0);    // GE_STAMPS = 2: + a {start, end, where, cycles} record per wavefront
+        if (hipMalloc(reinterpret_cast<void **>(&b->stamps_dev), sb) == hipSuccess) (void)hipMemset(b->stamps_dev, 0, sb);
     }
 #endif
     st = ge_batch_reset(b);
@@ -321,8 +327,6 @@ static int reset_impl(ge_batch *b) {
 // ---- one launch of the step kernel.  What is launched is chosen from four facts, each a template argument of the kernels so that
 // every build gets its own register allocation (ge_kernels.inl): the record layout (or "mixed": several segments), LOWOCC (up to
 // one wavefront per SIMD), GENERIC (some table has a generic target condition) and SINGLE (the launch is exactly one turn).
-// [block_lo, block_hi) restricts the launch to a range of its blocks: rooms never interact, so ranges of one batch can run as
-// independent launch chains (graph_for).
 namespace {
 struct LaunchShape { dim3 grid, block; uint32_t lds; hipStream_t st; const ge_batch *b; StepArgs a; };
 
@@ -333,7 +337,7 @@ template <class K> inline void launch_one(K kernel, const LaunchShape &L, bool q
     hipLaunchKernelGGL(kernel, L.grid, L.block, base + (L.b->generic ? L.b->cond_bytes : 0u), L.st, L.b->segs_dev, L.b->tables, a);
 }
 
-template <bool LOW, bool GEN, bool SINGLE> inline void launch_kind(uint32_t kind, const LaunchShape &L) {
+template <bool LOW, int GEN, bool SINGLE> inline void launch_kind(uint32_t kind, const LaunchShape &L) {
     switch (kind) {
     case K_WW8: launch_one(ge_step_kernel<K_WW8, LOW, GEN, SINGLE>, L, true, LOW); break;
     case K_WW12: launch_one(ge_step_kernel<K_WW12, LOW, GEN, SINGLE>, L, true, LOW); break;
@@ -342,10 +346,21 @@ template <bool LOW, bool GEN, bool SINGLE> inline void launch_kind(uint32_t kind
     default: launch_one(ge_step_kernel<K_TT12, LOW, GEN, SINGLE>, L, tt_uses_queue(12, LOW), LOW); break;
     }
 }
-template <bool LOW, bool GEN> inline void launch_kind(uint32_t kind, bool single, const LaunchShape &L) {
+template <bool LOW, int GEN> inline void launch_kind(uint32_t kind, bool single, const LaunchShape &L) {
     if (single) launch_kind<LOW, GEN, true>(kind, L); else launch_kind<LOW, GEN, false>(kind, L);
 }
-template <bool LOW, bool GEN> inline void launch_mixed(bool single, const LaunchShape &L) {
+// Two-Truths fused launches on a table whose generic conditions all have one of the common shapes: the shape-specialised builds
+template <bool LOW, int GEN> inline void launch_tt_shaped(uint32_t kind, const LaunchShape &L) {
+    switch (kind) {
+    case K_TT4: launch_one(ge_step_kernel<K_TT4, LOW, GEN, false>, L, tt_uses_queue(4, LOW), LOW); break;
+    case K_TT8: launch_one(ge_step_kernel<K_TT8, LOW, GEN, false>, L, tt_uses_queue(8, LOW), LOW); break;
+    default: launch_one(ge_step_kernel<K_TT12, LOW, GEN, false>, L, tt_uses_queue(12, LOW), LOW); break;
+    }
+}
+template <bool LOW> inline void launch_tt_shaped(uint32_t gshape, uint32_t kind, const LaunchShape &L) {
+    if (gshape == 2u) launch_tt_shaped<LOW, 2>(kind, L); else launch_tt_shaped<LOW, 3>(kind, L);
+}
+template <bool LOW, int GEN> inline void launch_mixed(bool single, const LaunchShape &L) {
     if (single) launch_one(ge_step_kernel_mixed<LOW, GEN, true>, L, true, LOW); else launch_one(ge_step_kernel_mixed<LOW, GEN, false>, L, true, LOW);
 }
 }  // namespace
@@ -374,24 +389,22 @@ static bool launch_low(const ge_batch *b, const StepArgs &a) {
     return a.lowocc != 0u && !(b->generic && b->segs.size() > 1);   // mixed batches with generic tables: the large-batch build serves every size
 }
 
-static hipError_t launch_step(const ge_batch *b, const StepArgs &a_in, hipStream_t st, uint32_t block_lo = 0u, uint32_t block_hi = ~0u) {
+static hipError_t launch_step(const ge_batch *b, const StepArgs &a_in, hipStream_t st) {
     const bool single = a_in.n_turns == 1u, mixed = b->segs.size() > 1, low = launch_low(b, a_in);
     uint32_t bt, blocks;
     launch_geometry(b, low, single, bt, blocks);
-    if (block_hi > blocks) block_hi = blocks;
-    if (block_lo >= block_hi) return hipSuccess;
-    LaunchShape L{dim3(block_hi - block_lo), dim3(bt), 0u, st, b, a_in};
+    LaunchShape L{dim3(blocks), dim3(bt), 0u, st, b, a_in};
     L.a.block_threads = bt;
-    L.a.block_off = block_lo;
     const uint32_t kind = b->segs[0].dev.kind;
     if (mixed) {
-        if (b->generic) launch_mixed<false, true>(single, L);
-        else if (low) launch_mixed<true, false>(single, L);
-        else launch_mixed<false, false>(single, L);
+        if (b->generic) launch_mixed<false, 1>(single, L);
+        else if (low) launch_mixed<true, 0>(single, L);
+        else launch_mixed<false, 0>(single, L);
     } else if (b->generic) {
-        if (low) launch_kind<true, true>(kind, single, L); else launch_kind<false, true>(kind, single, L);
+        if (b->gshape && !single) { if (low) launch_tt_shaped<true>(b->gshape, kind, L); else launch_tt_shaped<false>(b->gshape, kind, L); }
+        else if (low) launch_kind<true, 1>(kind, single, L); else launch_kind<false, 1>(kind, single, L);
     } else {
-        if (low) launch_kind<true, false>(kind, single, L); else launch_kind<false, false>(kind, single, L);
+        if (low) launch_kind<true, 0>(kind, single, L); else launch_kind<false, 0>(kind, single, L);
     }
     return hipGetLastError();
 }
@@ -431,83 +444,26 @@ static int ensure_deal_side(ge_batch *b) {
 // launch-bound for small batches; the sequence is captured once per n_turns into a hipGraph whose
 // launches take their first turn relative to a device word, and replayed.
 constexpr uint32_t GRAPH_MIN_LAUNCHES = 4;
-// default number of launch chains for a single-turn launch of `waves` wavefronts (A/B: profiles/r05_ab_launch_chains.txt)
-#ifndef GE_CHAINS_DEFAULT
-#define GE_CHAINS_DEFAULT(waves) 1u
-#endif
 
 
-
-// Launch chains.  A single-turn launch of a BASELINE-sized batch is two rounds of wavefronts: its load -> turn -> store pipeline
-// never reaches a steady state, and about 2.3 us of ramp and drain are exposed per launch.  Rooms never interact
-// (the reference runs one LangGraph thread per room, src/app/api/copilotkit/route.ts:24-37), so turn t + 1 of a room depends on
-// turn t of THAT room only: the batch's blocks are cut into S contiguous ranges and each range gets its own chain of launches, a
-// parallel branch of the captured graph - range A's launch drains while range B's is in its steady state.  S from the launch's
-// block count (GE_CHAINS = 1 / 2 / 4 / 8 overrides, for A/B runs; profiles/r05_ab_launch_chains.txt).
-static uint32_t chain_count(const ge_batch *b) {
-    static const uint32_t env = [] {
-        const char *e = getenv("GE_CHAINS");
-        const unsigned long v = e ? strtoul(e, nullptr, 10) : 0ul;
-        return (v == 1 || v == 2 || v == 4 || v == 8) ? (uint32_t)v : 0u;
-    }();
-    if (b->max_fuse != 1u || (b->flags & GE_FLAG_TRACE)) return 1u;
-    StepArgs a;
-    fill_args(b, a, 0u, 1u);
-    uint32_t bt, blocks;
-    launch_geometry(b, launch_low(b, a), true, bt, blocks);
-    const uint64_t waves = (uint64_t)blocks * (bt / 64u);
-    (void)waves;
-    uint32_t S = env ? env : GE_CHAINS_DEFAULT(waves);
-    while (S > 1u && blocks / S < 256u) S >>= 1;               // every chain still fills the chip: >= 256 blocks per launch
-    return S;
-}
 
 static hipGraphExec_t graph_for(ge_batch *b, uint32_t n_turns) {
     for (auto &g : b->graphs)
         if (g.first == n_turns) return g.second;
     if (!b->turn_dev && hipMalloc(reinterpret_cast<void **>(&b->turn_dev), sizeof(uint32_t)) != hipSuccess) return nullptr;
     if (!b->cap_stream && hipStreamCreateWithFlags(&b->cap_stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
-    const uint32_t S = chain_count(b);
-    for (uint32_t c = 1; c < S; c++) {
-        if (!b->chain_stream[c] && hipStreamCreateWithFlags(&b->chain_stream[c], hipStreamNonBlocking) != hipSuccess) return nullptr;
-        if (!b->chain_ev[c] && hipEventCreateWithFlags(&b->chain_ev[c], hipEventDisableTiming) != hipSuccess) return nullptr;
-    }
-    if (S > 1u && !b->chain_ev[0] && hipEventCreateWithFlags(&b->chain_ev[0], hipEventDisableTiming) != hipSuccess) return nullptr;
     if (hipStreamBeginCapture(b->cap_stream, hipStreamCaptureModeThreadLocal) != hipSuccess) return nullptr;
     bool ok = true;
-    if (S > 1u) {
-        // fork: every chain's stream joins the capture behind the origin; each chain is n_turns single-turn launches over its own
-        // block range; join: the origin waits for every chain before the turn word moves on
-        StepArgs a0;
-        fill_args(b, a0, 0u, 1u);
-        uint32_t bt, blocks;
-        launch_geometry(b, launch_low(b, a0), true, bt, blocks);
-        ok = hipEventRecord(b->chain_ev[0], b->cap_stream) == hipSuccess;
-        for (uint32_t c = 1; c < S && ok; c++) ok = hipStreamWaitEvent(b->chain_stream[c], b->chain_ev[0], 0) == hipSuccess;
-        for (uint32_t c = 0; c < S && ok; c++) {
-            hipStream_t cs = c ? b->chain_stream[c] : b->cap_stream;
-            const uint32_t lo = (uint32_t)((uint64_t)blocks * c / S), hi = (uint32_t)((uint64_t)blocks * (c + 1u) / S);
-            for (uint32_t t = 0; t < n_turns && ok; t++) {
-                StepArgs a;
-                fill_args(b, a, t, 1u);
-                a.turn_dev = b->turn_dev;
-                ok = launch_step(b, a, cs, lo, hi) == hipSuccess;
-            }
-        }
-        for (uint32_t c = 1; c < S; c++) {                     // always joined, or the capture cannot end
-            const bool j = hipEventRecord(b->chain_ev[c], b->chain_stream[c]) == hipSuccess &&
-                           hipStreamWaitEvent(b->cap_stream, b->chain_ev[c], 0) == hipSuccess;
-            ok = ok && j;
-        }
-    } else {
-        for (uint32_t done = 0; done < n_turns && ok; ) {
-            const uint32_t k = (n_turns - done) < b->max_fuse ? (n_turns - done) : b->max_fuse;
-            StepArgs a;
-            fill_args(b, a, done, k);
-            a.turn_dev = b->turn_dev;
-            ok = launch_step(b, a, b->cap_stream) == hipSuccess;
-            done += k;
-        }
+    // (Round 5 also captured the launches as S independent chains over block ranges - parallel graph branches, rooms never
+    // interact - to overlap one range's drain with another's steady state: the chains' launches ran on separate hardware queues
+    // but never together, and every shorter launch paid its own ramp and drain; 0-65 % slower.  profiles/r05_ab_launch_chains.txt)
+    for (uint32_t done = 0; done < n_turns && ok; ) {
+        const uint32_t k = (n_turns - done) < b->max_fuse ? (n_turns - done) : b->max_fuse;
+        StepArgs a;
+        fill_args(b, a, done, k);
+        a.turn_dev = b->turn_dev;
+        ok = launch_step(b, a, b->cap_stream) == hipSuccess;
+        done += k;
     }
     if (ok) {
         hipLaunchKernelGGL(ge_turn_bump, dim3(1), dim3(1), 0, b->cap_stream, b->turn_dev, n_turns);
@@ -940,10 +896,19 @@ void ge_batch_destroy(ge_batch *b) {
             unsigned long long h[8] = {0};
             (void)hipMemcpy(h, b->stamps_dev, 64, hipMemcpyDeviceToHost);
             if (FILE *f = fopen(getenv("GE_STAMPS_OUT"), "a")) {
-                fprintf(f, "{\"rooms\": %llu, \"wave_turns\": %llu, \"seg\": [%llu, %llu, %llu, %llu]}\n",
-                        (unsigned long long)b->n_rooms, h[4], h[0], h[1], h[2], h[3]);
+                fprintf(f, "{\"rooms\": %llu, \"wave_turns\": %llu, \"seg\": [%llu, %llu, %llu, %llu], \"wave_shader_cycles\": %llu, \"wave_realtime_ticks_100MHz\": %llu}\n",
+                        (unsigned long long)b->n_rooms, h[4], h[0], h[1], h[2], h[3], h[5], h[6]);
                 fclose(f);
             }
+#if GE_STAMPS == 2
+            if (b->segs.size() == 1) {                                       // the last long launch's timeline, one record per wavefront
+                const size_t nw = (size_t)((b->n_rooms + 63) / 64);
+                std::vector<unsigned long long> log(4 * nw);
+                (void)hipMemcpy(log.data(), b->stamps_dev + 8, 32 * nw, hipMemcpyDeviceToHost);
+                std::string path = std::string(getenv("GE_STAMPS_OUT")) + ".waves.bin";
+                if (FILE *f = fopen(path.c_str(), "wb")) { fwrite(log.data(), 32, nw, f); fclose(f); }
+            }
+#endif
             (void)hipFree(b->stamps_dev);
         }
 #endif
@@ -951,8 +916,6 @@ void ge_batch_destroy(ge_batch *b) {
         if (b->order_ev) (void)hipEventDestroy(b->order_ev);
         for (auto &g : b->graphs) (void)hipGraphExecDestroy(g.second);
         if (b->cap_stream) (void)hipStreamDestroy(b->cap_stream);
-        for (hipStream_t cs : b->chain_stream) if (cs) (void)hipStreamDestroy(cs);
-        for (hipEvent_t ce : b->chain_ev) if (ce) (void)hipEventDestroy(ce);
         if (b->turn_dev) (void)hipFree(b->turn_dev);
         if (b->inj_buf) (void)hipFree(b->inj_buf);
         if (b->io_buf) (void)hipHostFree(b->io_buf);

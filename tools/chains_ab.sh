@@ -3,6 +3,7 @@
 # parallel branches of the captured hipGraph; csrc/ge_step.hip graph_for), on one box, interleaved.  First a parity check of
 # every setting: 48 single-turn launches == 48 fused turns (summary checksum + a window of rooms).
 #   tools/chains_ab.sh "ww:8:1048576 ww:12:2097152 tt:4:1048576 ww:8:524288+tt:4:524288 ww:8:33554432"
+# NOTE: GE_CHAINS existed at commit 3731afc only (the variant was measured and removed; profiles/r05_ab_launch_chains.txt).
 SHAPES=${1:-"ww:8:1048576 ww:12:2097152 tt:4:1048576 ww:8:524288+tt:4:524288 ww:8:33554432"}
 for ch in 1 2 4 8; do
   GE_CHAINS=$ch timeout -k 10 300 python - <<'PY' || exit 1

@@ -76,7 +76,7 @@ def counters(sub):
 res = {"tag": tag, "key": key, "kernel": "ge_step_kernel", "rooms": rooms, "turns_per_launch": fuse, "waves": waves,
        "note": "medians over the launches of the timed shape (dispatches lasting >= half the longest one)"}
 allc = {}
-for sub in ("fetch", "write", "sq", "sq2"):
+for sub in ("fetch", "write", "sq", "sq2", "sq3", "sq4", "sq5"):
     allc.update(counters(sub))
 for name, vals in allc.items():
     dmax = max(d for _, d in vals)
