@@ -280,8 +280,9 @@ template <> struct WaveLdsOf<true> { using type = WaveLdsLow; };
 // element h * 32 + r; load_rows permutes while it copies): a wavefront's lanes read 18 or so different rows at once, and 32 bytes
 // apart rows r, r + 8, r + 16 share their banks (ds_read_b128: bank = dword address mod 64) - every row had one or two partners in
 // the shipped tables; 16 bytes apart only r and r + 16 do.
-// SPLIT = the large-batch builds (A/B, profiles/r05_ab_lds_banks.txt: with the packed results -2.2 % at 1 M Werewolf x 8 rooms,
-// -3 % on the C5 mix; a lone wavefront has no bank conflicts with itself to lose and pays 1 % for the second address).
+// SPLIT = the large-batch fused builds (A/B, profiles/r05_ab_lds_banks.txt: with the packed results -2.2 % at 1 M Werewolf x 8
+// rooms, -3 % on the C5 mix; a lone wavefront has no bank conflicts with itself to lose and pays 1 % for the second address, a
+// single-turn launch reads one row per room and gains nothing).
 template <bool SPLIT>
 __device__ __forceinline__ DevRow lds_row(const DevRow *rows, uint32_t idx) {
     if (!(SPLIT && GE_ROWS_SPLIT)) return rows[idx];

@@ -176,7 +176,7 @@ __device__ __forceinline__ void run_ww(const SegDev *__restrict__ sgp, const Ste
     load_words<L::WORDS, (NB > 8)>(sg.base, sg.rooms_padded, room, w);   // in flight while the block fills its LDS tables; streaming: see load_words
     // the slot -> player table of the action queue sits right behind the phase rows (step_lds_bytes)
     uint32_t *ord8 = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(rows) + LDS_ROWS);
-    load_rows<B::TABLE ? IMG_END / 16u : B::ORD ? 128u : 64u, !LOWOCC && !SINGLE, GENERIC, !LOWOCC>(rows, tables, sg.table_idx, sgp, a.cond_off);
+    load_rows<B::TABLE ? IMG_END / 16u : B::ORD ? 128u : 64u, !LOWOCC && !SINGLE, GENERIC, !LOWOCC && !SINGLE>(rows, tables, sg.table_idx, sgp, a.cond_off);
     WWR<NB> s;
     uint32_t cache;
     if (NB <= 8 && !SINGLE) {
@@ -237,7 +237,7 @@ __device__ __forceinline__ void run_ww(const SegDev *__restrict__ sgp, const Ste
             s.games = g < 0xFFFFu ? g + 1u : g;
             restarted = 1;
         }
-        DevRow row = lds_row<!LOWOCC>(rows, s.phase);
+        DevRow row = lds_row<!LOWOCC && !SINGLE>(rows, s.phase);
         const uint32_t p = s.phase;
         uint32_t ev_newly = 0;
         uint64_t ev_choice = 0;
@@ -272,10 +272,10 @@ __device__ __forceinline__ void run_ww(const SegDev *__restrict__ sgp, const Ste
         }
         if (trace && valid) store_event(sg.trace, sg.rooms_padded, 0u, room, turn0, p, s.phase, restarted, ev_newly, ev_choice);
     } else {
-        DevRow row = lds_row<!LOWOCC>(rows, s.phase);
+        DevRow row = lds_row<!LOWOCC && !SINGLE>(rows, s.phase);
         WWR<NB> s0;
         DevRow row0 = row;
-        if (LOWOCC) { s0 = fresh_room(); row0 = lds_row<!LOWOCC>(rows, sg.phase0_idx); }
+        if (LOWOCC) { s0 = fresh_room(); row0 = lds_row<!LOWOCC && !SINGLE>(rows, sg.phase0_idx); }
         // the turn loop; the lone-wavefront build compiles it once per trace setting: the event-trace branches (two per turn,
         // both wave-uniform and almost always taken) cost a lone wavefront an instruction-fetch bubble each
         auto turns = [&](auto trace_c) {
@@ -287,7 +287,7 @@ __device__ __forceinline__ void run_ww(const SegDev *__restrict__ sgp, const Ste
                     const uint32_t g = s.games;
                     s = LOWOCC ? s0 : fresh_room();
                     s.games = g < 0xFFFFu ? g + 1u : g;
-                    row = LOWOCC ? row0 : lds_row<!LOWOCC>(rows, ctx.phase0_idx);
+                    row = LOWOCC ? row0 : lds_row<!LOWOCC && !SINGLE>(rows, ctx.phase0_idx);
                     restarted = 1;
                 }
                 const uint32_t p = s.phase;
@@ -342,7 +342,7 @@ __device__ __forceinline__ void run_tt(const SegDev *__restrict__ sgp, const Ste
     const uint64_t room = valid ? room_in : 0;
     uint32_t w[L::WORDS];
     load_words<L::WORDS, true>(sg.base, sg.rooms_padded, room, w);
-    load_rows<(QUEUE && !LOWOCC) ? 256u : 64u, QUEUE && !LOWOCC && !SINGLE, GENERIC, !LOWOCC>(rows, tables, sg.table_idx, sgp, a.cond_off);
+    load_rows<(QUEUE && !LOWOCC) ? 256u : 64u, QUEUE && !LOWOCC && !SINGLE, GENERIC, !LOWOCC && !SINGLE>(rows, tables, sg.table_idx, sgp, a.cond_off);
     TT<NB> s;
     L::unpack(w, s);
     const uint32_t rk = room_key_from(a.seed_key, sg.first_global + room);
@@ -380,24 +380,24 @@ __device__ __forceinline__ void run_tt(const SegDev *__restrict__ sgp, const Ste
             done = done0;
             restarted = 1;
         }
-        DevRow row = lds_row<!LOWOCC>(rows, s.phase);
+        DevRow row = lds_row<!LOWOCC && !SINGLE>(rows, s.phase);
         const uint32_t p = s.phase;
         uint32_t ev_newly = 0;
         uint64_t ev_choice = 0;
         tt_turn<NB, QUEUE, !LOWOCC, GENERIC, true>(s, done, row, rows, cc, lw, nth8, valid, sg.n_players, sg.rounds, sg.phase0_idx, rk, turn0, a.trace != 0u, sg.human_mask, term_mask, ev_newly, ev_choice);
         if (a.trace && valid) store_event(sg.trace, sg.rooms_padded, 0u, room, turn0, p, s.phase, restarted, ev_newly, ev_choice);
     } else {
-        DevRow row = lds_row<!LOWOCC>(rows, s.phase);
+        DevRow row = lds_row<!LOWOCC && !SINGLE>(rows, s.phase);
         TT<NB> s0;
         DevRow row0 = row;
-        if (LOWOCC) { s0 = fresh_room(); row0 = lds_row<!LOWOCC>(rows, sg.phase0_idx); }
+        if (LOWOCC) { s0 = fresh_room(); row0 = lds_row<!LOWOCC && !SINGLE>(rows, sg.phase0_idx); }
         for (uint32_t t = 0; t < a.n_turns; t++) {
             uint32_t restarted = 0;
             if (a.restart && ((row.r0 >> 11) & 7u) == 0u) {
                 const uint32_t g = s.games;
                 s = LOWOCC ? s0 : fresh_room();
                 s.games = g < 0xFFFFu ? g + 1u : g;
-                row = LOWOCC ? row0 : lds_row<!LOWOCC>(rows, sg.phase0_idx);
+                row = LOWOCC ? row0 : lds_row<!LOWOCC && !SINGLE>(rows, sg.phase0_idx);
                 done = done0;
                 restarted = 1;
             }

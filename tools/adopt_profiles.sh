@@ -3,7 +3,7 @@
 # names (r03_*, pmc_*.json, the three bench records), and check that every counter profile carries the hash of the device
 # code in this tree; then rewrite the measurement tables of the docs from them.   tools/adopt_profiles.sh <tag> [round-prefix, default r03]
 set -eu
-TAG=$1; ROUND=${2:-r04}
+TAG=$1; ROUND=${2:-r05}
 cd "$(dirname "$0")/.."
 for f in gpurun_out/profiles_out/${TAG}_*; do cp "$f" "profiles/${ROUND}_$(basename "${f#gpurun_out/profiles_out/${TAG}_}")"; done
 cp gpurun_out/profiles_out/pmc_*.json profiles/

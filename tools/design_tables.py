@@ -6,7 +6,7 @@ usage: design_tables.py [tag] [--write]    (--write: rewrite the marked blocks o
 import io, json, os, re, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
-tag = args[0] if args else "r04"
+tag = args[0] if args else "r05"
 _blocks, _real_print, _cur = {}, print, [None]
 def begin(name): _cur[0] = name; _blocks[name] = []
 def print(*a):                                                   # rows go to the current block

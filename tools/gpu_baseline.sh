@@ -6,7 +6,7 @@
 #   tools/gpu_baseline.sh <tag> bench     the -m gpu suite, the bench under the driver's flags, the C5 line, the 2-rank rehearsal, RCCL with one rank
 # then tools/adopt_profiles.sh <tag> <round>.
 set -u
-TAG=${1:-r04}; PART=${2:-bench}
+TAG=${1:-r05}; PART=${2:-bench}
 mkdir -p gpurun_out/$TAG
 case "$PART" in
 fused)
@@ -21,6 +21,7 @@ single)
   bash tools/profile.sh $TAG ww8_1048576_k1 --rooms 1048576
   bash tools/profile.sh $TAG c4_k1 --workload c4
   bash tools/profile.sh $TAG c3_k1 --workload c3
+  bash tools/profile.sh $TAG c5_k1 --workload c5                          # the mixed kernel's single-turn build
   # resident state larger than the 256 MiB Infinity Cache: the HBM figure that is provably HBM
   bash tools/profile.sh $TAG ww8_33554432_k1 --workload ww8_33554432
   bash tools/profile.sh $TAG c4_whole_k1 --workload c4_whole

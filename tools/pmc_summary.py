@@ -48,7 +48,8 @@ def wanted(kernel_name):
     if not m:
         return False
     args = [a.strip() for a in m.group(2).split(",")]
-    is_single = not m.group(1) and len(args) >= 4 and args[3] == "true"
+    # ge_step_kernel<KIND, LOWOCC, GENERIC, SINGLE> / ge_step_kernel_mixed<LOWOCC, GENERIC, SINGLE>
+    is_single = (len(args) >= 3 and args[2] == "true") if m.group(1) else (len(args) >= 4 and args[3] == "true")
     return is_single == single
 
 
