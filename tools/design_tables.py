@@ -15,13 +15,16 @@ P = lambda k: json.load(open(os.path.join(root, "profiles", f"pmc_{k}.json")))
 bench = json.loads(open(os.path.join(root, "profiles", f"{tag}_bench_n1_driver_flags.json")).read().strip().splitlines()[-1])
 other = bench["other_shapes"]
 labels = {"c2": "C2: 65 536 Werewolf × 8 (1 wave/SIMD, ceiling 6.1·10¹¹)", "ww8_1048576": "1 048 576 Werewolf × 8",
-          "c4": "C4 share: 2 097 152 Werewolf × 12", "c3": "C3: 1 048 576 Two-Truths × 4"}
-okey = {"ww8_1048576": "1048576 Werewolf x8", "c4": "2097152 Werewolf x12 (one GPU's share of C4)", "c3": "1048576 Two-Truths x4 (C3)"}
-rooms = {"c2": 65536, "ww8_1048576": 1 << 20, "c4": 1 << 21, "c3": 1 << 20}
+          "c4": "C4 share: 2 097 152 Werewolf × 12", "c3": "C3: 1 048 576 Two-Truths × 4",
+          "c5": "C5 share: 524 288 Werewolf × 8 + 524 288 Two-Truths × 4, one launch"}
+okey = {"ww8_1048576": "1048576 Werewolf x8", "c4": "2097152 Werewolf x12 (one GPU's share of C4)", "c3": "1048576 Two-Truths x4 (C3)",
+        "c5": "524288 Werewolf x8 + 524288 Two-Truths x4 (one GPU's share of C5)"}
+rooms = {"c2": 65536, "ww8_1048576": 1 << 20, "c4": 1 << 21, "c3": 1 << 20, "c5": 1 << 20}
+SHAPES = ("c2", "ww8_1048576", "c4", "c3", "c5") if okey["c5"] in other else ("c2", "ww8_1048576", "c4", "c3")
 
 begin("fused_table")
 print("| shape (fused, 1 024 turns/launch) | VALU + SALU + LDS per wave-turn | µs per turn | room-phase steps/s | issue frac (all / VALU only) | `SQ_WAIT_ANY` of wave cycles |\n|---|---|---|---|---|---|")
-for k in ("c2", "ww8_1048576", "c4", "c3"):
+for k in SHAPES:
     p = P(k); i = p["instructions_per_wave_turn"]
     us = bench["roofline"]["avg_launch_us"] / 1024 if k == "c2" else other[okey[k]]["us_per_turn"]
     waves = rooms[k] // 64
@@ -29,16 +32,9 @@ for k in ("c2", "ww8_1048576", "c4", "c3"):
     wt = waves / (us * 1e-6)
     tot = i["valu"] + i["salu"] + i["lds"]
     print(f"| {labels[k]} | {i['valu']:.0f} + {i['salu']:.0f} + {i['lds']:.0f} | {us:.3f} | {rooms[k] / (us * 1e-6):.3g} | {tot * wt / ceil:.2f} / {i['valu'] * wt / ceil:.2f} | {100 * p['wait_any_frac']:.0f} % |")
-_c5b = os.path.join(root, "profiles", f"{tag}_bench_c5_share.json")
-if os.path.exists(os.path.join(root, "profiles", "pmc_c5.json")) and os.path.exists(_c5b):
-    # one GPU's share of the mixed batch (BASELINE configs[4]): its own bench line (python bench.py --workload c5) and counter passes
-    c5 = json.loads(open(_c5b).read().strip().splitlines()[-1]); p = P("c5"); i = p["instructions_per_wave_turn"]
-    us = c5["roofline"]["avg_launch_us"] / 1024; rooms5 = c5["config"]["rooms_per_gpu"]; wt = rooms5 // 64 / (us * 1e-6)
-    tot = i["valu"] + i["salu"] + i["lds"]; ceil5 = 1024 * 2.4e9 / 2.0
-    print(f"| C5 share: 524 288 Werewolf × 8 + 524 288 Two-Truths × 4, one launch | {i['valu']:.0f} + {i['salu']:.0f} + {i['lds']:.0f} | {us:.3f} | {rooms5 / (us * 1e-6):.3g} | {tot * wt / ceil5:.2f} / {i['valu'] * wt / ceil5:.2f} | {100 * p['wait_any_frac']:.0f} % |")
 begin("k1_table")
 print("| shape (single-turn launches; state <= 256 MiB: a memory-side rate, the Infinity Cache may serve) | VALU + SALU + LDS per wave-turn | measured memory-side bytes per launch (state read + written) | kernel-trace average (sustained) | % of 8 TB/s by kernel-trace | bench line: sustained / per-launch events | `SQ_WAIT_ANY` |\n|---|---|---|---|---|---|---|")
-for k in ("c2", "ww8_1048576", "c4", "c3"):
+for k in SHAPES:
     p = P(k + "_k1"); i = p["instructions_per_wave_turn"]; kt = p["kernel_trace"]
     hs = bench["hbm_streaming"] if k == "c2" else other[okey[k]]["hbm_streaming"]
     st = p["state_bytes_read_plus_written"]
@@ -51,6 +47,20 @@ for label, key in (("33554432 Werewolf x8 (1 GiB of records)", "ww8_33554432"), 
     b = bench["hbm_streaming_beyond_l3"][label]
     pct = 100 * st / kt["average_ns"] / 8e3
     print(f"| {label.replace(' x', ' × ')} | {b['resident_state_MiB']:.0f} MiB | {i['valu']:.0f} + {i['salu']:.0f} + {i['lds']:.0f} | {p['hbm_bytes_per_launch'] / 1e6:.1f} MB ({st / 1e6:.1f}) | {kt['average_ns'] / 1e3:.1f} µs ({kt['calls']} launches) | **{pct:.1f}** ({pct * 8 / 6.29:.0f}) | {100 * b['frac']:.1f} ({b['us_per_launch_sustained']:.1f} µs) | {'yes' if b['parity']['single_turn_equals_fused'] else 'NO'} |")
+begin("attrib_table")
+# where the fused launches' time goes: counters of tools/attrib_profile.sh (profiles/<tag>_<shape>_attrib_counters.json), per wave-turn
+def A(k): return json.load(open(os.path.join(root, "profiles", f"{tag}_{k}_attrib_counters.json")))
+print("| shape (fused) | SIMD cycles per wave-turn | vector pipe busy (VALU x 2 cycles) | active lanes per VALU instruction | LDS array busy (of it bank-conflict replays) | a wavefront's residency: issuing / issue-stalled (of it on the LDS) / parked at a wait | mean resident wavefronts per SIMD | instruction fetches, I-cache misses |\n|---|---|---|---|---|---|---|---|")
+for k in SHAPES:
+    try: a = A(k)
+    except OSError: continue
+    g = lambda n: a[n]["per_wave_turn"]
+    simd = 4.0 * g("SQ_BUSY_CU_CYCLES")                      # CU-busy cycles per wave-turn x the CU's 4 SIMDs working side by side
+    wave = 4.0 * g("SQ_WAVE_CYCLES")                          # quad-cycles -> cycles
+    print(f"| {labels[k].split(' (1 wave')[0]} | {simd:.0f} | {100 * 2 * g('SQ_INSTS_VALU') / simd:.0f} % | {g('SQ_THREAD_CYCLES_VALU') / g('SQ_INSTS_VALU'):.0f} of 64 | "
+          f"{100 * g('SQ_LDS_IDX_ACTIVE') / g('SQ_BUSY_CU_CYCLES'):.0f} % ({100 * g('SQ_LDS_BANK_CONFLICT') / g('SQ_LDS_IDX_ACTIVE'):.0f} %) | "
+          f"{100 * g('SQ_ACTIVE_INST_ANY') / g('SQ_WAVE_CYCLES'):.0f} % / {100 * g('SQ_WAIT_INST_ANY') / g('SQ_WAVE_CYCLES'):.0f} % ({100 * g('SQ_WAIT_INST_LDS') / g('SQ_WAVE_CYCLES'):.0f} %) / {100 * g('SQ_WAIT_ANY') / g('SQ_WAVE_CYCLES'):.0f} % | "
+          f"{wave / simd:.1f} | {g('SQ_IFETCH'):.0f}, {g('SQC_ICACHE_MISSES'):.2f} |")
 begin("asm_table")
 # registers, spills, scratch, occupancy of every kernel, from the compiler's remarks (tools/asm_table.py = make asm)
 sys.path.insert(0, os.path.join(root, "tools"))
@@ -59,13 +69,14 @@ for line in _asm.markdown(_asm.collect(rebuild=True)).splitlines(): print(line)
 begin("result_table")
 print("| shape | fused (1 024 turns/launch): steps/s | alg. GB/s (% of 8 TB/s: a yardstick, not traffic) | single-turn launches: memory-side % of 8 TB/s (sustained; state fits the Infinity Cache) | CPU: oracle, steps/s (cores) |\n|---|---|---|---|---|")
 print(f"| C2: 65 536 Werewolf × 8 — the `bench.py` line | **{bench['value']:.3g}** (wall) | {bench['roofline']['achieved']:.0f} ({100 * bench['roofline']['frac']:.1f}) | {100 * bench['hbm_streaming']['frac']:.1f} (launch-bound: {bench['hbm_streaming']['us_per_launch_sustained']:.1f} µs per launch) | {bench['cpu_baseline']['value']:.3g} ({bench['cpu_baseline']['cores']}); one thread {bench['cpu_baseline']['single_thread_value']:.3g} |")
-for k in ("ww8_1048576", "c4", "c3"):
+for k in SHAPES[1:]:
     v = other[okey[k]]
     print(f"| {labels[k]} | {v['value']:.3g} | {v['algorithmic_GBs']:.0f} ({100 * v['algorithmic_frac']:.0f}) | **{100 * v['hbm_streaming']['frac']:.1f}** ({v['hbm_streaming']['us_per_launch_sustained']:.2f} µs per launch) | {v['cpu_baseline']['value']:.3g} ({v['cpu_baseline']['cores']}) |")
 begin("baseline_rows")
 # BASELINE.md's round table: one row per shape
-blabels = {"c2": "C2 65 536 Werewolf×8", "ww8_1048576": "1 048 576 Werewolf×8", "c4": "C4 share 2 097 152 Werewolf×12", "c3": "C3 1 048 576 Two-Truths×4"}
-for k in ("c2", "ww8_1048576", "c4", "c3"):
+blabels = {"c2": "C2 65 536 Werewolf×8", "ww8_1048576": "1 048 576 Werewolf×8", "c4": "C4 share 2 097 152 Werewolf×12", "c3": "C3 1 048 576 Two-Truths×4",
+           "c5": "C5 share 524 288 Werewolf×8 + 524 288 Two-Truths×4"}
+for k in SHAPES:
     p = P(k); i = p["instructions_per_wave_turn"]; q = P(k + "_k1")
     us = bench["roofline"]["avg_launch_us"] / 1024 if k == "c2" else other[okey[k]]["us_per_turn"]
     waves = rooms[k] // 64
