@@ -59,7 +59,7 @@ SYMBOLS = ["ge_table_compile_json", "ge_batch_create", "ge_batch_step", "ge_batc
            "ge_batch_n_rooms", "ge_batch_read_rooms", "ge_batch_write_rooms", "ge_batch_read_events", "ge_batch_inject_action", "ge_batch_summary",
            "ge_batch_state", "ge_batch_set_timing", "ge_batch_kernel_time", "ge_batch_destroy",
            "ge_group_partition", "ge_batch_create_shard", "ge_group_create", "ge_group_size", "ge_group_shard", "ge_group_step", "ge_group_sync", "ge_group_summary", "ge_group_destroy",
-           "ge_strerror", "ge_last_hip_error", "ge_last_comm_error", "ge_abi_version", "ge_device_count"]
+           "ge_strerror", "ge_last_hip_error", "ge_last_rejected_room", "ge_last_comm_error", "ge_abi_version", "ge_device_count"]
 
 _lib = None
 
@@ -115,6 +115,8 @@ def load() -> C.CDLL:
     lib.ge_batch_destroy.restype = None
     lib.ge_strerror.argtypes = [C.c_int]
     lib.ge_strerror.restype = C.c_char_p
+    if hasattr(lib, "ge_last_rejected_room"):
+        lib.ge_last_rejected_room.restype = C.c_uint64
     # (GE_LIB_ANY_ABI: timing an older build through tools/abn.sh - only the entry points both versions share are used there)
     any_abi = bool(os.environ.get("GE_LIB_PATH") and os.environ.get("GE_LIB_ANY_ABI"))
     if lib.ge_abi_version() != GE_ABI_VERSION and not any_abi:

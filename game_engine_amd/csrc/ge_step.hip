@@ -30,6 +30,7 @@ namespace {
 #include "ge_kernels.inl"          // all device code: step / summary / fill / injection kernels
 
 thread_local int g_last_hip = 0;
+thread_local uint64_t g_last_rejected_room = ~0ull;   // ge_batch_write_rooms: the first view (index in the batch) that did not fit its segment
 
 #define HIP_TRY(expr)                                   \
     do {                                                \
@@ -140,6 +141,7 @@ extern "C" {
 
 int ge_abi_version(void) { return GE_ABI_VERSION; }
 int ge_last_hip_error(void) { return g_last_hip; }
+uint64_t ge_last_rejected_room(void) { return g_last_rejected_room; }
 
 int ge_device_count(void) {
     int n = 0;
@@ -610,17 +612,19 @@ static int rooms_io(ge_batch *b, uint64_t first, uint64_t count, ge_room_view *d
     }
     if (src) {                                                   // nothing is written unless every view fits its segment
         for (const Part &p : parts) {
-            std::atomic<int> bad{0};
+            std::atomic<uint64_t> bad{~0ull};                    // the lowest offending room of the part
             const ge_room_view *v = src + (p.lo - first);
             const uint32_t n = p.s->dev.n_players;
             const ge_game_table &tb = p.s->table;
             for_room_ranges(p.nr, [&](uint64_t a, uint64_t z) {
                 for (uint64_t r = a; r < z; r++) {
-                    const bool ok = view_fits(v[r], tb, n);
-                    if (!ok) { bad.store(1, std::memory_order_relaxed); return; }
+                    if (view_fits(v[r], tb, n)) continue;
+                    uint64_t cur = bad.load(std::memory_order_relaxed);
+                    while (r < cur && !bad.compare_exchange_weak(cur, r, std::memory_order_relaxed)) {}
+                    return;
                 }
             });
-            if (bad.load()) return GE_ERR_ARG;
+            if (bad.load() != ~0ull) { g_last_rejected_room = p.lo + bad.load(); return GE_ERR_ARG; }
         }
     }
     for (const Part &p : parts) {

@@ -40,11 +40,19 @@ function post(port, path, obj) {
   const ids = Object.values(burst[3].state.playerActions).map((r) => Object.keys(r.actions));
   const idsOk = ids.every((k) => k.every((id, j) => id === String(j + 1)));
   const busy = burst.some((r) => r && r.error && /busy/i.test(r.error));
+  // the message-level entry over HTTP: control plays a turn, chat does not, a game message is logged under Player 1 / phase 0's name
+  const m0 = await post(port, '/message', { threadId: 'room-h', text: 'Continue' });
+  const m1 = await post(port, '/message', { threadId: 'room-h', text: 'Player Bot 1 in game chat: hello' });
+  const m2 = await post(port, '/message', { threadId: 'room-h', text: 'Button "Skip" (ID: b1) has been clicked. Action: skip' });
+  const logged = Object.values(m2.state.playerActions['1'].actions).filter((a) => a.action.startsWith('Button "Skip"'));
+  const message = { kinds: [m0.kind, m1.kind, m2.kind], played: [m0.played, m1.played, m2.played],
+                    hist: [m0.state.phase_history.length, m1.state.phase_history.length, m2.state.phase_history.length],
+                    loggedPhase: logged.length === 1 ? logged[0].phase : null };
   const closed = await post(port, '/close', { threadId: 'room-h' });
   const after = await post(port, '/continue', { threadId: 'room-h' });
   server.close();
   console.log(JSON.stringify({ room: roomIndexOf('room-abc').toString(), phases, notes, acts, ui,
-                               burst: { hist, idsOk, busy, closed: closed.closed, afterClose: after.error || null, rooms: svc.rooms.size },
+                               burst: { hist, idsOk, busy, closed: closed.closed, afterClose: after.error || null, rooms: svc.rooms.size }, message,
                                name1: last.state.player_states['1'].name, finalPhase: last.state.current_phase_name,
                                alive: Object.values(last.state.player_states).map((p) => p.is_alive ? 1 : 0) }));
 })().catch((e) => { console.error(e); process.exit(1); });

@@ -230,7 +230,12 @@ class RoomBatch:
 
     def write_rooms(self, first: int, views: np.ndarray):
         assert views.dtype == ROOM_VIEW_DTYPE and views.flags.c_contiguous
-        _check(self._lib.ge_batch_write_rooms(self._h, first, len(views), views.ctypes.data), "ge_batch_write_rooms")
+        st = self._lib.ge_batch_write_rooms(self._h, first, len(views), views.ctypes.data)
+        if st == -1 and len(views):             # all-or-nothing: say which view did not fit its segment (pack / players / phase ids / role class)
+            bad = int(self._lib.ge_last_rejected_room())
+            if first <= bad < first + len(views):
+                raise GeError(st, f"ge_batch_write_rooms: room {bad} does not fit its segment (nothing was written)")
+        _check(st, "ge_batch_write_rooms")
 
     def inject_action(self, room: int, player_id: int, choice: int):
         """Log an action of a host-driven (human) player in the room's current phase."""

@@ -36,7 +36,7 @@ extern "C" {
  *   4  device group (ge_group_*, GE_ERR_COMM); ge_batch_write_rooms became all-or-nothing and REFUSES (GE_ERR_ARG) a view whose
  *      `pack` / player count is not the segment's or whose phase ids name no row of its table (until then unknown ids were
  *      silently stored as row 0) - a caller that zero-initialises views must set `pack`
- *   5  ge_group_partition + ge_batch_create_shard (the group's sharding arithmetic for hosts that place shards themselves);
+ *   5  ge_group_partition + ge_batch_create_shard (the group's sharding arithmetic for hosts that place shards themselves); ge_last_rejected_room;
  *      mixed and generic batches get single-turn kernel builds; the Werewolf x 12 deal side plane is allocated on first use */
 #define GE_ABI_VERSION 5
 #define GE_MAX_PHASES 32
@@ -347,6 +347,8 @@ int ge_last_comm_error(void);             /* ncclResult_t of the last GE_ERR_COM
 
 const char *ge_strerror(int status);
 int ge_last_hip_error(void);              /* hipError_t of the last GE_ERR_HIP on this thread */
+uint64_t ge_last_rejected_room(void);     /* ge_batch_write_rooms returned GE_ERR_ARG for a view that does not fit its segment: the index (in the batch) of
+                                             the first such room, on this thread; ~0 if none yet (ABI 5) */
 int ge_abi_version(void);
 int ge_device_count(void);                /* number of HIP devices, 0 if none; never fails */
 

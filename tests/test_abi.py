@@ -157,3 +157,4 @@ def test_group_partition_through_the_c_abi_needs_no_device():
     assert lib.ge_group_partition(C.byref(d), 2, 2, C.byref(sh), first) == -1
     assert lib.ge_group_partition(None, 2, 0, C.byref(sh), first) == -1
     assert lib.ge_batch_create_shard(C.byref(sh), None, None) == -1
+    assert lib.ge_last_rejected_room() == 0xFFFFFFFFFFFFFFFF               # no write has been refused on this thread

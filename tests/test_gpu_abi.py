@@ -193,12 +193,16 @@ def test_room_views_through_the_threaded_host_conversion(dsl_ww, dsl_tt, monkeyp
         bad["players"][total - 7, 0, 0] = 9                  # werewolf role class out of range
         with pytest.raises(GeError) as e:
             b.write_rooms(0, bad)
-        assert e.value.status == -1
+        assert e.value.status == -1 and f"room {total - 7} " in str(e.value)       # ge_last_rejected_room names the view
         bad = later.copy()
         bad["n_players"][80000] = 5                          # a view that does not fit its segment
+        bad["n_players"][90000] = 5                          # ... and a later one: the FIRST is reported
         with pytest.raises(GeError) as e:
             b.write_rooms(0, bad)
-        assert e.value.status == -1
+        assert e.value.status == -1 and "room 80000 " in str(e.value)
+        with pytest.raises(GeError) as e:                    # a write that starts in the middle of the batch: the index is the batch's
+            b.write_rooms(70000, bad[70000:100000].copy())
+        assert "room 80000 " in str(e.value)
         # a Two-Truths view inside the Werewolf x 12 segment; phase ids no table row has (either of the two)
         for room, field, value in ((100, "pack", 2), (70001 + 17, "pack", 1), (total - 1, "phase_id", 1234),
                                    (3, "prev_phase_id", -5), (70001 + 49999, "phase_id", 16)):
@@ -206,5 +210,5 @@ def test_room_views_through_the_threaded_host_conversion(dsl_ww, dsl_tt, monkeyp
             bad[field][room] = value
             with pytest.raises(GeError) as e:
                 b.write_rooms(0, bad)
-            assert e.value.status == -1, (room, field)
+            assert e.value.status == -1 and f"room {room} " in str(e.value), (room, field)
         assert b.read_rooms().tobytes() == mixed.tobytes()

@@ -122,6 +122,10 @@ def test_single_room_service_over_http():
     bt = r["burst"]
     assert bt["hist"] == 9 and bt["idsOk"] and not bt["busy"]
     assert bt["closed"] is True and "unknown thread" in bt["afterClose"] and bt["rooms"] == 1
+    # POST /message: control -> a turn, chat -> none, a game message -> logged under phase 0's name, then a turn
+    m = r["message"]
+    assert m["kinds"] == ["control", "chat", "action"] and m["played"] == [True, False, True]
+    assert m["hist"] == [10, 10, 11] and m["loggedPhase"] == "Game Introduction"
 
 
 @needs_node
