@@ -39,6 +39,20 @@ constexpr uint32_t GOLDEN = 0x9E3779B9u;
 #ifndef GE_RES_PACKED
 #define GE_RES_PACKED 1
 #endif
+// Issue priority (profiles/r05_ab_queue_prio.txt).  The large-batch fused builds are bound by latency on two half-busy shared units (vector
+//   pipe ~60 %, LDS array ~60 %: DESIGN.md 4 "Attribution"), so which wavefront issues next matters: a wavefront inside the queue's dependent
+//   LDS round trips (GE_QUEUE_PRIO, s_setprio from the context write to the result read) or inside a vote resolution's table lookups
+//   (GE_RESOLVE_PRIO) issues ahead of wavefronts doing independent vector work.  GE_RES_ATOMIC64: a queue slot of a Werewolf x 8 room returns its
+//   result with one 64-bit LDS atomic on the packed pair instead of two 32-bit ones.  Together -2.6 % at 1 M Werewolf x 8, -3.3 % Two-Truths x 4.
+#ifndef GE_QUEUE_PRIO
+#define GE_QUEUE_PRIO 3
+#endif
+#ifndef GE_RES_ATOMIC64
+#define GE_RES_ATOMIC64 1
+#endif
+#ifndef GE_RESOLVE_PRIO
+#define GE_RESOLVE_PRIO 2
+#endif
 #ifndef GE_ROWS_SPLIT
 #define GE_ROWS_SPLIT 1
 #endif
@@ -849,12 +863,18 @@ __device__ __forceinline__ void ww_queue_actions(WWR<NB> &s, const WwCtx &c, uin
     const uint32_t cnt = popc(todo);
     // N <= 8: the room's slot -> player map (nibble r = its r-th due bot) from the ord8 table; the read is
     // in flight during the scan, and a slot then needs a shift instead of an n-th-set-bit search
+#if GE_QUEUE_PRIO
+    if (!LOWOCC) __builtin_amdgcn_s_setprio(GE_QUEUE_PRIO);   // from the first table read and the scan on (Werewolf x 12 -0.7 % against raising it after the scan)
+#endif
     uint32_t ord = 0;
     if (B::ORD) ord = c.ord8[todo & 0xFFu];
     uint32_t off, total;
     wave_excl_scan(cnt, off, total);
     out.newly = 0; out.det_v = 0; out.det_w = 0;
     if (!(LOWOCC || total != 0u)) {                         // wave-uniform; LOWOCC: some room almost always has a due bot
+#if GE_QUEUE_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         shadow1();
         shadow2();
         return;
@@ -941,8 +961,13 @@ __device__ __forceinline__ void ww_queue_actions(WWR<NB> &s, const WwCtx &c, uin
         } else if (go) {
             const uint32_t ch = ww_choose<NB, true>(c4.x >> 28, i, d, c4.x & 0xFFFFu, (c4.x >> 16) & 0xFFFu, know, lokw, know, c.nth8);
             uint32_t *r = res_w + RW * L;
-            atomicOr(r, 1u << i);
-            atomicOr(r + 1 + (i >> 3), ch << (4u * (i & 7u)));
+            if (NB <= 8 && GE_RES_PACKED && GE_RES_ATOMIC64) {
+                // both result words of the room in ONE 64-bit LDS atomic (the pair is 8-byte aligned): who acted | the choice nibble
+                atomicOr(reinterpret_cast<unsigned long long *>(r), (unsigned long long)(1u << i) | ((unsigned long long)(ch << (4u * i)) << 32));
+            } else {
+                atomicOr(r, 1u << i);
+                atomicOr(r + 1 + (i >> 3), ch << (4u * (i & 7u)));
+            }
         }
         if (base + 64u >= total) break;                // wave-uniform
         c4 = fetch(k + 64u);
@@ -957,6 +982,9 @@ __device__ __forceinline__ void ww_queue_actions(WWR<NB> &s, const WwCtx &c, uin
         asm volatile("" :: "v"(c4.x), "v"(c4.y), "v"(c4.z), "v"(c4.w));
     }
     uint32_t newly = r.x;
+#if GE_QUEUE_PRIO
+    if (!LOWOCC) { asm volatile("" :: "v"(newly)); __builtin_amdgcn_s_setprio(0); }
+#endif
     if (GE_STAMPS == 1 && stamps) { asm volatile("" :: "v"(newly)); stamps->mark(2); }                 // [.. results in registers]
     const nib_t got = NB > 8 ? (nib_t)(((uint64_t)r.z << 32) | r.y) : (nib_t)r.y;
     nib_t m15;                                       // nibble mask of the players who acted now
@@ -1044,7 +1072,13 @@ __device__ __forceinline__ void ww_apply_effect(WWR<NB> &s, const DevRow &row, c
         for (int k = 0; k < R::NW; k++) s.W[k] = (s.W[k] & ~dmask.W[k]) | dealt.W[k];
         deal.gv = 0u;
     } else if (eff == EFF_NIGHT_RESOLVE || eff == EFF_DAY_RESOLVE) {
+#if GE_RESOLVE_PRIO
+        __builtin_amdgcn_s_setprio(GE_RESOLVE_PRIO);
+#endif
         resolve(true, eff == EFF_DAY_RESOLVE);
+#if GE_RESOLVE_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
     }
     const bool nbeg = eff == EFF_NIGHT_BEGIN;
     s.template clear<F_SUB>(nbeg ? R::FM : 0u);
@@ -1197,6 +1231,9 @@ __device__ __forceinline__ void tt_turn(TT<NB> &s, uint32_t &done, DevRow &row, 
             uint32_t off, total;
             wave_excl_scan(cnt, off, total);
             if (total != 0u) {                                  // wave-uniform
+#if GE_QUEUE_PRIO
+                if (TABLE) __builtin_amdgcn_s_setprio(GE_QUEUE_PRIO);
+#endif
                 lw->ctx[lane] = make_uint4(a_stm ? 1u : 0u, 0u, todo | (off << 16) | (lane << 26), tk);
                 lw->res[lane] = make_uint4(0u, 0u, 0u, 0u);
                 if (cnt != 0u) {
@@ -1225,6 +1262,9 @@ __device__ __forceinline__ void tt_turn(TT<NB> &s, uint32_t &done, DevRow &row, 
                 wave_sync();
                 const uint4 r = lw->res[lane];
                 newly = r.x;
+#if GE_QUEUE_PRIO
+                if (TABLE) { asm volatile("" :: "v"(newly)); __builtin_amdgcn_s_setprio(0); }
+#endif
                 const uint32_t got = r.y;                        // 2 bits per player, c >= 1 for every actor
                 const uint32_t t1 = (got | (got >> 1)) & 0x00555555u, m2 = t1 | (t1 << 1);
                 s.choice = (s.choice & ~m2) | got;

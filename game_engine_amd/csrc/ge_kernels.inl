@@ -4,6 +4,11 @@
 // exactly these three files and the Makefile's flags: what a committed counter profile (profiles/pmc_*.json) is tied to.
 // LDS of a step block: the table image (DevTable's leading IMG_* bytes: [phase rows][ord8][nth8][spread8][tally64], the last
 // three in the large-batch builds only), the restart template (large-batch), then one WaveLds per wavefront
+// single-turn launches: a wavefront about to store its record issues ahead of the others (it leaves, and its slot goes to a new wavefront
+// whose loads then start earlier): -0.6 % (profiles/r05_ab_k1_prio.txt; raising NEW wavefronts' priority until their loads are out costs 3 - 10 %)
+#ifndef GE_STORE_PRIO
+#define GE_STORE_PRIO 3
+#endif
 constexpr uint32_t LDS_ROWS = sizeof(DevRow) * GE_MAX_PHASES;
 constexpr uint32_t LDS_ORD8 = 1024;
 static_assert(LDS_ROWS == IMG_ORD8 && LDS_ROWS + LDS_ORD8 == IMG_NTH8, "LDS image offsets");
@@ -320,6 +325,9 @@ __device__ __forceinline__ void run_ww(const SegDev *__restrict__ sgp, const Ste
         }
     }
     if (!valid) return;
+#if GE_STORE_PRIO
+    if (SINGLE) __builtin_amdgcn_s_setprio(GE_STORE_PRIO);    // a finished wavefront leaves: its slot goes to a new one, whose loads then start earlier
+#endif
     ww_store_regs<NB>(s, deal_to_cache<NB, B::DEAL_FORM>(deal, s), w);
     store_words<L::WORDS, true>(sg.base, sg.rooms_padded, room, w);
 }
@@ -409,6 +417,9 @@ __device__ __forceinline__ void run_tt(const SegDev *__restrict__ sgp, const Ste
         }
     }
     if (!valid) return;
+#if GE_STORE_PRIO
+    if (SINGLE) __builtin_amdgcn_s_setprio(GE_STORE_PRIO);
+#endif
     L::pack(s, w);
     store_words<L::WORDS, true>(sg.base, sg.rooms_padded, room, w);
 }
