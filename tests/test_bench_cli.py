@@ -119,3 +119,24 @@ def test_gpus_2_rehearsal_on_one_card_reports_two_ranks():
             b.step(c4["turns_stepped"])
             total = (total + b.summary()["checksum"]) % (1 << 64)
     assert total == c4["checksum"]
+
+
+@pytest.mark.gpu
+def test_n1_line_carries_the_physical_figures_in_the_roofline_block():
+    """The driver keeps `roofline` whole: the physical (single-turn launch) figures of the run live inside it, each with its parity
+    check, and the line ends with `roofline` and `cpu_baseline` so that a tail of it still shows them (round-4 verdict, item 2)."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "0", "--no-other-shapes", "--no-from-init"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert list(d)[-2:] == ["roofline", "cpu_baseline"]
+    rf = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "physical", "fused", "bound_actual", "frac_of_actual_bound"):
+        assert k in rf, k
+    rows = rf["physical"]
+    assert len(rows) == 1 and rows[0]["rooms"] == 65536 and rows[0]["parity"] is True and rows[0]["hbm"] is False
+    assert 0.02 < rows[0]["frac"] < 1.0 and rows[0]["hbm_floor_frac"] == 0.0
+    assert rf["fused"][0]["steps_per_s"] == d["value"] and d["cpu_baseline"]["kind"] == "port"
+    assert "note" not in rf and len(lines[0]) < 8192             # without the other shapes the whole line fits a tail

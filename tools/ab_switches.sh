@@ -5,7 +5,8 @@
 #   tools/ab_switches.sh test <tag>   on the GPU box: parity subset + timing probe per variant -> gpurun_out/<tag>/switches.txt
 set -u
 VARIANTS=("deal8:-DGE_DEAL_PERIOD=8" "deal32:-DGE_DEAL_PERIOD=32" "ttq13:-DGE_TT_LOW_QUEUE_MIN=13" "ttq4:-DGE_TT_LOW_QUEUE_MIN=4"
-          "ww12w5:-DGE_WW12_WAVES=5" "ww8w8:-DGE_WW8_WAVES=8" "genw7:-DGE_GENERIC_WAVES=7" "stamps:-DGE_STAMPS=1")
+          "ww12w5:-DGE_WW12_WAVES=5" "ww8w8:-DGE_WW8_WAVES=8" "genw7:-DGE_GENERIC_WAVES=7" "stamps:-DGE_STAMPS=1" "clock:-DGE_STAMPS=2"
+          "lds_old:-DGE_RES_PACKED=0 -DGE_ROWS_SPLIT=0 -DGE_RES_ATOMIC64=0" "noprio:-DGE_QUEUE_PRIO=0 -DGE_RESOLVE_PRIO=0 -DGE_STORE_PRIO=0")
 cd "$(dirname "$0")/.."
 case "${1:-}" in
 build)
@@ -17,7 +18,7 @@ build)
       && echo "built sw_$name.so ($flag)" || echo "BUILD FAILED $name"
   done ;;
 test)
-  TAG=${2:-r04}; mkdir -p gpurun_out/$TAG; OUT=gpurun_out/$TAG/switches.txt; : > $OUT
+  TAG=${2:-r05}; mkdir -p gpurun_out/$TAG; OUT=gpurun_out/$TAG/switches.txt; : > $OUT
   for v in "${VARIANTS[@]}"; do
     name=${v%%:*}
     echo "== sw_$name (${v#*:})" >> $OUT
