@@ -330,7 +330,7 @@ static int reset_impl(ge_batch *b) {
 // every build gets its own register allocation (ge_kernels.inl): the record layout (or "mixed": several segments), LOWOCC (up to
 // one wavefront per SIMD), GENERIC (some table has a generic target condition) and SINGLE (the launch is exactly one turn).
 namespace {
-struct LaunchShape { dim3 grid, block; uint32_t lds; hipStream_t st; const ge_batch *b; StepArgs a; };
+struct LaunchShape { dim3 grid, block; hipStream_t st; const ge_batch *b; StepArgs a; };
 
 template <class K> inline void launch_one(K kernel, const LaunchShape &L, bool queue, bool lds_low) {
     StepArgs a = L.a;
@@ -395,7 +395,7 @@ static hipError_t launch_step(const ge_batch *b, const StepArgs &a_in, hipStream
     const bool single = a_in.n_turns == 1u, mixed = b->segs.size() > 1, low = launch_low(b, a_in);
     uint32_t bt, blocks;
     launch_geometry(b, low, single, bt, blocks);
-    LaunchShape L{dim3(blocks), dim3(bt), 0u, st, b, a_in};
+    LaunchShape L{dim3(blocks), dim3(bt), st, b, a_in};
     L.a.block_threads = bt;
     const uint32_t kind = b->segs[0].dev.kind;
     if (mixed) {
@@ -446,8 +446,6 @@ static int ensure_deal_side(ge_batch *b) {
 // launch-bound for small batches; the sequence is captured once per n_turns into a hipGraph whose
 // launches take their first turn relative to a device word, and replayed.
 constexpr uint32_t GRAPH_MIN_LAUNCHES = 4;
-
-
 
 static hipGraphExec_t graph_for(ge_batch *b, uint32_t n_turns) {
     for (auto &g : b->graphs)

@@ -13,7 +13,8 @@ from __future__ import annotations
 
 from typing import Any, Dict, List, Optional
 
-from .stepper import PACK_WEREWOLF, GeError, GameTable, RoomBatch, load_dsl_by_gamename, slot_values, view_to_agent_state
+from . import messages as M
+from .stepper import GE_ERR_ARG, PACK_WEREWOLF, GeError, GameTable, RoomBatch, load_dsl_by_gamename, slot_values, view_to_agent_state
 from .toolcalls import WW_IS_ALIVE, RoomLog, turn_tool_calls
 from .ui_script import ui_tool_calls
 
@@ -87,7 +88,6 @@ class RoomService:
                            statements phase: ge_batch_inject_action), then one turn.
         Returns {"state", "toolCalls", "uiCalls", "played", "kind"}; an action message that is no valid game action is still
         logged and still plays the turn, as in the reference."""
-        from . import messages as M
         room = self._rooms[thread_id]
         kind = M.classify(text)
         if kind == M.CHAT:
@@ -104,7 +104,7 @@ class RoomService:
                     room["batch"].inject_action(0, seat, choice)
                     break
                 except GeError as e:                     # not a living pending target of this phase: logged, no game effect
-                    if e.status != -1:                 # GE_ERR_ARG
+                    if e.status != GE_ERR_ARG:
                         raise
         out = self._turn(room, items)
         out.update(played=True, kind=kind)
@@ -124,8 +124,7 @@ class RoomService:
         deaths = [c["args"]["player_id"] for c in calls if c["name"] == "update_player_state"
                   and c["args"]["state_name"] == "is_alive" and c["args"]["state_value"] is False]
         ui = ui_tool_calls(room["table"].dsl, state, room["table"], turn=int(event["turn"]), deaths=deaths, items=items)
-        from .messages import newest_panel
-        room["panel"] = newest_panel(ui)                  # what a person's next vote message can answer
+        room["panel"] = M.newest_panel(ui)                # what a person's next vote message can answer
         return {"state": state, "toolCalls": calls, "uiCalls": ui}
 
     def close(self, thread_id: Optional[str] = None):

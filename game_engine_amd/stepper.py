@@ -35,6 +35,9 @@ _TEAMS = ["", "villagers", "werewolves"]
 SLOT_DET_MEMORY, SLOT_WOLF_CHAT, SLOT_STATEMENTS = 9, 10, 9
 
 
+GE_ERR_ARG = -1                           # include/ge_step.h ge_status
+
+
 class GeError(RuntimeError):
     def __init__(self, status: int, what: str = ""):
         msg = _lib.load().ge_strerror(status).decode()

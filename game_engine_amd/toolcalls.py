@@ -199,16 +199,13 @@ class RoomLog:
         passes `state.get("currentPhaseId", 0)` and `state.get("playerStates", {})`, keys the state does not have
         (agent/game_agent_v2.py:324-331), so the phase id is always 0 and the name comes from roomSession.  Mirrored, not
         corrected: the string layer is the reference's (POLICY.md 3b)."""
-        from .messages import logged_text
-        self.calls_fold_person(logged_text(text), self.table.phase_name(0), now_ms)
-
-    def calls_fold_person(self, action: str, phase: str, now_ms: Optional[int]) -> None:
         import time
+        from .messages import logged_text
         rec = self.player_actions.setdefault("1", {"name": self.names[0], "actions": {}})
-        aid = str(max((int(x["id"]) for x in rec["actions"].values()), default=0) + 1)
+        aid = str(max((int(x["id"]) for x in rec["actions"].values()), default=0) + 1)       # Player 1's own sequence, bt:323-332
         rec["name"] = self.names[0]
-        rec["actions"][aid] = {"action": action, "timestamp": int(time.time() * 1000) if now_ms is None else now_ms,
-                               "phase": phase, "id": aid}
+        rec["actions"][aid] = {"action": logged_text(text), "timestamp": int(time.time() * 1000) if now_ms is None else now_ms,
+                               "phase": self.table.phase_name(0), "id": aid}
 
     def agent_state(self, view) -> Dict[str, Any]:
         """AgentState of the room (v2:97-117) with the reference's key order inside player_states."""
