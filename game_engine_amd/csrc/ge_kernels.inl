@@ -36,6 +36,7 @@ struct StepArgs {
     unsigned long long *stamps; // GE_STAMPS diagnostic build: 4 segment sums + wave-turn count (else null)
     uint32_t n_seg, turn0, n_turns, seed_key, block_threads, restart, trace, lowocc;
     uint32_t cond_off;         // GENERIC builds: byte offset of the literal image (DevTable::cond_img) in a block's LDS, behind everything else
+    uint32_t rooms_per_block;  // rooms a block steps: blockDim.x, or 32 of its 64 lanes (ge_step.hip launch_geometry: half-filled lone wavefronts)
     uint32_t block_begin[GE_MAX_SEGMENTS];
 };
 
@@ -478,7 +479,8 @@ __device__ __forceinline__ void step_body(const SegDev *__restrict__ segs, const
     DevRow *rows = reinterpret_cast<DevRow *>(ge_lds);
     uint8_t *nth8 = ge_lds + LDS_ROWS + LDS_ORD8;
     auto *wl = reinterpret_cast<typename WaveLdsOf<LOWOCC>::type *>(ge_lds + LDS_ROWS + LDS_ORD8 + (LOWOCC ? 0u : LDS_NTH8 + LDS_S0));
-    const uint64_t room = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // (a lane past rooms_per_block holds no room: it shadows room 0 like a lane past the end of the segment)
+    const uint64_t room = (!LOWOCC || threadIdx.x < a.rooms_per_block) ? (uint64_t)blockIdx.x * (LOWOCC ? a.rooms_per_block : blockDim.x) + threadIdx.x : ~0ull;
     run_kind<KIND, LOWOCC, GENERIC, SINGLE>(segs, a, rows, WWK ? &wl[threadIdx.x >> 6] : nullptr, nth8, tables, room);
 }
 template <int KIND, bool LOWOCC, int GENERIC = false, bool SINGLE = false>

@@ -368,8 +368,9 @@ template <bool LOW, int GEN> inline void launch_mixed(bool single, const LaunchS
 }  // namespace
 
 // rooms per block and number of blocks of a launch of n_turns turns
-static void launch_geometry(const ge_batch *b, bool low, bool single, uint32_t &bt, uint32_t &blocks) {
+static void launch_geometry(const ge_batch *b, bool low, bool single, uint32_t &bt, uint32_t &blocks, uint32_t &rpb) {
     bt = b->block_threads; blocks = b->n_blocks;
+    rpb = bt;                                                   // rooms per block
     // One turn per launch (max_fuse = 1, or the tail of a step): a block's first act is to fill its 7 KB of LDS tables behind a
     // barrier - the fewer blocks, the less of that per launch - so a large single-game Werewolf x 8 batch runs these launches in
     // blocks of 512 rooms (GE_SINGLE_BLOCK = 256 / 512 / 1024 overrides, for A/B runs); a single game's rooms start at block 0,
@@ -384,6 +385,20 @@ static void launch_geometry(const ge_batch *b, bool low, bool single, uint32_t &
     if (single && b->segs.size() == 1 && !b->generic && !low && bt == 256u) {
         bt = single_block_env ? single_block_env : (b->segs[0].dev.kind == K_WW8 ? 512u : 256u);
         blocks = (uint32_t)((b->segs[0].dev.rooms + bt - 1u) / bt);
+        rpb = bt;
+    }
+    // Half-filled lone wavefronts: a fused launch over a single-game batch of at most 32 768 rooms runs 32 rooms per wavefront (still
+    // at most one wavefront per SIMD).  A lone wavefront's time is its instruction stream, whatever its lanes hold, and a wavefront of
+    // 32 rooms almost never needs the second round of its action queue that 43 % (Werewolf x 8) to 86 % (x 12) of the 64-room
+    // wave-turns take: at 32 768 rooms Werewolf x 8 1.09 -> 0.97 us per turn (-11 %), x 12 -16 %, Two-Truths x 4 / 8 / 12 -9 / -16 /
+    // -19 % (profiles/r05_ab_half_waves.txt).  Not beyond 32 768: two such wavefronts on a SIMD take 1.39 us against 1.06 for one
+    // full one - at this occupancy a SIMD issues about one instruction per 4 cycles in all.  Not for single-turn launches (twice the
+    // blocks to fill tables for: up to +9 %).  GE_HALF_WAVES=0 / 1 forces it off / on (A/B, and a knob run of the test suite)
+    static const int half_env = [] { const char *e = getenv("GE_HALF_WAVES"); return e ? atoi(e) : -1; }();
+    const bool half_fits = b->segs.size() == 1 && low && bt == 64u && (!single || half_env == 1);
+    if (half_fits && (half_env == 1 || (half_env != 0 && b->segs[0].dev.rooms <= 32768u))) {
+        rpb = 32u;
+        blocks = (uint32_t)((b->segs[0].dev.rooms + 31u) / 32u);
     }
 }
 
@@ -393,10 +408,11 @@ static bool launch_low(const ge_batch *b, const StepArgs &a) {
 
 static hipError_t launch_step(const ge_batch *b, const StepArgs &a_in, hipStream_t st) {
     const bool single = a_in.n_turns == 1u, mixed = b->segs.size() > 1, low = launch_low(b, a_in);
-    uint32_t bt, blocks;
-    launch_geometry(b, low, single, bt, blocks);
+    uint32_t bt, blocks, rpb;
+    launch_geometry(b, low, single, bt, blocks, rpb);
     LaunchShape L{dim3(blocks), dim3(bt), st, b, a_in};
     L.a.block_threads = bt;
+    L.a.rooms_per_block = rpb;
     const uint32_t kind = b->segs[0].dev.kind;
     if (mixed) {
         if (b->generic) launch_mixed<false, 1>(single, L);

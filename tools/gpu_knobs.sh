@@ -11,3 +11,5 @@ run block64_nograph GE_BLOCK_THREADS=64 GE_NO_GRAPH=1
 run single_block512 GE_SINGLE_BLOCK=512 GE_BLOCK_THREADS=256 GE_LOWOCC_ROOMS=0
 run single_block1024 GE_SINGLE_BLOCK=1024 GE_BLOCK_THREADS=256 GE_LOWOCC_ROOMS=0
 run no_generic_shapes GE_NO_GENERIC_SHAPES=1
+run half_waves_on GE_HALF_WAVES=1
+run half_waves_off GE_HALF_WAVES=0
