@@ -517,3 +517,21 @@ def test_mixed_batch_with_werewolf_12_single_turn_launches(dsl_ww, dsl_tt, n_roo
         want = oracle_batch(_oracle(dsl, n), r, seed, first + lo, t, restart=True)
         assert_views_equal(got[lo:lo + r], want, f"mixed batch segment x{n}, {n_rooms} rooms")
         lo += r
+
+
+@pytest.mark.parametrize("game,n", [("werewolf-(mafia)", 8), ("werewolf-(mafia)", 12), ("two-truths-and-a-lie", 4), ("two-truths-and-a-lie", 9)])
+def test_half_filled_lone_wavefronts_around_their_threshold(game, n):
+    """A fused launch over at most 32 768 rooms runs 32 rooms per wavefront (csrc/ge_step.hip launch_geometry), one more room and it
+    is 64 again; ragged sizes leave a last wavefront with a handful of rooms in either form.  Every room against the oracle, steady
+    state, and the same batch stepped in single-turn launches (always 64 rooms per wavefront) ends in the same bytes."""
+    dsl = load_dsl(game)
+    tb, orc = GameTable(dsl), _oracle(dsl, n)
+    for rooms in (32768, 32769, 31, 33, 32768 - 17):
+        seed, first, turns = 0xBEEF + rooms, (1 << 34) + rooms, 75
+        want = oracle_batch(orc, rooms, seed, first, turns, restart=True)
+        with RoomBatch([(tb, n, rooms)], seed=seed, first_room=first, restart=True) as f, \
+             RoomBatch([(tb, n, rooms)], seed=seed, first_room=first, restart=True, max_fuse=1) as k1:
+            f.step(turns); k1.step(turns)
+            got = f.read_rooms()
+            assert_views_equal(got, want, f"{game} x{n}, {rooms} rooms, fused")
+            assert got.tobytes() == k1.read_rooms().tobytes() and f.summary() == k1.summary()
