@@ -128,7 +128,7 @@ def cpu_baseline(spec, budget_s=12.0, sample_rooms=None, single_thread=True):
     for orc, _, _, rooms in parts:                                   # calibrate
         orc.run(orc.init_rooms(rooms), SEED, 0, 0, 8, threads=cores, restart=True)
     dt = max(time.perf_counter() - t0, 1e-4)
-    turns = int(min(max(8 * budget_s / dt, 16), 4096))
+    turns = int(min(max(8 * budget_s / dt, 16), 16384))
     states = [orc.init_rooms(rooms) for orc, _, _, rooms in parts]
     t0 = time.perf_counter()
     for (orc, _, _, _), state in zip(parts, states):
