@@ -66,13 +66,13 @@ _lib = None
 
 def kernel_source_hash() -> str:
     """sha256 over the device code libge_step.so is built from - the kernels (ge_kernels.inl), the turn (ge_device.h), the record
-    layout (ge_layout.h) - and the Makefile, whose compiler flags shape them: what ties a committed counter profile
+    layout (ge_layout.h) - and the Makefile and peephole.sed, whose compiler flags and rewrites shape them: what ties a committed counter profile
     (profiles/pmc_*.json, tools/pmc_summary.py) to the kernels it was measured on (bench.py does not quote a profile of other
     kernels).  Host-side sources (ge_step.hip, ge_group.inl, ge_table.cpp) are not part of it."""
     import hashlib
     h = hashlib.sha256()
     src = os.path.join(_HERE, "csrc")
-    for name in ("Makefile", "ge_device.h", "ge_kernels.inl", "ge_layout.h"):
+    for name in ("Makefile", "peephole.sed", "ge_device.h", "ge_kernels.inl", "ge_layout.h"):
         with open(os.path.join(src, name), "rb") as f:
             h.update(name.encode() + b"\0" + f.read())
     return h.hexdigest()

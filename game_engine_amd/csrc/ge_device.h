@@ -31,6 +31,14 @@ constexpr uint32_t GOLDEN = 0x9E3779B9u;
 //   is outstanding anyway, accumulated per wavefront; never in the product build.  GE_STAMPS=2: only the two clocks at a
 //   wavefront's start and end - s_memtime (shader cycles) against s_memrealtime (constant 100 MHz): the shader clock the
 //   turn loop really ran at, un-profiled (tools/clock_probe.py)
+// GE_DEAL_EARLY=1: the large-batch fused builds prepare the next deal (every GE_DEAL_PERIOD-th turn) at the head of the turn, not inside
+//   the action queue's second LDS shadow: there the compiler duplicated the ~130-instruction deal into both continuations of the queue
+//   and carried the prepared deal's words through two register sets, copied over on every turn.  Werewolf x 8 large-batch build 803 ->
+//   676 vector instructions, 1 M rooms -0.8 %, Werewolf x 12 -0.5 % (profiles/r05_ab_valu_price.txt; the lone-wavefront build keeps the
+//   shadow: a lone wavefront has nothing else to run during an LDS round trip)
+#ifndef GE_DEAL_EARLY
+#define GE_DEAL_EARLY 1
+#endif
 #ifndef GE_STAMPS
 #define GE_STAMPS 0
 #endif
@@ -78,6 +86,7 @@ template <int NB, bool LOWOCC, bool SINGLE = false> struct WwBuild {
     static constexpr bool SEL_OPEN = LOWOCC;                // completion test without short-circuit evaluation (r02_ab_open_tpldeal)
     static constexpr bool TPL_TRACE = LOWOCC;               // the turn loop compiled once per trace setting (r02_ab_branch_diet)
     static constexpr int DEAL_FORM = SINGLE ? 2 : LOWOCC ? 0 : NB <= 8 ? 1 : 2;   // DEAL_PACKED / DEAL_MASKS / DEAL_WORDS, see struct Deal
+    static constexpr bool DEAL_EARLY = GE_DEAL_EARLY && !LOWOCC && !SINGLE;   // the deal is prepared at the head of the turn, not in the queue's second LDS shadow (see ww_turn)
     static constexpr bool TABLE = !LOWOCC;                  // n-th-set-bit through the 2 KB LDS table instead of ~15 VALU instructions
 };
 
@@ -818,10 +827,13 @@ __device__ __forceinline__ void ww_phase_branch(const WWR<NB> &s, const DevRow &
     const bool guard = s.phase == phase0_idx && !(s.flags & FLAG_PHASE0_DONE);
     b.open = !guard;
     const uint32_t w = popc(alive & team_w), g = popc(alive & s.template get<F_TEAM_V>());
-    const uint32_t prev_eff = (s.flags >> 1) & 7u;
-    const uint32_t C = 1u | ((w == 0u) << RES_WOLVES_ZERO) | ((w >= g) << RES_WOLVES_GE_VILLAGERS) |
-                       ((prev_eff == EFF_DAY_RESOLVE) << RES_FOLLOWS_DAY) |
-                       ((prev_eff == EFF_NIGHT_RESOLVE) << RES_FOLLOWS_NIGHT) | (1u << RES_OTHERWISE);
+    // (prev_eff == EFF_DAY_RESOLVE) << RES_FOLLOWS_DAY | (prev_eff == EFF_NIGHT_RESOLVE) << RES_FOLLOWS_NIGHT, prev_eff = flags bits 1..3,
+    // as three simple instructions instead of a field extract, two compares and two selects (a compare or a select costs a SIMD as
+    // much as two simple instructions: profiles/r05_encoding_probe.txt): 0xC00 >> 2 * prev_eff has bit 3 set for 4, bit 4 for 3
+    static_assert(EFF_DAY_RESOLVE == 4 && RES_FOLLOWS_DAY == 3 && EFF_NIGHT_RESOLVE == 3 && RES_FOLLOWS_NIGHT == 4 && FLAG_PHASE0_DONE == 1,
+                  "the constant below is made for these codes");
+    const uint32_t follows = (0xC00u >> (s.flags & 0xEu)) & 0x18u;
+    const uint32_t C = 1u | ((w == 0u) << RES_WOLVES_ZERO) | ((w >= g) << RES_WOLVES_GE_VILLAGERS) | follows | (1u << RES_OTHERWISE);
     // first branch (DSL order) whose resolver holds: row.r2 has one byte per branch with the bit of
     // its resolver set (0 for absent branches), so the lowest non-zero byte of r2 & (C in every byte) wins
     const uint32_t hit = row.r2 & __builtin_amdgcn_perm(C, C, 0u);   // C (< 256) in every byte
@@ -1110,6 +1122,7 @@ __device__ __forceinline__ void ww_turn(WWR<NB> &s, DevRow &row, const WwCtx &c,
 
     WwBranch br;
     R dealt;
+    if (B::DEAL_EARLY) ww_prepare_deal<NB, LOWOCC, SINGLE>(s, c, deal, deal_now, ALL, dealt);
     uint32_t tk_next = 0;
     WwActs acts;
     ww_queue_actions<NB, LOWOCC>(s, c, T, act, night, alive, team_w, r_det, tk_io, acts,
@@ -1119,10 +1132,10 @@ __device__ __forceinline__ void ww_turn(WWR<NB> &s, DevRow &row, const WwCtx &c,
         },
         [&]() {
             if (!SINGLE) tk_next = turn_key(c.rkey, turn + 1u);
-            ww_prepare_deal<NB, LOWOCC, SINGLE>(s, c, deal, deal_now, ALL, dealt);
+            if (!B::DEAL_EARLY) ww_prepare_deal<NB, LOWOCC, SINGLE>(s, c, deal, deal_now, ALL, dealt);
             if (B::SHADOW) {
                 if (!SINGLE) asm volatile("" : "+v"(tk_next));
-                if (B::DEAL_FORM != DEAL_PACKED) {
+                if (B::DEAL_FORM != DEAL_PACKED && !B::DEAL_EARLY) {
 #pragma unroll
                     for (int k = 0; k < R::NW; k++) asm volatile("" : "+v"(dealt.W[k]));
                 }

@@ -6,15 +6,14 @@
 set -u
 VARIANTS=("deal8:-DGE_DEAL_PERIOD=8" "deal32:-DGE_DEAL_PERIOD=32" "ttq13:-DGE_TT_LOW_QUEUE_MIN=13" "ttq4:-DGE_TT_LOW_QUEUE_MIN=4"
           "ww12w5:-DGE_WW12_WAVES=5" "ww8w8:-DGE_WW8_WAVES=8" "genw7:-DGE_GENERIC_WAVES=7" "stamps:-DGE_STAMPS=1" "clock:-DGE_STAMPS=2"
-          "lds_old:-DGE_RES_PACKED=0 -DGE_ROWS_SPLIT=0 -DGE_RES_ATOMIC64=0" "noprio:-DGE_QUEUE_PRIO=0 -DGE_RESOLVE_PRIO=0 -DGE_STORE_PRIO=0")
+          "lds_old:-DGE_RES_PACKED=0 -DGE_ROWS_SPLIT=0 -DGE_RES_ATOMIC64=0" "noprio:-DGE_QUEUE_PRIO=0 -DGE_RESOLVE_PRIO=0 -DGE_STORE_PRIO=0" "deal_in_shadow:-DGE_DEAL_EARLY=0")
 cd "$(dirname "$0")/.."
 case "${1:-}" in
 build)
   mkdir -p game_engine_amd/ab
   for v in "${VARIANTS[@]}"; do
     name=${v%%:*}; flag=${v#*:}
-    # the Makefile's own compile line (make -n), with the switch added and the output beside the product library
-    ( cd game_engine_amd/csrc && cmd=$(make -n -B | grep -m1 -- "-shared") && eval "${cmd/-shared -o ..\/libge_step.so/$flag -shared -o ../ab/sw_$name.so}" ) \
+    ( make -C game_engine_amd/csrc -s OUT=../ab/sw_$name.so B=build/sw_$name EXTRA="$flag" 2>&1 | grep -i "error" ; test -f game_engine_amd/ab/sw_$name.so ) \
       && echo "built sw_$name.so ($flag)" || echo "BUILD FAILED $name"
   done ;;
 test)

@@ -50,7 +50,7 @@ for label, key in (("33554432 Werewolf x8 (1 GiB of records)", "ww8_33554432"), 
 begin("attrib_table")
 # where the fused launches' time goes: counters of tools/attrib_profile.sh (profiles/<tag>_<shape>_attrib_counters.json), per wave-turn
 def A(k): return json.load(open(os.path.join(root, "profiles", f"{tag}_{k}_attrib_counters.json")))
-print("| shape (fused) | SIMD cycles per wave-turn | vector pipe busy (VALU x 2 cycles) | active lanes per VALU instruction | LDS array busy (of it bank-conflict replays) | a wavefront's residency: issuing / issue-stalled (of it on the LDS) / parked at a wait | mean resident wavefronts per SIMD | instruction fetches, I-cache misses |\n|---|---|---|---|---|---|---|---|")
+print("| shape (fused) | SIMD cycles per wave-turn | vector instructions x the nominal 2 cycles | active lanes per VALU instruction | LDS array busy (of it bank-conflict replays) | a wavefront's residency: issuing / issue-stalled (of it on the LDS) / parked at a wait | mean resident wavefronts per SIMD | instruction fetches, I-cache misses |\n|---|---|---|---|---|---|---|---|")
 for k in SHAPES:
     try: a = A(k)
     except OSError: continue
@@ -66,6 +66,10 @@ begin("asm_table")
 sys.path.insert(0, os.path.join(root, "tools"))
 import asm_table as _asm
 for line in _asm.markdown(_asm.collect(rebuild=True)).splitlines(): print(line)
+begin("valu_mix")
+# the vector instructions priced by what each kind costs a SIMD (tools/microbench/encoding_probe.hip): tools/valu_mix.py over the ge_step.s just rebuilt
+import valu_mix as _mix
+for line in _mix.table(tag): print(line)
 begin("result_table")
 print("| shape | fused (1 024 turns/launch): steps/s | alg. GB/s (% of 8 TB/s: a yardstick, not traffic) | single-turn launches: memory-side % of 8 TB/s (sustained; state fits the Infinity Cache) | CPU: oracle, steps/s (cores) |\n|---|---|---|---|---|")
 print(f"| C2: 65 536 Werewolf × 8 — the `bench.py` line | **{bench['value']:.3g}** (wall) | {bench['roofline']['achieved']:.0f} ({100 * bench['roofline']['frac']:.1f}) | {100 * bench['hbm_streaming']['frac']:.1f} (launch-bound: {bench['hbm_streaming']['us_per_launch_sustained']:.1f} µs per launch) | {bench['cpu_baseline']['value']:.3g} ({bench['cpu_baseline']['cores']}); one thread {bench['cpu_baseline']['single_thread_value']:.3g} |")
