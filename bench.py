@@ -190,7 +190,22 @@ def spawn_ranks(args, argv):
     sys.stdout.flush()
 
 
-def issue_block(prof, rooms, turns, kernel_s):
+def valu_price(key):
+    """(mean cycles per vector instruction of this shape's fused kernel, cycles per instruction for a lone wavefront) from
+    profiles/valu_mix.json (tools/valu_mix.py --write: the binary's instruction mix priced by tools/microbench/encoding_probe.hip's
+    per-class costs), or None when it was made for other device code"""
+    from game_engine_amd._lib import kernel_source_hash
+    try:
+        with open(os.path.join(ROOT, "profiles", "valu_mix.json")) as f:
+            d = json.load(f)
+    except (OSError, ValueError):
+        return None
+    if d.get("kernel_src_sha256") != kernel_source_hash() or key not in d.get("mean_price_cycles", {}):
+        return None
+    return float(d["mean_price_cycles"][key]), float(d.get("lone_wavefront_cycles", 5.2))
+
+
+def issue_block(prof, rooms, turns, kernel_s, key=None):
     """The bound of the fused kernel: wave-instructions issued per second against the SIMD issue
     ceiling.  A wave64 VALU instruction occupies its SIMD-32 for 2 cycles (MI355X_MICROARCH.md:54, :473)
     -> 1 024 SIMDs x 2.4 GHz / 2 = 1.23e12 wave-instr/s with >= 2 wavefronts per SIMD; a wavefront ALONE
@@ -214,6 +229,15 @@ def issue_block(prof, rooms, turns, kernel_s):
                     "valu_frac": float(ipt.get("valu", 0)) * wave_turns_per_s / ceiling,
                     "wait_any_frac_of_wave_cycles": prof.get("wait_any_frac"),
                     "source": f"{prof.get('_path')} (committed rocprofv3 --pmc SQ pass of this shape and fuse setting, same kernel sources)"})
+        # the same count at what the instructions really cost a SIMD (profiles/r05_encoding_probe.txt: 2.3 cycles for a simple op,
+        # 4.15 for fused / bit-field / multiply / compare / DPP ...; a lone wavefront ~5.2 per instruction of any kind): the share of
+        # its SIMD's cycles a wave-turn's vector instructions occupy.  valu_frac (nominal 2 cycles) FALLS when cheap instructions are removed
+        price = valu_price(key) if (key and turns > 1) else None
+        if price:
+            cyc_i = price[1] if waves_per_simd < 2.0 else price[0]
+            out.update({"valu_mean_price_cycles": cyc_i,
+                        "valu_priced_frac": float(ipt.get("valu", 0)) * cyc_i / out["simd_cycles_per_wave_turn"],
+                        "valu_price_source": "profiles/valu_mix.json (tools/valu_mix.py: static instruction mix x tools/microbench/encoding_probe.hip class costs, same kernel sources)"})
     else:
         out.update({"instructions_per_wave_turn": None, "frac": None,
                     "source": (f"{prof.get('_path')} is stale: taken on other kernel sources (kernel_src_sha256 differs)" if ipt else None)})
@@ -452,7 +476,7 @@ def main():
                             "us_per_turn": ms * 1e3 / turns, "turns_timed": turns, "bytes_per_room_record": bpr,
                             "algorithmic_GBs": alg, "algorithmic_frac": alg / HBM_PEAK_GBS,
                             "bound_actual": "valu-issue",
-                            "issue": issue_block(committed_profile(key, args.fuse), r, turns, ms * 1e-3),
+                            "issue": issue_block(committed_profile(key, args.fuse), r, turns, ms * 1e-3, key if args.fuse > 1 else None),
                             "hbm_streaming": None if args.no_unfused else streaming_point(sp, launches=128)}
             if not args.no_cpu_baseline:
                 other[label]["cpu_baseline"] = cpu_baseline(sp, budget_s=4.0, sample_rooms=1 << 18, single_thread=False)
@@ -516,8 +540,8 @@ def main():
         prof = committed_profile(args.workload if not args.rooms else f"ww8_{args.rooms}", args.fuse)
         state_rw = 2.0 * bytes_per_room * rooms
         traffic = prof.get("hbm_bytes_per_launch") if abs(prof.get("state_bytes_read_plus_written", -1) - state_rw) < 1 else None
-        issue = issue_block(prof, rooms, turns_timed, kernel_ms * 1e-3)
         fused = args.fuse > 1
+        issue = issue_block(prof, rooms, turns_timed, kernel_ms * 1e-3, (args.workload if not args.rooms else f"ww8_{args.rooms}") if fused else None)
         def phys(label, pt):
             """one row of roofline.physical: a single-turn launch that really moves the state, from this run's HIP events"""
             return {"shape": label, "rooms": pt["rooms"], "state_MiB": round(pt["resident_state_MiB"], 1),
@@ -534,10 +558,10 @@ def main():
             if o.get("hbm_streaming"):
                 physical.append(phys(label, o["hbm_streaming"]))
         fused_rows = [{"shape": f"{rooms} {GAME} x{N_PLAYERS} ({args.workload})", "us_per_turn": round(kernel_ms * 1e3 / turns_timed, 3),
-                       "steps_per_s": total_steps / elapsed, "valu_frac": issue.get("valu_frac"), "issue_frac": issue.get("frac")}]
+                       "steps_per_s": total_steps / elapsed, "valu_frac": issue.get("valu_frac"), "valu_priced_frac": issue.get("valu_priced_frac"), "issue_frac": issue.get("frac")}]
         for label, o in (other or {}).items():
             fused_rows.append({"shape": label, "us_per_turn": round(o["us_per_turn"], 3), "steps_per_s": o["value"],
-                               "valu_frac": o["issue"].get("valu_frac"), "issue_frac": o["issue"].get("frac")})
+                               "valu_frac": o["issue"].get("valu_frac"), "valu_priced_frac": o["issue"].get("valu_priced_frac"), "issue_frac": o["issue"].get("frac")})
         out = {
             "metric": "room-phase steps/sec", "value": total_steps / elapsed, "unit": "room-phase steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -569,6 +593,8 @@ def main():
                          "algorithmic": True, "algorithmic_bytes_per_launch": alg_bytes,
                          "bound_actual": "valu-issue" if fused else "hbm",
                          "frac_of_actual_bound": issue.get("valu_frac") if fused else achieved / HBM_PEAK_GBS,
+                         # ... and the same with every vector instruction at its measured price instead of a nominal 2 cycles (issue.valu_priced_frac)
+                         "frac_of_priced_bound": issue.get("valu_priced_frac") if fused else None,
                          "hbm_frac_of_measured_traffic": (traffic / avg_launch_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
                          # the PHYSICAL figures of this run: single-turn launches (max_fuse = 1), every launch reads and writes every
                          # record; frac = state read + written / device time per launch (HIP events around a replayed hipGraph on the

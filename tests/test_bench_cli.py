@@ -133,8 +133,11 @@ def test_n1_line_carries_the_physical_figures_in_the_roofline_block():
     d = json.loads(lines[0])
     assert list(d)[-2:] == ["roofline", "cpu_baseline"]
     rf = d["roofline"]
-    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "physical", "fused", "bound_actual", "frac_of_actual_bound"):
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "physical", "fused", "bound_actual", "frac_of_actual_bound", "frac_of_priced_bound"):
         assert k in rf, k
+    # the vector pipe's share at measured instruction prices: quoted only from a profiles/valu_mix.json made for this device code
+    if rf["frac_of_priced_bound"] is not None:
+        assert rf["frac_of_actual_bound"] < rf["frac_of_priced_bound"] < 1.05 and d["issue"]["valu_mean_price_cycles"] >= 2.0
     rows = rf["physical"]
     assert len(rows) == 1 and rows[0]["rooms"] == 65536 and rows[0]["parity"] is True and rows[0]["hbm"] is False
     assert 0.02 < rows[0]["frac"] < 1.0 and rows[0]["hbm_floor_frac"] == 0.0

@@ -1,6 +1,7 @@
 #!/bin/bash
-# The round's GPU records, in three box calls (a call is limited to 20 minutes):
+# The round's GPU records, in four box calls (a call is limited to 20 minutes):
 #   tools/gpu_baseline.sh <tag> fused     counter / kernel-trace passes of the fused bench shapes
+#   tools/gpu_baseline.sh <tag> attrib    the attribution passes of the same shapes (tools/attrib_profile.sh: LDS, front end, lanes, CU-busy cycles)
 #   tools/gpu_baseline.sh <tag> single    ... of the single-turn launches, BASELINE shapes and the beyond-Infinity-Cache shapes
 #   (copy gpurun_out/profiles_out/pmc_*.json into profiles/ in between: the bench lines quote the profiles of THIS kernel build)
 #   tools/gpu_baseline.sh <tag> bench     the -m gpu suite, the bench under the driver's flags, the C5 line, the 2-rank rehearsal, RCCL with one rank
@@ -15,6 +16,13 @@ fused)
   bash tools/profile.sh $TAG c4 --workload c4 --steps 2 --warmup 0
   bash tools/profile.sh $TAG c3 --workload c3 --steps 2 --warmup 0
   bash tools/profile.sh $TAG c5 --workload c5 --steps 2 --warmup 0        # one GPU's share of the mixed batch (ge_step_kernel_mixed)
+  ;;
+attrib)
+  bash tools/attrib_profile.sh $TAG c2 --steps 4 --warmup 1
+  bash tools/attrib_profile.sh $TAG ww8_1048576 --rooms 1048576 --steps 2 --warmup 0
+  bash tools/attrib_profile.sh $TAG c4 --workload c4 --steps 2 --warmup 0
+  bash tools/attrib_profile.sh $TAG c3 --workload c3 --steps 2 --warmup 0
+  bash tools/attrib_profile.sh $TAG c5 --workload c5 --steps 2 --warmup 0
   ;;
 single)
   bash tools/profile.sh $TAG c2_k1
@@ -45,3 +53,6 @@ PY
   GE_FORCE_DIST=1 timeout -k 10 300 python bench.py --gpus 1 --steps 4 --warmup 1 --no-cpu-baseline --no-other-shapes --no-from-init --no-unfused > gpurun_out/$TAG/bench_rccl_one_rank.json 2> gpurun_out/$TAG/bench_rccl.err; echo "bench rccl rc=$?"
   ;;
 esac
+# the raw per-pass directories have been summarised into gpurun_out/profiles_out/ (tools/pmc_summary.py); they alone exceed what a box call
+# copies back (64 MiB)
+case "$PART" in fused|attrib|single) rm -rf gpurun_out/prof_${TAG}_* ;; esac

@@ -39,13 +39,16 @@ def price(op, args):
 
 
 KEYS = {"ww8_1048576": ("1 048 576 Werewolf × 8", "ILi0ELb0ELi0ELb0E"), "c4": ("C4 share: 2 097 152 Werewolf × 12", "ILi1ELb0ELi0ELb0E"),
-        "c3": ("C3: 1 048 576 Two-Truths × 4", "ILi2ELb0ELi0ELb0E"), "c2": ("C2: 65 536 Werewolf × 8, a lone wavefront per SIMD", "ILi0ELb1ELi0ELb0E")}
+        "c3": ("C3: 1 048 576 Two-Truths × 4", "ILi2ELb0ELi0ELb0E"),
+        "c5": ("C5 share: 524 288 Werewolf × 8 + 524 288 Two-Truths × 4, one launch", "_mixedILb0ELi0ELb0E"),
+        "c2": ("C2: 65 536 Werewolf × 8, a lone wavefront per SIMD", "ILi0ELb1ELi0ELb0E")}
+LONE = 5.2          # a lone wavefront: cycles per vector instruction of any kind (the probe's 1-wavefront column)
 OTHER = "other half-rate (fused 3-operand, bfe, perm, bcnt, ffbl, 64-bit, DPP ...)"
 
 
 def mix(txt, mangled):
     """(instructions by kind, priced cycles) of the vector instructions of one kernel of ge_step.s"""
-    i = txt.index("ge_step_kernel" + mangled)
+    i = txt.index("ge_step_kernel" + mangled + "E")
     body = txt[txt.rfind("\n", 0, i):txt.index("s_endpgm", i)]
     n = collections.Counter(); cyc = 0.0
     for ln in body.splitlines():
@@ -66,8 +69,8 @@ def table(tag="r05"):
         try:
             valu = json.load(open(os.path.join(ROOT, "profiles", f"pmc_{key}.json")))["instructions_per_wave_turn"]["valu"]
             simd = 4.0 * json.load(open(os.path.join(ROOT, "profiles", f"{tag}_{key}_attrib_counters.json")))["SQ_BUSY_CU_CYCLES"]["per_wave_turn"]
-            if key == "c2":                                  # a lone wavefront: ~5.2 cycles per vector instruction whatever its kind (the probe's 1-wavefront column)
-                tail = f"{valu:.0f} × 5.2 (a lone wavefront: any kind) = {valu * 5.2:.0f} | {simd:.0f} | {100 * valu * 5.2 / simd:.0f} % |"
+            if key == "c2":
+                tail = f"{valu:.0f} × {LONE} (a lone wavefront: any kind) = {valu * LONE:.0f} | {simd:.0f} | {100 * valu * LONE / simd:.0f} % |"
             else:
                 tail = f"{valu:.0f} × {mean:.2f} = {valu * mean:.0f} | {simd:.0f} | {100 * valu * mean / simd:.0f} % |"
         except (OSError, KeyError):
@@ -78,5 +81,27 @@ def table(tag="r05"):
     return rows
 
 
+def write():
+    """profiles/valu_mix.json: the mean price per fused kernel, tied to the device code by its hash (bench.py quotes it as `valu_priced_frac`)"""
+    sys.path.insert(0, ROOT)
+    from game_engine_amd._lib import kernel_source_hash
+    txt = open(os.path.join(ROOT, "game_engine_amd", "csrc", "ge_step.s")).read()
+    out = {"kernel_src_sha256": kernel_source_hash(), "prices_from": "profiles/r05_encoding_probe.txt (tools/microbench/encoding_probe.hip)",
+           "what": "mean cycles a SIMD spends per vector instruction of the kernel's binary (static mix) at >= 4 wavefronts per SIMD; "
+                   "a lone wavefront issues one vector instruction of any kind per lone_wavefront_cycles",
+           "lone_wavefront_cycles": LONE, "mean_price_cycles": {}, "vector_instructions_in_binary": {}}
+    for key, (_, mangled) in KEYS.items():
+        n, cyc = mix(txt, mangled)
+        out["mean_price_cycles"][key] = round(cyc / sum(n.values()), 3)
+        out["vector_instructions_in_binary"][key] = sum(n.values())
+    with open(os.path.join(ROOT, "profiles", "valu_mix.json"), "w") as f:
+        json.dump(out, f, indent=1); f.write("\n")
+    print(json.dumps(out["mean_price_cycles"]))
+
+
 if __name__ == "__main__":
-    print("\n".join(table(sys.argv[1] if len(sys.argv) > 1 else "r05")))
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    if "--write" in sys.argv:
+        write()
+    else:
+        print("\n".join(table(args[0] if args else "r05")))
