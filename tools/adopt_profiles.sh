@@ -20,4 +20,5 @@ stale = [p for p in sorted(glob.glob("profiles/pmc_*.json")) if json.load(open(p
 stale = [p for p in stale if "traffic" not in p]
 print("device-code hash", h[:12], "- stale profiles:", stale or "none")
 PY
+make -C game_engine_amd/csrc asm -s > /dev/null 2>&1; python tools/valu_mix.py --write      # the mean instruction price per fused kernel, tied to the device-code hash
 python tools/design_tables.py $ROUND --write      # the marked tables / values of DESIGN.md, BASELINE.md, profiles/README.md
