@@ -36,6 +36,18 @@ constexpr uint32_t GOLDEN = 0x9E3779B9u;
 //   and carried the prepared deal's words through two register sets, copied over on every turn.  Werewolf x 8 large-batch build 803 ->
 //   676 vector instructions, 1 M rooms -0.8 %, Werewolf x 12 -0.5 % (profiles/r05_ab_valu_price.txt; the lone-wavefront build keeps the
 //   shadow: a lone wavefront has nothing else to run during an LDS round trip)
+// GE_SINGLE_GLOBAL: which single-turn builds read the table image where it lies in global memory (through the vector cache) instead of
+//   filling the block's LDS with it behind a barrier first - bit 0 Werewolf lone-wavefront, 1 Werewolf large-batch, 2 Two-Truths
+//   lone-wavefront, 3 Two-Truths large-batch.  A lone wavefront's single turn is a chain of latencies, and fill -> barrier -> LDS read is a
+//   longer one than a cached load: sustained us per single-turn launch at 65 536 rooms (profiles/r05_ab_single_global.txt) Werewolf x 8
+//   3.73 -> 3.38 (-9.5 %), x 12 4.46 -> 4.29, Two-Truths x 4 3.12 -> 2.85, x 12 4.22 -> 3.97, a mixed 16 384 + 16 384 batch 3.59 -> 3.35.
+//   The large-batch builds keep the LDS tables: a Werewolf turn looks up a table per queue slot and 64 scattered addresses cost the
+//   vector cache far more than LDS (1 M x 8 13.5 -> 15.7 us, 2 M x 12 31.9 -> 41, 1 GiB of records 376 -> 486); Two-Truths x 4 gains 2 % at
+//   1 M rooms but loses 13 % once the records stream from HBM (33 M rooms 273 -> 309 us), x 8 loses 5 %.
+#ifndef GE_SINGLE_GLOBAL
+#define GE_SINGLE_GLOBAL 5
+#endif
+template <bool LOWOCC, bool SINGLE> constexpr bool single_global(int game_bit) { return SINGLE && ((GE_SINGLE_GLOBAL >> (game_bit + (LOWOCC ? 0 : 1))) & 1) != 0; }
 #ifndef GE_DEAL_EARLY
 #define GE_DEAL_EARLY 1
 #endif

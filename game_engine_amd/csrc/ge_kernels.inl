@@ -181,8 +181,21 @@ __device__ __forceinline__ void run_ww(const SegDev *__restrict__ sgp, const Ste
     uint32_t w[L::WORDS];
     load_words<L::WORDS, (NB > 8)>(sg.base, sg.rooms_padded, room, w);   // in flight while the block fills its LDS tables; streaming: see load_words
     // the slot -> player table of the action queue sits right behind the phase rows (step_lds_bytes)
-    uint32_t *ord8 = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(rows) + LDS_ROWS);
-    load_rows<B::TABLE ? IMG_END / 16u : B::ORD ? 128u : 64u, !LOWOCC && !SINGLE, GENERIC, !LOWOCC && !SINGLE>(rows, tables, sg.table_idx, sgp, a.cond_off);
+    const uint32_t *ord8 = reinterpret_cast<const uint32_t *>(reinterpret_cast<unsigned char *>(rows) + LDS_ROWS);
+    const DevRow *rows_t = rows;
+    const uint8_t *nth8_t = nth8;
+    const unsigned char *cond_t = reinterpret_cast<const unsigned char *>(rows) + a.cond_off;
+    if (single_global<LOWOCC, SINGLE>(0)) {
+        // GE_SINGLE_GLOBAL: a single-turn launch reads the tables where they lie in global memory (DevTable leads with the LDS image)
+        // instead of every block copying them into LDS behind a barrier first (ge_device.h: which builds do)
+        const unsigned char *img = reinterpret_cast<const unsigned char *>(tables + sg.table_idx);
+        rows_t = reinterpret_cast<const DevRow *>(img);
+        ord8 = reinterpret_cast<const uint32_t *>(img + IMG_ORD8);
+        nth8_t = img + IMG_NTH8;
+        cond_t = reinterpret_cast<const unsigned char *>(tables[sg.table_idx].cond_img);
+    } else {
+        load_rows<B::TABLE ? IMG_END / 16u : B::ORD ? 128u : 64u, !LOWOCC && !SINGLE, GENERIC, !LOWOCC && !SINGLE>(rows, tables, sg.table_idx, sgp, a.cond_off);
+    }
     WWR<NB> s;
     uint32_t cache;
     if (NB <= 8 && !SINGLE) {
@@ -232,7 +245,7 @@ __device__ __forceinline__ void run_ww(const SegDev *__restrict__ sgp, const Ste
     uint32_t tk = turn_key(rk, turn0);                        // this turn's key; ww_turn leaves the next turn's (computed in an LDS wait shadow)
     Stamps stamps;
     if (GE_STAMPS) { stamps.start(); stamps.clocks_start(); }
-    const WwCtx ctx = {rows, CondCtx{reinterpret_cast<const unsigned char *>(rows) + a.cond_off, cs}, lw, nth8, ord8, valid, sg.n_players, sg.nw, sg.phase0_idx, rk, sg.human_mask, term_mask};
+    const WwCtx ctx = {rows_t, CondCtx{cond_t, cs}, lw, nth8_t, ord8, valid, sg.n_players, sg.nw, sg.phase0_idx, rk, sg.human_mask, term_mask};
     if constexpr (SINGLE) {
         // one turn, no loop: the row is fetched after the restart decision (terminal rows are a bit mask), nothing is
         // prepared for a next turn
@@ -243,7 +256,7 @@ __device__ __forceinline__ void run_ww(const SegDev *__restrict__ sgp, const Ste
             s.games = g < 0xFFFFu ? g + 1u : g;
             restarted = 1;
         }
-        DevRow row = lds_row<!LOWOCC && !SINGLE>(rows, s.phase);
+        DevRow row = lds_row<!LOWOCC && !SINGLE>(rows_t, s.phase);
         const uint32_t p = s.phase;
         uint32_t ev_newly = 0;
         uint64_t ev_choice = 0;
@@ -278,7 +291,7 @@ __device__ __forceinline__ void run_ww(const SegDev *__restrict__ sgp, const Ste
         }
         if (trace && valid) store_event(sg.trace, sg.rooms_padded, 0u, room, turn0, p, s.phase, restarted, ev_newly, ev_choice);
     } else {
-        DevRow row = lds_row<!LOWOCC && !SINGLE>(rows, s.phase);
+        DevRow row = lds_row<!LOWOCC && !SINGLE>(rows_t, s.phase);
         WWR<NB> s0;
         DevRow row0 = row;
         if (LOWOCC) { s0 = fresh_room(); row0 = lds_row<!LOWOCC && !SINGLE>(rows, sg.phase0_idx); }
@@ -351,7 +364,17 @@ __device__ __forceinline__ void run_tt(const SegDev *__restrict__ sgp, const Ste
     const uint64_t room = valid ? room_in : 0;
     uint32_t w[L::WORDS];
     load_words<L::WORDS, true>(sg.base, sg.rooms_padded, room, w);
-    load_rows<(QUEUE && !LOWOCC) ? 256u : 64u, QUEUE && !LOWOCC && !SINGLE, GENERIC, !LOWOCC && !SINGLE>(rows, tables, sg.table_idx, sgp, a.cond_off);
+    const DevRow *rows_t = rows;
+    const uint8_t *nth8_t = nth8;
+    const unsigned char *cond_t = reinterpret_cast<const unsigned char *>(rows) + a.cond_off;
+    if (single_global<LOWOCC, SINGLE>(2)) {                    // see run_ww
+        const unsigned char *img = reinterpret_cast<const unsigned char *>(tables + sg.table_idx);
+        rows_t = reinterpret_cast<const DevRow *>(img);
+        nth8_t = img + IMG_NTH8;
+        cond_t = reinterpret_cast<const unsigned char *>(tables[sg.table_idx].cond_img);
+    } else {
+        load_rows<(QUEUE && !LOWOCC) ? 256u : 64u, QUEUE && !LOWOCC && !SINGLE, GENERIC, !LOWOCC && !SINGLE>(rows, tables, sg.table_idx, sgp, a.cond_off);
+    }
     TT<NB> s;
     L::unpack(w, s);
     const uint32_t rk = room_key_from(a.seed_key, sg.first_global + room);
@@ -378,7 +401,7 @@ __device__ __forceinline__ void run_tt(const SegDev *__restrict__ sgp, const Ste
         cs = CondShape{(uint32_t)__builtin_amdgcn_readfirstlane(tb.cond_shape), (uint32_t)__builtin_amdgcn_readfirstlane(tb.cond_g[0]), (uint32_t)__builtin_amdgcn_readfirstlane(tb.cond_g[1]),
                        (uint32_t)__builtin_amdgcn_readfirstlane(tb.cond_fields[0]), (uint32_t)__builtin_amdgcn_readfirstlane(tb.cond_fields[1])};
     }
-    const CondCtx cc = {reinterpret_cast<const unsigned char *>(rows) + a.cond_off, cs};
+    const CondCtx cc = {cond_t, cs};
     uint32_t done = tt_done_mask<NB>(s.rounds, sg.rounds);   // who has spoken all agreed rounds (ge_device.h)
     if constexpr (SINGLE) {
         uint32_t restarted = 0;
@@ -389,14 +412,14 @@ __device__ __forceinline__ void run_tt(const SegDev *__restrict__ sgp, const Ste
             done = done0;
             restarted = 1;
         }
-        DevRow row = lds_row<!LOWOCC && !SINGLE>(rows, s.phase);
+        DevRow row = lds_row<!LOWOCC && !SINGLE>(rows_t, s.phase);
         const uint32_t p = s.phase;
         uint32_t ev_newly = 0;
         uint64_t ev_choice = 0;
-        tt_turn<NB, QUEUE, !LOWOCC, GENERIC, true>(s, done, row, rows, cc, lw, nth8, valid, sg.n_players, sg.rounds, sg.phase0_idx, rk, turn0, a.trace != 0u, sg.human_mask, term_mask, ev_newly, ev_choice);
+        tt_turn<NB, QUEUE, !LOWOCC, GENERIC, true>(s, done, row, rows_t, cc, lw, nth8_t, valid, sg.n_players, sg.rounds, sg.phase0_idx, rk, turn0, a.trace != 0u, sg.human_mask, term_mask, ev_newly, ev_choice);
         if (a.trace && valid) store_event(sg.trace, sg.rooms_padded, 0u, room, turn0, p, s.phase, restarted, ev_newly, ev_choice);
     } else {
-        DevRow row = lds_row<!LOWOCC && !SINGLE>(rows, s.phase);
+        DevRow row = lds_row<!LOWOCC && !SINGLE>(rows_t, s.phase);
         TT<NB> s0;
         DevRow row0 = row;
         if (LOWOCC) { s0 = fresh_room(); row0 = lds_row<!LOWOCC && !SINGLE>(rows, sg.phase0_idx); }
