@@ -27,7 +27,7 @@ for spec in sys.argv[1:] or ["ww:8:1048576", "ww:12:2097152", "tt:4:1048576"]:
     launches = max(16, min(256, int(2e10 // (rooms * 64))))        # ~a few hundred ms of replays at most
     b = RoomBatch(segs, seed=0xC0FFEE, max_fuse=1, restart=True)
     state = sum(b.bytes_per_room(k) * x[2] for k, x in enumerate(segs))
-    b.step(256, stream); b.step(launches, stream); b.sync()
+    b.step(int(os.environ.get('K1_PREROLL', '256')), stream); b.step(launches, stream); b.sync()
     best = None
     for _ in range(5):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
