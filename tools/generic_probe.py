@@ -37,6 +37,15 @@ for d, extra in ((same, " and player.selected_target_id >= 0"), (tt_same, " and 
         cc = ph.get("completion_criteria") or {}
         if cc.get("type") == "player_action":
             cc["target_players"]["condition"] += extra
+# the same games again with FOUR literal slots (2 clauses x 2 literals, three numeric fields across the rows): each action phase's own condition twice,
+# OR-ed, each copy with a numeric literal that always holds - what the widest table shape costs without a change of dynamics
+tt_same4 = copy.deepcopy(tt_base)
+extras = {2: ("player.total_score >= 0", "player.rounds_as_speaker >= 0"), 3: ("player.lie_index >= 0", "player.total_score <= 255"),
+          5: ("player.vote_choice >= 0", "player.rounds_as_speaker <= 15")}
+for pid, (e1, e2) in extras.items():
+    cc = tt_same4["phases"][str(pid)]["completion_criteria"]
+    c0 = cc["target_players"]["condition"]
+    cc["target_players"]["condition"] = f"{c0} and {e1} or {c0} and {e2}"
 for game, n, rooms, b0, g0, s0, rounds in (("werewolf", 8, 65536, base, gen, same, 1), ("werewolf", 8, 1048576, base, gen, same, 1), ("werewolf", 12, 1048576, base, gen, same, 1),
                                            ("two-truths", 4, 1048576, tt_base, tt_gen, tt_same, 2)):
     res = {}
@@ -48,6 +57,13 @@ for game, n, rooms, b0, g0, s0, rounds in (("werewolf", 8, 65536, base, gen, sam
             b.step(512); b.sync()
             ms, _ = b.kernel_time(reset=True)
             res[name] = ms * 1e3 / 512
+    if b0 is tt_base:
+        with RoomBatch([(GameTable(tt_same4, rounds), n, rooms)], seed=0xC0FFEE, max_fuse=64, restart=True) as b:
+            b.step(256); b.sync()
+            b.set_timing(True); b.kernel_time(reset=True)
+            b.step(512); b.sync()
+            ms, _ = b.kernel_time(reset=True)
+        print(f"{game} x{n}, {rooms:>8} rooms: shipped rules in a 2 x 2 generic form (four literal slots, three numeric fields) {ms * 1e3 / 512:7.3f} us/turn (x{ms * 1e3 / 512 / res['shipped']:.2f})", flush=True)
     print(f"{game} x{n}, {rooms:>8} rooms: shipped conditions {res['shipped']:7.3f} us/turn ({rooms / res['shipped'] * 1e6:.3e} steps/s)   "
           f"generic conditions {res['generic']:7.3f} us/turn ({rooms / res['generic'] * 1e6:.3e} steps/s, x{res['generic'] / res['shipped']:.2f})   "
           f"shipped rules in generic form {res['same']:7.3f} us/turn (x{res['same'] / res['shipped']:.2f})", flush=True)

@@ -2,7 +2,8 @@
 """Single-turn launches (max_fuse = 1) in their sustained regime: device time of a replayed hipGraph of back-to-back launches
 (HIP events around the replay on the launch stream), per launch - the figure bench.py's hbm_streaming block reports.
     python tools/k1_probe.py [game:n:rooms[+game:n:rooms] ...]     (launch knobs such as GE_SINGLE_BLOCK / GE_CHAINS are read once per
-    process; `+` joins the segments of a mixed batch)"""
+    process; `+` joins the segments of a mixed batch).  K1_PREROLL = untimed turns before the window (default 1 024, as in bench.py: Two-Truths rooms
+    start in step and are still loosely in phase after 256 turns, where a mixed Werewolf + Two-Truths launch times 5 % faster than in steady state)"""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -27,7 +28,7 @@ for spec in sys.argv[1:] or ["ww:8:1048576", "ww:12:2097152", "tt:4:1048576"]:
     launches = max(16, min(256, int(2e10 // (rooms * 64))))        # ~a few hundred ms of replays at most
     b = RoomBatch(segs, seed=0xC0FFEE, max_fuse=1, restart=True)
     state = sum(b.bytes_per_room(k) * x[2] for k, x in enumerate(segs))
-    b.step(int(os.environ.get('K1_PREROLL', '256')), stream); b.step(launches, stream); b.sync()
+    b.step(int(os.environ.get('K1_PREROLL', '1024')), stream); b.step(launches, stream); b.sync()
     best = None
     for _ in range(5):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
