@@ -57,6 +57,7 @@ struct ge_batch {
     bool deal_side_failed = false;    // ... or never (no Werewolf x 12 segment / no memory for a cache)
     uint32_t last_step_turns = 0;     // turns of the most recent ge_batch_step (what the trace holds)
     size_t state_bytes = 0;
+    bool stream_loads = false;  // single-turn launches of a large Werewolf x 8 batch load the record with streaming loads (create_impl)
     DevTable *tables = nullptr;
     SegDev *segs_dev = nullptr;
     unsigned long long *sum_dev = nullptr;
@@ -226,6 +227,13 @@ static int create_impl(const ge_batch_desc *desc, ge_batch **out, const uint64_t
         b->segs.push_back(s);
     }
     b->n_rooms = local; b->n_blocks = blocks; b->state_bytes = bytes;
+    // The 8-word Werewolf record of a single-turn launch: streaming loads once the state no longer fits the Infinity Cache (256 MiB on
+    // MI355X; measured at 256 MiB: plain loads 10 % better, at 320 MiB: streaming loads 4 % better; ge_kernels.inl load_words).
+    // GE_NT_LOADS=0 / 1 forces it (A/B, knob runs)
+    {
+        static const int nt_env = [] { const char *e = getenv("GE_NT_LOADS"); return e ? atoi(e) : -1; }();
+        b->stream_loads = nt_env >= 0 ? nt_env != 0 : bytes > ((size_t)288 << 20);
+    }
     int st = GE_OK;
     {
         DeviceGuard dg(b->device);
@@ -341,7 +349,10 @@ template <class K> inline void launch_one(K kernel, const LaunchShape &L, bool q
 
 template <bool LOW, int GEN, bool SINGLE> inline void launch_kind(uint32_t kind, const LaunchShape &L) {
     switch (kind) {
-    case K_WW8: launch_one(ge_step_kernel<K_WW8, LOW, GEN, SINGLE>, L, true, LOW); break;
+    case K_WW8:
+        if (SINGLE && !LOW && GEN == 0 && L.b->stream_loads) launch_one(ge_step_kernel<K_WW8, LOW, GEN, SINGLE, SINGLE && !LOW && GEN == 0>, L, true, LOW);
+        else launch_one(ge_step_kernel<K_WW8, LOW, GEN, SINGLE>, L, true, LOW);
+        break;
     case K_WW12: launch_one(ge_step_kernel<K_WW12, LOW, GEN, SINGLE>, L, true, LOW); break;
     case K_TT4: launch_one(ge_step_kernel<K_TT4, LOW, GEN, SINGLE>, L, tt_uses_queue(4, LOW), LOW); break;
     case K_TT8: launch_one(ge_step_kernel<K_TT8, LOW, GEN, SINGLE>, L, tt_uses_queue(8, LOW), LOW); break;

@@ -1,6 +1,6 @@
 """Every kernel build over every batch size (-m gpu).  Which build a launch gets - the lone-wavefront one or the
 large-batch one, 64- or 256-room blocks - is normally chosen from the batch size (ge_step.hip fill_args / create_impl); the
-knobs GE_LOWOCC_ROOMS / GE_BLOCK_THREADS force the choice.  They are read once per process, so every case runs its scenario
+knobs GE_LOWOCC_ROOMS / GE_BLOCK_THREADS / GE_NT_LOADS force the choice.  They are read once per process, so every case runs its scenario
 (tests/knob_worker.py: event trace, host-driven seats + batched injection, mixed batch in steady state - each against the
 oracle, with single-turn and fused launches) in a fresh child process.  Without these the large-batch build's trace path
 and the lone-wavefront mixed kernel with restart would only be covered at the sizes that pick them by default."""
@@ -21,6 +21,8 @@ NEVER_LOW, ALWAYS_LOW = {"GE_LOWOCC_ROOMS": "0"}, {"GE_LOWOCC_ROOMS": "99999999"
     (NEVER_LOW, "mixed", 2500), (ALWAYS_LOW, "mixed", 2500), (ALWAYS_LOW, "mixed", 70001),
     ({"GE_LOWOCC_ROOMS": "0", "GE_BLOCK_THREADS": "256"}, "mixed", 2500),
     ({"GE_LOWOCC_ROOMS": "99999999", "GE_BLOCK_THREADS": "128"}, "trace", 3000),
+    # the streaming-load form of the large-batch single-turn Werewolf x 8 kernel (normally only for a state beyond the Infinity Cache)
+    ({"GE_NT_LOADS": "1", "GE_LOWOCC_ROOMS": "0"}, "trace", 3000), ({"GE_NT_LOADS": "1"}, "humans", 140001),
 ], ids=lambda v: "-".join(f"{k[3:].lower()}={x}" for k, x in v.items()) if isinstance(v, dict) else str(v))
 def test_scenario_under_forced_launch_knobs(knobs, scenario, rooms):
     env = dict(os.environ, **knobs)

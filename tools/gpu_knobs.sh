@@ -13,3 +13,5 @@ run single_block1024 GE_SINGLE_BLOCK=1024 GE_BLOCK_THREADS=256 GE_LOWOCC_ROOMS=0
 run no_generic_shapes GE_NO_GENERIC_SHAPES=1
 run half_waves_on GE_HALF_WAVES=1
 run half_waves_off GE_HALF_WAVES=0
+run nt_loads_on GE_NT_LOADS=1
+run nt_loads_off GE_NT_LOADS=0
