@@ -51,10 +51,14 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 // Round 5 (profiles/r05_ab_ww8_nt_loads.txt): for that record it depends on where the state lives.  While it fits the 256 MiB
 // Infinity Cache a plain load is better (1 M rooms 62.0 against 59.8 %, 8 M rooms = 256 MiB 82.5 against 74.9 %); once it streams from
 // HBM the streaming load is (16 M rooms 74.2 -> 77.9 %, 33 M 70.9 -> 73.2 %), and in a mixed batch too (C5 share 55.4 -> 57.5 %).
-// So the large-batch single-turn Werewolf x 8 kernel exists in both forms (the NTL template argument; ge_step.hip picks by the size of
-// the state), and a mixed batch's single-turn launches stream.  (A wave-uniform branch between two load sequences inside one kernel was
-// tried first: the optimiser merges the arms' loads and drops the hint unless inline-asm statements keep them apart, and behind any
-// such statement it fetches the launch's turn word with a vector load instead of a scalar one - 4 % of the launch.)
+// The other layouts turn over too (profiles/r05_ab_nt_others.txt): Two-Truths x 4 streaming at 24 MiB (61.2 against 59.9 %), plain from 96 MiB
+// (75.7 against 69.7 %) to 252 MiB (85.8 against 72.8 %), streaming again beyond the cache; Werewolf x 12 level at 80 MiB, plain at 160 MiB
+// (74.1 against 70.2 %), streaming beyond (400 MiB: 72.5 against 66.6 %).  So the large-batch single-turn kernels of the shipped games exist
+// in both forms (the LD template argument; ge_step.hip record_loads picks by layout and size of the state), and a mixed batch's single-turn
+// launches stream.  (A wave-uniform branch between two load sequences inside one kernel was tried first: the optimiser merges the arms'
+// loads and drops the hint unless inline-asm statements keep them apart, and behind any such statement it fetches the launch's turn word
+// with a vector load instead of a scalar one - 4 % of the launch.)
+constexpr bool stream_loads(int ld, bool layout_default) { return ld == 0 ? layout_default : ld == 2; }
 template <int WORDS, bool NT = false>
 __device__ __forceinline__ void load_words(const uint32_t *base, uint64_t rooms_padded, uint64_t room, uint32_t *w) {
     constexpr int NP = (WORDS + 3) / 4;
@@ -175,7 +179,7 @@ __device__ __forceinline__ void load_init_regs(const SegDev &sg, uint32_t *ir) {
 // (profiles/r03_ab_deal_period_12.txt: every 16th / 32nd / 64th turn = 18.37 / 18.21 / 19.53 us per turn at 2 M x 12)
 template <int NB> constexpr uint32_t deal_period() { return NB <= 8 ? GE_DEAL_PERIOD : 2u * GE_DEAL_PERIOD; }
 
-template <int NB, bool LOWOCC, int GENERIC, bool SINGLE, bool NTL = false>
+template <int NB, bool LOWOCC, int GENERIC, bool SINGLE, int LD = 0>
 __device__ __forceinline__ void run_ww(const SegDev *__restrict__ sgp, const StepArgs &a, DevRow *rows, void *lw,
                                        uint8_t *nth8, const DevTable *__restrict__ tables, uint64_t room_in) {
     const SegDev &sg = *sgp;
@@ -186,7 +190,7 @@ __device__ __forceinline__ void run_ww(const SegDev *__restrict__ sgp, const Ste
     const bool valid = room_in < sg.rooms;
     const uint64_t room = valid ? room_in : 0;
     uint32_t w[L::WORDS];
-    load_words<L::WORDS, (NB > 8) || NTL>(sg.base, sg.rooms_padded, room, w);   // in flight while the block fills its LDS tables; streaming: see load_words
+    load_words<L::WORDS, stream_loads(LD, NB > 8)>(sg.base, sg.rooms_padded, room, w);   // in flight while the block fills its LDS tables; streaming: see load_words
     // the slot -> player table of the action queue sits right behind the phase rows (step_lds_bytes)
     const uint32_t *ord8 = reinterpret_cast<const uint32_t *>(reinterpret_cast<unsigned char *>(rows) + LDS_ROWS);
     const DevRow *rows_t = rows;
@@ -361,7 +365,7 @@ __device__ __forceinline__ void run_ww(const SegDev *__restrict__ sgp, const Ste
 #endif
 constexpr bool tt_uses_queue(int nb, bool lowocc) { return !lowocc || nb >= GE_TT_LOW_QUEUE_MIN; }
 
-template <int NB, bool LOWOCC, int GENERIC, bool SINGLE>
+template <int NB, bool LOWOCC, int GENERIC, bool SINGLE, int LD = 0>
 __device__ __forceinline__ void run_tt(const SegDev *__restrict__ sgp, const StepArgs &a, DevRow *rows, void *lw, uint8_t *nth8,
                                        const DevTable *__restrict__ tables, uint64_t room_in) {
     constexpr bool QUEUE = tt_uses_queue(NB, LOWOCC);
@@ -370,7 +374,7 @@ __device__ __forceinline__ void run_tt(const SegDev *__restrict__ sgp, const Ste
     const bool valid = room_in < sg.rooms;
     const uint64_t room = valid ? room_in : 0;
     uint32_t w[L::WORDS];
-    load_words<L::WORDS, true>(sg.base, sg.rooms_padded, room, w);
+    load_words<L::WORDS, stream_loads(LD, true)>(sg.base, sg.rooms_padded, room, w);
     const DevRow *rows_t = rows;
     const uint8_t *nth8_t = nth8;
     const unsigned char *cond_t = reinterpret_cast<const unsigned char *>(rows) + a.cond_off;
@@ -460,14 +464,14 @@ __device__ __forceinline__ void run_tt(const SegDev *__restrict__ sgp, const Ste
 // Two-Truths batch diverges per block, never inside a wavefront.  Segment descriptors live in
 // device memory and are read with a block-uniform index (scalar loads): indexing the kernel
 // arguments dynamically would push them through scratch.
-template <int KIND, bool LOWOCC, int GENERIC, bool SINGLE = false, bool NTL = false>
+template <int KIND, bool LOWOCC, int GENERIC, bool SINGLE = false, int LD = 0>
 __device__ __forceinline__ void run_kind(const SegDev *__restrict__ sg, const StepArgs &a, DevRow *rows, void *lw,
                                          uint8_t *nth8, const DevTable *__restrict__ tables, uint64_t room) {
-    if (KIND == K_WW8) run_ww<8, LOWOCC, GENERIC, SINGLE, NTL>(sg, a, rows, lw, nth8, tables, room);
-    else if (KIND == K_WW12) run_ww<12, LOWOCC, GENERIC, SINGLE>(sg, a, rows, lw, nth8, tables, room);
-    else if (KIND == K_TT4) run_tt<4, LOWOCC, GENERIC, SINGLE>(sg, a, rows, lw, nth8, tables, room);
-    else if (KIND == K_TT8) run_tt<8, LOWOCC, GENERIC, SINGLE>(sg, a, rows, lw, nth8, tables, room);
-    else run_tt<12, LOWOCC, GENERIC, SINGLE>(sg, a, rows, lw, nth8, tables, room);
+    if (KIND == K_WW8) run_ww<8, LOWOCC, GENERIC, SINGLE, LD>(sg, a, rows, lw, nth8, tables, room);
+    else if (KIND == K_WW12) run_ww<12, LOWOCC, GENERIC, SINGLE, LD>(sg, a, rows, lw, nth8, tables, room);
+    else if (KIND == K_TT4) run_tt<4, LOWOCC, GENERIC, SINGLE, LD>(sg, a, rows, lw, nth8, tables, room);
+    else if (KIND == K_TT8) run_tt<8, LOWOCC, GENERIC, SINGLE, LD>(sg, a, rows, lw, nth8, tables, room);
+    else run_tt<12, LOWOCC, GENERIC, SINGLE, LD>(sg, a, rows, lw, nth8, tables, room);
 }
 
 // LDS of a step block is sized at launch (a 64-room block must not pay for four wavefronts' queues, or
@@ -503,7 +507,7 @@ extern __shared__ __align__(16) unsigned char ge_lds[];
 #define GE_GENERIC_WAVES 1
 #endif
 // SINGLE: the launch is one turn (a.n_turns == 1) (run_ww / run_tt)
-template <int KIND, bool LOWOCC, int GENERIC, bool SINGLE, bool NTL = false>
+template <int KIND, bool LOWOCC, int GENERIC, bool SINGLE, int LD = 0>
 __device__ __forceinline__ void step_body(const SegDev *__restrict__ segs, const DevTable *__restrict__ tables, const StepArgs &a) {
     constexpr bool WWK = KIND == K_WW8 || KIND == K_WW12 || tt_uses_queue(KIND == K_TT4 ? 4 : KIND == K_TT8 ? 8 : 12, LOWOCC);   // uses the action queue
     DevRow *rows = reinterpret_cast<DevRow *>(ge_lds);
@@ -511,12 +515,13 @@ __device__ __forceinline__ void step_body(const SegDev *__restrict__ segs, const
     auto *wl = reinterpret_cast<typename WaveLdsOf<LOWOCC>::type *>(ge_lds + LDS_ROWS + LDS_ORD8 + (LOWOCC ? 0u : LDS_NTH8 + LDS_S0));
     // (a lane past rooms_per_block holds no room: it shadows room 0 like a lane past the end of the segment)
     const uint64_t room = (!LOWOCC || threadIdx.x < a.rooms_per_block) ? (uint64_t)blockIdx.x * (LOWOCC ? a.rooms_per_block : blockDim.x) + threadIdx.x : ~0ull;
-    run_kind<KIND, LOWOCC, GENERIC, SINGLE, NTL>(segs, a, rows, WWK ? &wl[threadIdx.x >> 6] : nullptr, nth8, tables, room);
+    run_kind<KIND, LOWOCC, GENERIC, SINGLE, LD>(segs, a, rows, WWK ? &wl[threadIdx.x >> 6] : nullptr, nth8, tables, room);
 }
-// NTL (the large-batch single-turn Werewolf x 8 kernel only): the record with streaming loads - for a state beyond the Infinity Cache (load_words)
-template <int KIND, bool LOWOCC, int GENERIC = false, bool SINGLE = false, bool NTL = false>
+// LD (the large-batch single-turn kernels of the shipped games only): 1 / 2 = the record with plain / streaming loads instead of the layout's
+// default - chosen at launch by the size of the state (load_words, ge_step.hip record_loads)
+template <int KIND, bool LOWOCC, int GENERIC = false, bool SINGLE = false, int LD = 0>
 __global__ void __launch_bounds__(SINGLE ? 1024 : 256, SINGLE ? 8 : (!LOWOCC && GENERIC) ? GE_GENERIC_WAVES : (KIND == K_WW12 && !LOWOCC) ? GE_WW12_WAVES : (KIND == K_WW8 && !LOWOCC) ? GE_WW8_WAVES : 1) ge_step_kernel(const SegDev *__restrict__ segs, const DevTable *__restrict__ tables, const StepArgs a) {
-    step_body<KIND, LOWOCC, GENERIC, SINGLE, NTL>(segs, tables, a);
+    step_body<KIND, LOWOCC, GENERIC, SINGLE, LD>(segs, tables, a);
 }
 
 // mixed batch: several segments (games / player counts) in one launch.  SINGLE: the launch is one turn - each kind's single-turn
@@ -535,7 +540,7 @@ __global__ void __launch_bounds__(256, SINGLE ? 8 : !LOWOCC ? (GENERIC ? GE_GENE
     const uint64_t room = (uint64_t)(bid - a.block_begin[si]) * blockDim.x + threadIdx.x;
     void *lw = &wl[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)];    // wave-uniform: kept in a scalar register across the kind switch
     switch (sg->kind) {
-    case K_WW8: run_kind<K_WW8, LOWOCC, GENERIC, SINGLE, SINGLE && !LOWOCC>(sg, a, rows, lw, nth8, tables, room); break;   // streaming record loads (load_words)
+    case K_WW8: run_kind<K_WW8, LOWOCC, GENERIC, SINGLE, (SINGLE && !LOWOCC) ? 2 : 0>(sg, a, rows, lw, nth8, tables, room); break;   // streaming record loads (load_words)
     case K_WW12: run_kind<K_WW12, LOWOCC, GENERIC, SINGLE>(sg, a, rows, lw, nth8, tables, room); break;
     case K_TT4: run_kind<K_TT4, LOWOCC, GENERIC, SINGLE>(sg, a, rows, lw, nth8, tables, room); break;
     case K_TT8: run_kind<K_TT8, LOWOCC, GENERIC, SINGLE>(sg, a, rows, lw, nth8, tables, room); break;

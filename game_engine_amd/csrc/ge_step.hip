@@ -57,7 +57,7 @@ struct ge_batch {
     bool deal_side_failed = false;    // ... or never (no Werewolf x 12 segment / no memory for a cache)
     uint32_t last_step_turns = 0;     // turns of the most recent ge_batch_step (what the trace holds)
     size_t state_bytes = 0;
-    bool stream_loads = false;  // single-turn launches of a large Werewolf x 8 batch load the record with streaming loads (create_impl)
+    bool stream_loads = false;  // a single-game batch's large single-turn launches load the record with streaming loads (create_impl)
     DevTable *tables = nullptr;
     SegDev *segs_dev = nullptr;
     unsigned long long *sum_dev = nullptr;
@@ -227,12 +227,18 @@ static int create_impl(const ge_batch_desc *desc, ge_batch **out, const uint64_t
         b->segs.push_back(s);
     }
     b->n_rooms = local; b->n_blocks = blocks; b->state_bytes = bytes;
-    // The 8-word Werewolf record of a single-turn launch: streaming loads once the state no longer fits the Infinity Cache (256 MiB on
-    // MI355X; measured at 256 MiB: plain loads 10 % better, at 320 MiB: streaming loads 4 % better; ge_kernels.inl load_words).
-    // GE_NT_LOADS=0 / 1 forces it (A/B, knob runs)
+    // The record loads of a single-game batch's large single-turn launches, plain or streaming (non-temporal), by layout and by where the state
+    // lives (ge_kernels.inl load_words; profiles/r05_ab_ww8_nt_loads.txt, r05_ab_nt_others.txt): beyond the 256 MiB Infinity Cache of MI355X
+    // every layout streams; while the cache holds the state plain loads are served from it (+4 ... +18 % at 100 - 250 MiB), except that the
+    // smallest states measured - Two-Truths at 24 MiB, Werewolf x 12 at 80 MiB - are level or 2 % better streaming.  GE_NT_LOADS=0 / 1 forces
+    // plain / streaming (A/B, knob runs)
     {
         static const int nt_env = [] { const char *e = getenv("GE_NT_LOADS"); return e ? atoi(e) : -1; }();
-        b->stream_loads = nt_env >= 0 ? nt_env != 0 : bytes > ((size_t)288 << 20);
+        const uint32_t kind0 = b->segs[0].dev.kind;
+        const size_t mib = (size_t)1 << 20, small = kind0 == K_WW8 ? 0 : kind0 == K_WW12 ? 96 * mib : 48 * mib;
+        size_t touched = 0;                                     // what a launch reads: the records' own words (a layout's last plane is allocated 16 bytes wide)
+        for (const Segment &sg : b->segs) touched += (size_t)sg.dev.words * 4u * sg.dev.rooms_padded;
+        b->stream_loads = nt_env >= 0 ? nt_env != 0 : (touched > 288 * mib || touched <= small);
     }
     int st = GE_OK;
     {
@@ -348,15 +354,31 @@ template <class K> inline void launch_one(K kernel, const LaunchShape &L, bool q
 }
 
 template <bool LOW, int GEN, bool SINGLE> inline void launch_kind(uint32_t kind, const LaunchShape &L) {
+    constexpr bool HAS_ALT = SINGLE && !LOW && GEN == 0;
+    const bool alt = HAS_ALT && L.b->stream_loads != (kind != K_WW8);      // the layouts' default: Werewolf x 8 plain, the others streaming
     switch (kind) {
+    // (the large-batch single-turn kernels of the shipped games exist with plain and with streaming record loads: ALT = the form that is not the
+    // layout's default, launched when record_loads() asks for it)
     case K_WW8:
-        if (SINGLE && !LOW && GEN == 0 && L.b->stream_loads) launch_one(ge_step_kernel<K_WW8, LOW, GEN, SINGLE, SINGLE && !LOW && GEN == 0>, L, true, LOW);
+        if (alt) launch_one(ge_step_kernel<K_WW8, LOW, GEN, SINGLE, HAS_ALT ? 2 : 0>, L, true, LOW);
         else launch_one(ge_step_kernel<K_WW8, LOW, GEN, SINGLE>, L, true, LOW);
         break;
-    case K_WW12: launch_one(ge_step_kernel<K_WW12, LOW, GEN, SINGLE>, L, true, LOW); break;
-    case K_TT4: launch_one(ge_step_kernel<K_TT4, LOW, GEN, SINGLE>, L, tt_uses_queue(4, LOW), LOW); break;
-    case K_TT8: launch_one(ge_step_kernel<K_TT8, LOW, GEN, SINGLE>, L, tt_uses_queue(8, LOW), LOW); break;
-    default: launch_one(ge_step_kernel<K_TT12, LOW, GEN, SINGLE>, L, tt_uses_queue(12, LOW), LOW); break;
+    case K_WW12:
+        if (alt) launch_one(ge_step_kernel<K_WW12, LOW, GEN, SINGLE, HAS_ALT ? 1 : 0>, L, true, LOW);
+        else launch_one(ge_step_kernel<K_WW12, LOW, GEN, SINGLE>, L, true, LOW);
+        break;
+    case K_TT4:
+        if (alt) launch_one(ge_step_kernel<K_TT4, LOW, GEN, SINGLE, HAS_ALT ? 1 : 0>, L, tt_uses_queue(4, LOW), LOW);
+        else launch_one(ge_step_kernel<K_TT4, LOW, GEN, SINGLE>, L, tt_uses_queue(4, LOW), LOW);
+        break;
+    case K_TT8:
+        if (alt) launch_one(ge_step_kernel<K_TT8, LOW, GEN, SINGLE, HAS_ALT ? 1 : 0>, L, tt_uses_queue(8, LOW), LOW);
+        else launch_one(ge_step_kernel<K_TT8, LOW, GEN, SINGLE>, L, tt_uses_queue(8, LOW), LOW);
+        break;
+    default:
+        if (alt) launch_one(ge_step_kernel<K_TT12, LOW, GEN, SINGLE, HAS_ALT ? 1 : 0>, L, tt_uses_queue(12, LOW), LOW);
+        else launch_one(ge_step_kernel<K_TT12, LOW, GEN, SINGLE>, L, tt_uses_queue(12, LOW), LOW);
+        break;
     }
 }
 template <bool LOW, int GEN> inline void launch_kind(uint32_t kind, bool single, const LaunchShape &L) {

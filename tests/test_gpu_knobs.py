@@ -21,8 +21,10 @@ NEVER_LOW, ALWAYS_LOW = {"GE_LOWOCC_ROOMS": "0"}, {"GE_LOWOCC_ROOMS": "99999999"
     (NEVER_LOW, "mixed", 2500), (ALWAYS_LOW, "mixed", 2500), (ALWAYS_LOW, "mixed", 70001),
     ({"GE_LOWOCC_ROOMS": "0", "GE_BLOCK_THREADS": "256"}, "mixed", 2500),
     ({"GE_LOWOCC_ROOMS": "99999999", "GE_BLOCK_THREADS": "128"}, "trace", 3000),
-    # the streaming-load form of the large-batch single-turn Werewolf x 8 kernel (normally only for a state beyond the Infinity Cache)
+    # the streaming-load form of the large-batch single-turn Werewolf x 8 kernel (normally only for a state beyond the Infinity Cache) ...
     ({"GE_NT_LOADS": "1", "GE_LOWOCC_ROOMS": "0"}, "trace", 3000), ({"GE_NT_LOADS": "1"}, "humans", 140001),
+    # ... and the plain-load forms of the other layouts' (normally for states of 50 - 290 MiB)
+    ({"GE_NT_LOADS": "0", "GE_LOWOCC_ROOMS": "0"}, "trace", 3000), ({"GE_NT_LOADS": "0"}, "humans", 140001),
 ], ids=lambda v: "-".join(f"{k[3:].lower()}={x}" for k, x in v.items()) if isinstance(v, dict) else str(v))
 def test_scenario_under_forced_launch_knobs(knobs, scenario, rooms):
     env = dict(os.environ, **knobs)

@@ -24,15 +24,15 @@ KEYS = {"Function Name": "name", "TotalSGPRs": "sgprs", "VGPRs": "vgprs", "AGPRs
 
 
 def describe(mangled: str) -> dict:
-    """ge_step_kernel<KIND, LOWOCC, GENERIC, SINGLE, NTL> / ge_step_kernel_mixed<LOWOCC, GENERIC, SINGLE> / the helper kernels"""
+    """ge_step_kernel<KIND, LOWOCC, GENERIC, SINGLE, LD> / ge_step_kernel_mixed<LOWOCC, GENERIC, SINGLE> / the helper kernels"""
     m = re.search(r"ge_step_kernel_mixedILb([01])ELi(\d)ELb([01])E", mangled)
     if m:
         low, gen = m.group(1) == "1", int(m.group(2))
         return {"kernel": "ge_step_kernel_mixed", "layout": "mixed batch", "lowocc": low, "generic": gen, "single": m.group(3) == "1"}
-    m = re.search(r"ge_step_kernelILi(\d)ELb([01])ELi(\d)ELb([01])ELb([01])E", mangled)
+    m = re.search(r"ge_step_kernelILi(\d)ELb([01])ELi(\d)ELb([01])ELi(\d)E", mangled)
     if m:
         return {"kernel": "ge_step_kernel", "layout": KINDS[int(m.group(1))], "lowocc": m.group(2) == "1", "generic": int(m.group(3)),
-                "single": m.group(4) == "1", "ntl": m.group(5) == "1"}
+                "single": m.group(4) == "1", "ld": int(m.group(5))}
     m = re.search(r"N_1\d+(ge_[a-z_0-9]+?)E", mangled)
     return {"kernel": m.group(1) if m else mangled, "layout": "-", "lowocc": False, "generic": False, "single": False}
 
@@ -64,7 +64,7 @@ def label(r):
     form = "single-turn" if r["single"] else "fused"
     occ = "lone-wavefront" if r["lowocc"] else "large-batch"
     shape = {0: "", 1: ", GENERIC", 2: ", GENERIC 1 x 1", 3: ", GENERIC 1 x 2"}[int(r["generic"])]
-    return f"{r['layout']}, {occ}, {form}{shape}" + (", streaming record loads" if r.get("ntl") else "")
+    return f"{r['layout']}, {occ}, {form}{shape}" + {0: "", 1: ", plain record loads", 2: ", streaming record loads"}[r.get("ld", 0)]
 
 
 def markdown(rows):

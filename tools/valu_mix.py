@@ -38,10 +38,10 @@ def price(op, args):
     return 4.15, "other half-rate (fused 3-operand, bfe, perm, bcnt, ffbl, 64-bit, DPP ...)"
 
 
-KEYS = {"ww8_1048576": ("1 048 576 Werewolf × 8", "ILi0ELb0ELi0ELb0ELb0E"), "c4": ("C4 share: 2 097 152 Werewolf × 12", "ILi1ELb0ELi0ELb0ELb0E"),
-        "c3": ("C3: 1 048 576 Two-Truths × 4", "ILi2ELb0ELi0ELb0ELb0E"),
+KEYS = {"ww8_1048576": ("1 048 576 Werewolf × 8", "ILi0ELb0ELi0ELb0ELi0E"), "c4": ("C4 share: 2 097 152 Werewolf × 12", "ILi1ELb0ELi0ELb0ELi0E"),
+        "c3": ("C3: 1 048 576 Two-Truths × 4", "ILi2ELb0ELi0ELb0ELi0E"),
         "c5": ("C5 share: 524 288 Werewolf × 8 + 524 288 Two-Truths × 4, one launch", "_mixedILb0ELi0ELb0E"),
-        "c2": ("C2: 65 536 Werewolf × 8, a lone wavefront per SIMD", "ILi0ELb1ELi0ELb0ELb0E")}
+        "c2": ("C2: 65 536 Werewolf × 8, a lone wavefront per SIMD", "ILi0ELb1ELi0ELb0ELi0E")}
 LONE = 5.2          # a lone wavefront: cycles per vector instruction of any kind (the probe's 1-wavefront column)
 OTHER = "other half-rate (fused 3-operand, bfe, perm, bcnt, ffbl, 64-bit, DPP ...)"
 
