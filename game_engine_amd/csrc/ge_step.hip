@@ -181,7 +181,12 @@ static int create_impl(const ge_batch_desc *desc, ge_batch **out, const uint64_t
     b->flags = desc->flags;
     uint64_t total = 0;
     for (uint32_t k = 0; k < desc->n_segments; k++) total += desc->seg[k].n_rooms;
-    b->block_threads = total >= (1u << 19) ? 256u : 64u;
+    // Rooms per block.  Up to four wavefronts per SIMD (262 144 rooms) 64-room blocks are as fast as any and balance best; beyond, a block's
+    // LDS (the 7 KB table image + its wavefronts' queues) caps a CU at 5 wavefronts per SIMD when every wavefront brings its own image, and
+    // the launch takes a second round: fused us per turn at 393 216 / 524 000 rooms, 64- against 256-room blocks: Werewolf x 8 3.50 / 4.66 ->
+    // 2.54 / 3.52, Two-Truths x 4 at 524 000 3.31 -> 2.35, Werewolf x 12 6.46 -> 4.87 (-24 .. -28 %; level at 262 144 and below;
+    // profiles/r05_fused_midsize.txt).  (Until round 5 the switch was at 524 288 rooms.)
+    b->block_threads = total > (1u << 18) ? 256u : 64u;
     if (const char *e = getenv("GE_BLOCK_THREADS")) {          // tuning / A-B runs: 64, 128 or 256
         const unsigned long v = strtoul(e, nullptr, 10);
         if (v == 64 || v == 128 || v == 256) b->block_threads = (uint32_t)v;
@@ -417,6 +422,17 @@ static void launch_geometry(const ge_batch *b, bool low, bool single, uint32_t &
     }();
     if (single && b->segs.size() == 1 && !b->generic && !low && bt == 256u) {
         bt = single_block_env ? single_block_env : (b->segs[0].dev.kind == K_WW8 ? 512u : 256u);
+        blocks = (uint32_t)((b->segs[0].dev.rooms + bt - 1u) / bt);
+        rpb = bt;
+    }
+    // A single-game batch of up to 262 144 rooms is cut into 64-room blocks (create_impl: more, shorter blocks balance a fused launch
+    // better).  Its single-turn launches on the large-batch kernels run 256-room blocks all the same - a quarter of the table fills:
+    // sustained us per launch, 64- against 256-room blocks (profiles/r05_k1_midsize.txt): Werewolf x 8 at 131 072 / 262 144 rooms
+    // 4.96 / 6.35 -> 4.21 / 5.40, Two-Truths x 4 at 262 144 5.14 -> 4.58, Werewolf x 12 at 131 072 / 262 144 5.80 / 7.53 -> 5.10 / 6.90
+    // (-8 .. -15 %; -29 % at 524 000 rooms, which create_impl now cuts into 256-room blocks anyway; the lone-wavefront kernels, which fill nothing, are level at 131 072 rooms and
+    // slower beyond).  A mixed batch's segments are padded to its block size, so it keeps it.
+    if (single && b->segs.size() == 1 && !low && bt < 256u && single_block_env == 0u) {
+        bt = 256u;
         blocks = (uint32_t)((b->segs[0].dev.rooms + bt - 1u) / bt);
         rpb = bt;
     }
