@@ -101,7 +101,7 @@ while time.time() < t_end:
     n = rng.randint(4, 12) if pack == 1 else rng.randint(3, 12)
     if pack == 2 and rounds * 2 * (n - 1) > 255:
         rounds = 1
-    R = rng.choice([1, 63, 64, 65, 1000, 4097, 20000, 65536, 65537, 70000, 150000])
+    R = rng.choice([1, 63, 64, 65, 1000, 4097, 20000, 65536, 65537, 70000, 150000, 300000])
     seed, first = rng.randrange(1 << 48), rng.randrange(1 << 40)
     mask = rng.choice([0, 0, 0, 1, 1 << (n - 1), 0b101]) & ((1 << n) - 1)
     restart = rng.random() < 0.8
