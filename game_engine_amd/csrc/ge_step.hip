@@ -187,6 +187,9 @@ static int create_impl(const ge_batch_desc *desc, ge_batch **out, const uint64_t
     // 2.54 / 3.52, Two-Truths x 4 at 524 000 3.31 -> 2.35, Werewolf x 12 6.46 -> 4.87 (-24 .. -28 %; level at 262 144 and below;
     // profiles/r05_fused_midsize.txt).  (Until round 5 the switch was at 524 288 rooms.)
     b->block_threads = total > (1u << 18) ? 256u : 64u;
+    // a batch that only ever runs single-turn launches (max_fuse = 1) on the large-batch kernels: 256-room blocks at once (launch_geometry does
+    // the same per launch for a single-game batch; a mixed batch's block size is fixed here, its segments are padded to it)
+    if (b->max_fuse == 1u && total > 65536u) b->block_threads = 256u;
     if (const char *e = getenv("GE_BLOCK_THREADS")) {          // tuning / A-B runs: 64, 128 or 256
         const unsigned long v = strtoul(e, nullptr, 10);
         if (v == 64 || v == 128 || v == 256) b->block_threads = (uint32_t)v;
