@@ -235,7 +235,7 @@ static int create_impl(const ge_batch_desc *desc, ge_batch **out, const uint64_t
         b->segs.push_back(s);
     }
     b->n_rooms = local; b->n_blocks = blocks; b->state_bytes = bytes;
-    // The record loads of a single-game batch's large single-turn launches, plain or streaming (non-temporal), by layout and by where the state
+    // record_loads - the record loads of a single-game batch's large single-turn launches, plain or streaming (non-temporal), by layout and by where the state
     // lives (ge_kernels.inl load_words; profiles/r05_ab_ww8_nt_loads.txt, r05_ab_nt_others.txt): beyond the 256 MiB Infinity Cache of MI355X
     // every layout streams; while the cache holds the state plain loads are served from it (+4 ... +18 % at 100 - 250 MiB), except that the
     // smallest states measured - Two-Truths at 24 MiB, Werewolf x 12 at 80 MiB - are level or 2 % better streaming.  GE_NT_LOADS=0 / 1 forces
@@ -366,7 +366,7 @@ template <bool LOW, int GEN, bool SINGLE> inline void launch_kind(uint32_t kind,
     const bool alt = HAS_ALT && L.b->stream_loads != (kind != K_WW8);      // the layouts' default: Werewolf x 8 plain, the others streaming
     switch (kind) {
     // (the large-batch single-turn kernels of the shipped games exist with plain and with streaming record loads: ALT = the form that is not the
-    // layout's default, launched when record_loads() asks for it)
+    // layout's default, launched when the batch's stream_loads (create_impl: record_loads) differs from that default)
     case K_WW8:
         if (alt) launch_one(ge_step_kernel<K_WW8, LOW, GEN, SINGLE, HAS_ALT ? 2 : 0>, L, true, LOW);
         else launch_one(ge_step_kernel<K_WW8, LOW, GEN, SINGLE>, L, true, LOW);
@@ -433,8 +433,8 @@ static void launch_geometry(const ge_batch *b, bool low, bool single, uint32_t &
     // better).  Its single-turn launches on the large-batch kernels run 256-room blocks all the same - a quarter of the table fills:
     // sustained us per launch, 64- against 256-room blocks (profiles/r05_k1_midsize.txt): Werewolf x 8 at 131 072 / 262 144 rooms
     // 4.96 / 6.35 -> 4.21 / 5.40, Two-Truths x 4 at 262 144 5.14 -> 4.58, Werewolf x 12 at 131 072 / 262 144 5.80 / 7.53 -> 5.10 / 6.90
-    // (-8 .. -15 %; -29 % at 524 000 rooms, which create_impl now cuts into 256-room blocks anyway; the lone-wavefront kernels, which fill nothing, are level at 131 072 rooms and
-    // slower beyond).  A mixed batch's segments are padded to its block size, so it keeps it.
+    // (-8 .. -15 %; -29 % at 524 000 rooms, which create_impl now cuts into 256-room blocks anyway; the lone-wavefront kernels, which fill
+    // nothing, are level at 131 072 rooms and slower beyond).  A mixed batch's segments are padded to its block size, so it keeps it.
     if (single && b->segs.size() == 1 && !low && bt < 256u && single_block_env == 0u) {
         bt = 256u;
         blocks = (uint32_t)((b->segs[0].dev.rooms + bt - 1u) / bt);
