@@ -452,6 +452,12 @@ static void launch_geometry(const ge_batch *b, bool low, bool single, uint32_t &
     if (half_fits && (half_env == 1 || (half_env != 0 && b->segs[0].dev.rooms <= 32768u))) {
         rpb = 32u;
         blocks = (uint32_t)((b->segs[0].dev.rooms + 31u) / 32u);
+    } else if (half_fits && half_env != 0 && b->segs[0].dev.rooms < 65536u) {
+        // between 32 768 and 65 536 rooms: as few rooms per wavefront as still give every SIMD at most one (49 152 rooms = 1 024 wavefronts of 48):
+        // us per turn against 64 rooms per wavefront (profiles/r05_rooms_per_wavefront.txt) Werewolf x 8 at 40 000 / 49 152 / 57 000 rooms
+        // 1.08 / 1.06 / 1.05 -> 0.98 / 0.96 / 1.02, x 12 1.51 / 1.49 / 1.49 -> 1.29 / 1.35 / 1.43, Two-Truths x 7 1.15 -> 1.01 / 1.01 / 1.09, x 4 -4 %
+        rpb = (uint32_t)((b->segs[0].dev.rooms + 1023u) / 1024u);
+        blocks = (uint32_t)((b->segs[0].dev.rooms + rpb - 1u) / rpb);
     }
 }
 

@@ -48,6 +48,9 @@ def test_golden_trajectories_fused(name):
 @pytest.mark.parametrize("game,n,n_rooms,turns,rounds", [
     ("werewolf-(mafia)", 8, 65536, 64, 1),          # BASELINE config C2
     ("werewolf-(mafia)", 12, 20000, 80, 1),
+    ("werewolf-(mafia)", 12, 40000, 70, 1),         # 32 769 .. 65 535 rooms: lone wavefronts of 33 .. 63 rooms (ge_step.hip launch_geometry)
+    ("werewolf-(mafia)", 8, 57001, 70, 1),
+    ("two-truths-and-a-lie", 7, 49152, 70, 1),
     ("werewolf-(mafia)", 4, 5000, 40, 1),
     ("werewolf-(mafia)", 9, 3001, 64, 1),
     ("draft-werewolf-(mafia)", 8, 65536, 72, 1),    # the reference's earlier Werewolf draft: own field names, two terminal phases
